@@ -1,0 +1,86 @@
+"""ctypes binding of libafd_hip.so (the C ABI declared in include/afd_hip.h).
+
+The library is built in-tree (``audiodeepfake-detection_amd/lib/libafd_hip.so``, see
+``__graft_entry__.build``).  There is no CPU fallback: if the library is missing or no
+MI355X is visible every entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libafd_hip.so")
+
+_lib: Optional[ctypes.CDLL] = None
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_u = ctypes.c_uint
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+c_l = ctypes.c_longlong
+c_ul = ctypes.c_ulonglong
+
+# name -> (restype, argtypes); mirrors include/afd_hip.h
+_SIGNATURES = {
+    "afd_last_error": (ctypes.c_char_p, []),
+    "afd_version": (c_i, []),
+    "afd_wpt_out_len": (c_i, [c_i, c_i, c_i]),
+    "afd_wpt_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
+    "afd_wpt_forward": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i,
+                              c_u, c_f, c_f, c_f, c_f, c_p, c_p, c_sz, c_p]),
+}
+
+
+def signatures():
+    return dict(_SIGNATURES)
+
+
+def load() -> ctypes.CDLL:
+    """Load libafd_hip.so and declare every prototype; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libafd_hip.so not found at {LIB_PATH}: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C audiodeepfake-detection_amd/csrc). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().afd_last_error().decode(errors="replace")
+        raise RuntimeError(f"libafd_hip {what} failed ({rc}): {msg}")
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "audiofakedetect (MI355X build) needs a visible gfx950 GPU; there is no CPU path."
+        )
+
+
+def stream_ptr() -> c_p:
+    return c_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> c_p:
+    return c_p(0) if t is None else c_p(t.data_ptr())
+
+
+def float_array(vals):
+    return (c_f * len(vals))(*[float(v) for v in vals])

@@ -1,0 +1,282 @@
+"""Transform plugin of the hot path: wavelet packets / STFT -> normalise (MI355X host side).
+
+Keeps the public surface of the reference's ``src/audiofakedetect/wavelet_math.py``
+(``Packets`` :223-263, ``STFTLayer`` :25-68, ``compute_pytorch_packet_representation``
+:167-220, ``get_transforms`` :266-384, ``calc_normalization`` :387-452); the arithmetic is
+one HIP launch per batch in ``libafd_hip.so`` (``afd_wpt_forward`` / ``afd_stft_forward``).
+There is no CPU path: inputs are moved to the GPU, and a missing library or GPU raises.
+"""
+
+from __future__ import annotations
+
+import os
+import pickle
+from math import log
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native
+from .data_loader import WelfordEstimator, get_costum_dataset
+from .utils import DotDict
+from .wavelets import Wavelet
+
+_WPT_LOG, _WPT_SIGN, _WPT_NORM = 1, 2, 4
+_STFT_LOG, _STFT_NORM = 1, 4
+
+
+def _as_frames(x: torch.Tensor) -> torch.Tensor:
+    """[B,1,N] / [B,N] / [1,N] / [N] -> contiguous f32 [B,N] on the GPU."""
+    _native.require_gpu()
+    if x.dim() == 3:
+        if x.shape[1] != 1:
+            raise ValueError(f"expected mono frames [B,1,N], got {tuple(x.shape)}")
+        x = x[:, 0, :]
+    elif x.dim() == 1:
+        x = x.unsqueeze(0)
+    elif x.dim() != 2:
+        raise ValueError(f"expected [B,1,N] or [B,N] frames, got {tuple(x.shape)}")
+    if not x.is_cuda:
+        x = x.cuda(non_blocking=True)
+    return x.to(torch.float32).contiguous()
+
+
+def wpt_forward(
+    frames: torch.Tensor,
+    wavelet: Wavelet,
+    max_lev: int,
+    log_scale: bool = False,
+    loss_less: bool = False,
+    power: float = 2.0,
+    mean: Optional[float] = None,
+    std: Optional[float] = None,
+) -> torch.Tensor:
+    """Launch the fused packet transform; returns memory-order [B, C, T, P]."""
+    lib = _native.load()
+    x = _as_frames(frames)
+    b, n = x.shape
+    length = wavelet.dec_len
+    t_len = lib.afd_wpt_out_len(n, length, max_lev)
+    if t_len <= 0:
+        raise ValueError(f"wavelet packets: level {max_lev} is not defined for N={n}, L={length}")
+    flags = 0
+    nch = 1
+    if log_scale:
+        flags |= _WPT_LOG
+        if loss_less:
+            flags |= _WPT_SIGN
+            nch = 2
+    if mean is not None:
+        flags |= _WPT_NORM
+    out = torch.empty((b, nch, t_len, 1 << max_lev), dtype=torch.float32, device=x.device)
+    rc = lib.afd_wpt_forward(
+        _native.ptr(x), b, n, _native.float_array(wavelet.dec_lo),
+        _native.float_array(wavelet.dec_hi), length, max_lev, flags, float(power), 1e-12,
+        float(mean or 0.0), float(std if std is not None else 1.0), _native.ptr(out),
+        None, 0, _native.stream_ptr(),
+    )
+    _native.check(rc, "afd_wpt_forward")
+    return out
+
+
+def compute_pytorch_packet_representation(
+    pt_data: torch.Tensor,
+    wavelet: Wavelet,
+    max_lev: int = 8,
+    log_scale: bool = False,
+    loss_less: bool = False,
+    power: float = 2.0,
+    block_norm: bool = False,
+    compute_welford: bool = False,
+    block_norm_dict=None,
+) -> Tuple[torch.Tensor, dict]:
+    """Packet image [B, C, T, P] (+ the per-node statistics dict of the reference API).
+
+    The reference updates one Welford estimator per node on every call
+    (wavelet_math.py:194-200) although the result is only read when ``--block-norm`` is set;
+    here the dict is passed through untouched unless block normalisation is requested.
+    """
+    if block_norm:
+        raise NotImplementedError(
+            "block_norm (per-packet max normalisation, wavelet_math.py:202-203) is not part "
+            "of this round's hot path (SURVEY.md 8(f-1))."
+        )
+    if block_norm_dict is None:
+        block_norm_dict = {}
+    out = wpt_forward(pt_data, wavelet, max_lev, log_scale, loss_less, power)
+    return out, block_norm_dict
+
+
+class Packets(torch.nn.Module):
+    """Wavelet-packet representation as a module (reference wavelet_math.py:223-263)."""
+
+    def __init__(
+        self,
+        wavelet_str: str = "sym8",
+        max_lev: int = 8,
+        log_scale: bool = False,
+        loss_less: bool = False,
+        power: float = 2.0,
+        block_norm: bool = False,
+        compute_welford: bool = False,
+        block_norm_dict=None,
+    ) -> None:
+        super().__init__()
+        self.wavelet = Wavelet(wavelet_str)
+        self.max_lev = max_lev
+        self.log_scale = log_scale
+        self.loss_less = loss_less
+        self.power = power
+        self.block_norm = block_norm
+        self.compute_welford = compute_welford
+        self.block_norm_dict = block_norm_dict
+        # set by fuse_normalization(): (mean, std) applied in the kernel epilogue
+        self.fused_norm: Optional[Tuple[float, float]] = None
+
+    def forward(self, pt_data: torch.Tensor) -> Tuple[torch.Tensor, dict]:
+        if self.block_norm:
+            raise NotImplementedError("block_norm is not part of this round's hot path")
+        mean, std = self.fused_norm if self.fused_norm is not None else (None, None)
+        packets = wpt_forward(pt_data, self.wavelet, self.max_lev, self.log_scale,
+                              self.loss_less, self.power, mean, std)
+        bdict = self.block_norm_dict if self.block_norm_dict is not None else {}
+        # logical [B, C, P, T]; memory stays [B, C, T, P] exactly like the reference's view
+        return packets.permute(0, 1, 3, 2), bdict
+
+
+class STFTLayer(torch.nn.Module):
+    """Power spectrogram (reference wavelet_math.py:25-68; torchaudio Spectrogram defaults)."""
+
+    def __init__(self, n_fft: int = 511, hop_length: int = 220, log_offset: float = 1e-12,
+                 log_scale: bool = False, power: float = 2.0) -> None:
+        super().__init__()
+        self.n_fft = n_fft
+        self.hop_length = hop_length
+        self.log_scale = log_scale
+        self.log_offset = log_offset
+        self.power = power
+        self.block_norm_dict = None
+        self.fused_norm: Optional[Tuple[float, float]] = None
+        self._basis: Optional[torch.Tensor] = None
+
+    def forward(self, input: torch.Tensor) -> Tuple[torch.Tensor, None]:
+        from .stft import stft_forward
+
+        mean, std = self.fused_norm if self.fused_norm is not None else (None, None)
+        spec = stft_forward(self, input, mean, std)
+        return spec, None
+
+
+class Normalize(torch.nn.Module):
+    """``torchvision.transforms.Normalize`` with scalar statistics (wavelet_math.py:380-382)."""
+
+    def __init__(self, mean, std) -> None:
+        super().__init__()
+        self.mean = float(mean.reshape(-1)[0]) if torch.is_tensor(mean) else float(mean)
+        self.std = float(std.reshape(-1)[0]) if torch.is_tensor(std) else float(std)
+        if self.std == 0.0:
+            raise ValueError("std evaluated to zero")
+        self.identity = False  # True once the statistics are fused into the transform
+
+    def forward(self, t: torch.Tensor) -> torch.Tensor:
+        if self.identity:
+            return t
+        from .ops import normalize_forward
+
+        return normalize_forward(t, self.mean, self.std)
+
+
+def fuse_normalization(transforms: torch.nn.Sequential, normalize: torch.nn.Sequential) -> bool:
+    """Move the scalar (x - mean) / std into the transform kernel's epilogue.
+
+    Saves the clone + two elementwise passes of the reference's Normalize.  Returns False
+    (and changes nothing) when the pair cannot be fused.
+    """
+    if len(transforms) != 1 or len(normalize) != 1:
+        return False
+    tr, nm = transforms[0], normalize[0]
+    if not isinstance(nm, Normalize) or not hasattr(tr, "fused_norm"):
+        return False
+    tr.fused_norm = (nm.mean, nm.std)
+    nm.identity = True
+    return True
+
+
+def get_transforms(
+    args: DotDict,
+    features: str,
+    device: str,
+    normalization: bool,
+    pbar: bool = False,
+    verbose: bool = True,
+) -> Tuple[torch.nn.Sequential, torch.nn.Sequential]:
+    """Build the frequency-space transform and the normalisation (wavelet_math.py:266-384)."""
+    if features not in (None, "none"):
+        raise NotImplementedError("lfcc/delta features are outside the hot path (SURVEY.md #13)")
+    log_scale = bool(args.features == "none" and args.log_scale)
+    if args.transform == "stft":
+        transform: torch.nn.Module = STFTLayer(
+            n_fft=args.num_of_scales * 2 - 1, hop_length=args.hop_length,
+            log_scale=log_scale, power=args.power,
+        )
+    elif args.transform == "packets":
+        transform = Packets(
+            wavelet_str=args.wavelet, max_lev=int(log(args.num_of_scales, 2)),
+            log_scale=log_scale, loss_less=False if args.loss_less == "False" else True,
+            power=args.power, block_norm_dict=None, block_norm=False, compute_welford=True,
+        )
+    else:
+        raise ValueError(f"unknown transform {args.transform!r}")
+    transforms = torch.nn.Sequential(transform)
+
+    loss_less = "_loss_less" if args.loss_less == "True" else ""
+    norm_dir = "{}/norms/{}_{}_{}_{}_{}_{}{}_{}_{}secs".format(
+        args.log_dir, str(args.data_path).replace("/", "_"), "-".join(args.only_use or []),
+        args.transform, args.wavelet, args.num_of_scales, args.power, loss_less,
+        args.sample_rate, args.seconds,
+    )
+    if args.block_norm:
+        raise NotImplementedError("block_norm is not part of this round's hot path")
+    if os.path.exists(f"{norm_dir}_mean_std.pkl"):
+        if verbose:
+            print("Loading pre calculated mean and std from file.")
+        with open(f"{norm_dir}_mean_std.pkl", "rb") as file:
+            mean, std = pickle.load(file)
+        mean = torch.from_numpy(np.asarray(mean, dtype=np.float32))
+        std = torch.from_numpy(np.asarray(std, dtype=np.float32))
+    elif normalization:
+        if verbose:
+            print("computing mean and std values.", flush=True)
+        _, mean, std = calc_normalization(args, pbar, transforms, norm_dir)
+    else:
+        if verbose:
+            print("Using default mean and std.")
+        mean = torch.tensor(args.mean if args.mean is not None else 0.0)
+        std = torch.tensor(args.std if args.std is not None else 1.0)
+    normalize = torch.nn.Sequential(Normalize(mean, std))
+    return transforms, normalize
+
+
+def calc_normalization(args: DotDict, pbar: bool, transforms: torch.nn.Sequential,
+                       norm_dir: str) -> tuple:
+    """Scalar mean / std of the transformed training set (wavelet_math.py:387-452)."""
+    dataset = get_costum_dataset(
+        data_path=args.data_path, ds_type="train", only_use=args.only_use,
+        save_path=args.save_path, limit=args.limit_train[0] if args.limit_train else None,
+        file_type=args.file_type, resample_rate=args.sample_rate, seconds=args.seconds,
+        synthetic=bool(args.synthetic),
+    )
+    loader = torch.utils.data.DataLoader(dataset, batch_size=4000, shuffle=False,
+                                         num_workers=0)
+    welford = WelfordEstimator()
+    welford_dict = None
+    with torch.no_grad():
+        for batch in loader:
+            feats, welford_dict = transforms(batch["audio"].cuda(non_blocking=True))
+            welford.update(feats.permute(0, 3, 2, 1))
+        mean, std = welford.finalize()
+    os.makedirs(os.path.dirname(norm_dir), exist_ok=True)
+    with open(f"{norm_dir}_mean_std.pkl", "wb") as f:
+        pickle.dump([mean.cpu().numpy(), std.cpu().numpy()], f)
+    return welford_dict, mean, std

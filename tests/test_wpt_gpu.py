@@ -1,0 +1,158 @@
+"""GPU parity of the fused wavelet-packet kernel (through the C ABI) against the oracle.
+
+Tolerances (fp32 kernel vs float64 oracle; the reference itself computes in fp32):
+  coefficients : max|gpu - ref| <= 5e-6 * max|ref|                      (COEF_RTOL)
+  log features : |gpu - ref| <= 1e-5 + 2|x| d / (x^2 + 1e-12), d = COEF_RTOL * max|x|
+                 (first-order bound of log(x^2+eps) under a coefficient error d: the log
+                 is ill-conditioned at zero crossings for the reference as well)
+  sign channel : bit-exact wherever |x| > d
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from audiofakedetect import wavelets
+from audiofakedetect.wavelet_math import Packets, compute_pytorch_packet_representation
+from oracle import wpt_oracle
+
+pytestmark = pytest.mark.gpu
+COEF_RTOL = 5e-6
+N = 22050
+
+
+def _parity_inputs(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = (0.1 * torch.randn(3, N, generator=g)).clamp_(-1, 1)
+    t = torch.arange(N) / 22050.0
+    tone = sum(torch.sin(2 * np.pi * f * t) for f in (440.0, 3000.0, 7500.0, 10500.0)) / 4
+    imp = torch.zeros(3, N)
+    imp[0, 0] = 1.0
+    imp[1, 11025] = 1.0
+    imp[2, 22049] = 1.0
+    return torch.cat([x, tone[None], imp], 0)
+
+
+def _check_coeffs(got, ref):
+    scale = np.max(np.abs(ref))
+    err = np.max(np.abs(got - ref))
+    assert err <= COEF_RTOL * scale, f"coef err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("name,level", [
+    ("haar", 1), ("haar", 2), ("haar", 8), ("haar", 14),
+    ("sym5", 3), ("sym5", 8), ("sym5", 14),
+    ("coif4", 1), ("coif4", 8), ("coif4", 9), ("coif4", 14),
+    ("db8", 7), ("db2", 10), ("db3", 5),
+])
+def test_coefficients_match_oracle(name, level):
+    x = _parity_inputs()
+    w = wavelets.Wavelet(name)
+    got, _ = Packets(name, max_lev=level)(x.cuda())
+    ref = wpt_oracle.packet_features(x.double().numpy(), w.dec_lo, level)
+    assert tuple(got.shape) == ref.shape
+    _check_coeffs(got.cpu().double().numpy(), ref)
+
+
+@pytest.mark.parametrize("name,level", [("sym5", 8), ("coif4", 8), ("coif4", 14), ("haar", 14)])
+def test_log_power_and_sign_channel(name, level):
+    x = _parity_inputs(seed=1)[:4]
+    w = wavelets.Wavelet(name)
+    got, _ = Packets(name, max_lev=level, log_scale=True, loss_less=True)(x.cuda())
+    got = got.cpu().double().numpy()
+    coef = wpt_oracle.packet_features(x.double().numpy(), w.dec_lo, level)[:, 0]
+    ref = wpt_oracle.packet_features(x.double().numpy(), w.dec_lo, level, log_scale=True,
+                                     loss_less=True)
+    assert got.shape == ref.shape and got.shape[1] == 2
+    d = COEF_RTOL * np.max(np.abs(coef))
+    bound = 1e-5 + 2 * np.abs(coef) * d / (coef ** 2 + 1e-12) + 2e-6 * np.abs(ref[:, 0])
+    assert np.all(np.abs(got[:, 0] - ref[:, 0]) <= bound)
+    sure = np.abs(coef) > d
+    assert np.array_equal(got[:, 1][sure], ref[:, 1][sure])
+    assert set(np.unique(got[:, 1])) <= {-1.0, 1.0}
+
+
+def test_input_forms_and_layout():
+    x = _parity_inputs()[:2]
+    p = Packets("sym5", max_lev=8, log_scale=True)
+    a, d = p(x.cuda())
+    b, _ = p(x.unsqueeze(1).cuda())
+    c, _ = p(x[:1])  # CPU [1, N] as get_input_dims passes it (reference utils.py:606-612)
+    assert isinstance(d, dict)
+    assert a.shape == (2, 1, 256, 95) and not a.is_contiguous()
+    assert a.permute(0, 1, 3, 2).is_contiguous()  # memory order [B, C, T, P]
+    assert torch.equal(a, b) and torch.equal(a[:1], c)
+    raw, _ = compute_pytorch_packet_representation(x.cuda(), wavelets.Wavelet("sym5"), 8)
+    assert raw.shape == (2, 1, 95, 256)
+
+
+def test_reference_test_shapes():
+    # reference tests/test_transforms.py:54-142 (db8 / 16-tap, level 7)
+    x = torch.randn(2, 22050)
+    out, d = compute_pytorch_packet_representation(x, wavelets.Wavelet("db8"), max_lev=7,
+                                                   log_scale=True, compute_welford=True)
+    assert out.shape == (2, 1, 187, 128) and d is not None
+    out, _ = compute_pytorch_packet_representation(x, wavelets.Wavelet("db8"), max_lev=7,
+                                                   log_scale=True, loss_less=True)
+    assert out.shape == (2, 2, 187, 128)
+    out, _ = Packets("db8", max_lev=7, log_scale=True)(x)
+    assert out.shape == (2, 1, 128, 187)
+
+
+def test_fused_normalisation():
+    x = _parity_inputs()[:2].cuda()
+    p = Packets("coif4", max_lev=8, log_scale=True)
+    plain, _ = p(x)
+    p.fused_norm = (-9.5, 3.25)
+    fused, _ = p(x)
+    assert torch.allclose(fused, (plain - (-9.5)) / 3.25, atol=1e-6, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n", [22051, 16000, 4097])
+def test_other_frame_lengths(n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(2, n, generator=g)
+    for name, level in (("sym5", 6), ("haar", 9)):
+        got, _ = Packets(name, max_lev=level)(x.cuda())
+        ref = wpt_oracle.packet_features(x.double().numpy(), wavelets.Wavelet(name).dec_lo, level)
+        _check_coeffs(got.cpu().double().numpy(), ref)
+
+
+def test_full_size_properties_coif4_l14_b128():
+    """BASELINE config 2 size: batch independence, linearity, energy."""
+    g = torch.Generator().manual_seed(42)
+    x = (0.1 * torch.randn(128, 1, N, generator=g)).clamp_(-1, 1).cuda()
+    p = Packets("coif4", max_lev=14)
+    full, _ = p(x)
+    assert full.shape == (128, 1, 16384, 24)
+    for b in (0, 77, 127):
+        one, _ = p(x[b])
+        assert torch.equal(one[0], full[b])
+    y = torch.roll(x, 1, 0)
+    lin, _ = p(0.5 * x + 2.0 * y)
+    comb = 0.5 * full + 2.0 * torch.roll(full, 1, 0)
+    assert (lin - comb).abs().max() <= 2e-5 * comb.abs().max()
+    ref = wpt_oracle.packet_features(x[5].double().cpu().numpy(), wavelets.Wavelet("coif4").dec_lo, 14)
+    _check_coeffs(full[5:6].cpu().double().numpy(), ref)
+
+
+def test_full_size_haar_l14_b4096_properties():
+    """BASELINE config 4 size: orthogonality -> energy, batch independence."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(4096, N, generator=g, device="cuda") * 0.1
+    p = Packets("haar", max_lev=14)
+    full, _ = p(x)
+    assert full.shape == (4096, 1, 16384, 2)
+    one, _ = p(x[4000:4001])
+    assert torch.equal(one[0], full[4000])
+    ref = wpt_oracle.packet_features(x[17:18].double().cpu().numpy(), wpt_oracle.HAAR, 14)
+    _check_coeffs(full[17:18].cpu().double().numpy(), ref)
+
+
+def test_bad_arguments_raise():
+    with pytest.raises(ValueError):
+        Packets("nope", max_lev=3)
+    with pytest.raises(ValueError):
+        Packets("coif4", max_lev=3)(torch.randn(2, 20).cuda())  # pad >= node length
+    with pytest.raises(ValueError):
+        Packets("haar", max_lev=3)(torch.randn(2, 2, 100).cuda())
