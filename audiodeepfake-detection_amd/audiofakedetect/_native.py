@@ -34,6 +34,25 @@ _SIGNATURES = {
     "afd_wpt_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "afd_wpt_forward": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i,
                               c_u, c_f, c_f, c_f, c_f, c_p, c_p, c_sz, c_p]),
+    "afd_conv2d_workspace_bytes": (c_sz, [c_i] * 8),
+    "afd_conv2d_forward": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
+    "afd_conv2d_backward_data": (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
+    "afd_conv2d_backward_weight": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
+    "afd_normalize_forward": (c_i, [c_p, c_p, c_sz, c_f, c_f, c_p]),
+    "afd_transpose_last2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "afd_prelu_dropout_forward": (c_i, [c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),
+    "afd_prelu_dropout_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),
+    "afd_prelu_pool_forward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "afd_prelu_pool_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "afd_bn_stats": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "afd_bn_apply_forward": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_p]),
+    "afd_bn_backward_stats": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_p]),
+    "afd_bn_backward_apply": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_p]),
+    "afd_dropout_permute": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_ul, c_i, c_p]),
+    "afd_linear_mean_forward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "afd_linear_mean_backward": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),
+    "afd_cross_entropy": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    "afd_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
 }
 
 

@@ -1,0 +1,119 @@
+"""Model plugin of the hot path: DCNN (and the ``get_model`` factory) on libafd_hip.
+
+Keeps the reference's plugin contract (``src/audiofakedetect/models.py``): a module class
+takes ``args: DotDict`` (reads ``input_dim, ochannels1..5, kernel1, dropout_cnn,
+dropout_lstm, time_dim_add, flattend_size, ddp``, models.py:255-299), maps
+``x[B, C, P, T] -> logits[B, 2]``, has ``get_name()``, and its ``state_dict()`` carries the
+reference's key names (``cnn.N.*``, ``dil_conv.N.*``, ``fc.1.*``) so the shipped
+checkpoints load after stripping ``module.``.
+
+The torch.nn layer objects below only HOLD parameters / buffers (and give the reference's
+default initialisation); ``forward`` never calls them -- it drives the fused HIP kernels:
+conv (MFMA implicit GEMM) -> [PReLU+MaxPool] -> BatchNorm with the PReLU folded into its
+input, dropout folded into the cnn->dil_conv permute, Linear+mean in one kernel.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .utils import DotDict
+
+
+class DCNN(nn.Module):
+    """Deep CNN with dilated convolutions (reference models.py:240-317)."""
+
+    def __init__(self, args: DotDict) -> None:
+        super().__init__()
+        oc = [args.input_dim[1], args.ochannels1, args.ochannels2, args.ochannels3,
+              args.ochannels4, args.ochannels5, 64]
+        # (kernel, padding, pooled, normalised) per conv block
+        blocks = ((args.kernel1, 2, True, True), (1, 0, False, True), (3, 1, True, True),
+                  (3, 1, False, True), (3, 1, False, True), (3, 1, True, False))
+        layers = []
+        self._cnn_plan = []  # (conv idx, prelu idx, pooled, bn idx or None)
+        for i, (k, pad, pooled, normed) in enumerate(blocks):
+            conv_i = len(layers)
+            layers += [nn.Conv2d(oc[i], oc[i + 1], k, stride=1, padding=pad), nn.PReLU()]
+            if pooled:
+                layers.append(nn.MaxPool2d(2, 2))
+            bn_i = None
+            if normed:
+                bn_i = len(layers)
+                layers.append(nn.BatchNorm2d(oc[i + 1], affine=False))
+            self._cnn_plan.append((conv_i, conv_i + 1, pooled, bn_i))
+        layers.append(nn.Dropout(args.dropout_cnn))
+        self.cnn = nn.Sequential(*layers)
+
+        time_dim = args.input_dim[-1] // 8 + args.time_dim_add
+        dil = []
+        for k, pad, d in ((3, 1, 1), (5, 2, 2), (7, 2, 4)):
+            dil += [nn.BatchNorm2d(time_dim, affine=True),
+                    nn.Conv2d(time_dim, time_dim, k, 1, padding=pad, dilation=d), nn.PReLU()]
+        dil.append(nn.Dropout(args.dropout_lstm))
+        self.dil_conv = nn.Sequential(*dil)
+        self.fc = nn.Sequential(nn.Flatten(2), nn.Linear(args.flattend_size, 2))
+        self.single_gpu = not args.ddp
+        self.sync_bn = bool(args.ddp)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        # [batch, channels, packets, time] -> NCHW [batch, channels, time, packets]
+        h = x.permute(0, 1, 3, 2)
+        if not h.is_contiguous():
+            # STFT features are dense [B, C, F, T]: one tiled transpose on the GPU
+            h = ops.transpose_contiguous(x.contiguous())
+        cnn = self.cnn
+        for conv_i, prelu_i, pooled, bn_i in self._cnn_plan:
+            conv = cnn[conv_i]
+            slope = cnn[prelu_i].weight
+            z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
+            if pooled:
+                h = ops.prelu_maxpool2x2(z, slope)
+                if bn_i is not None:
+                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
+            else:
+                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn)
+        # Dropout + [batch, channels, time, packets] -> [batch, time, channels, packets]
+        h = ops.dropout_permute(h, cnn[-1].p, self.training)
+        dil = self.dil_conv
+        slope = None
+        z = h
+        for j in range(3):
+            bn, conv = dil[3 * j], dil[3 * j + 1]
+            h = ops.batch_norm(z, bn, slope, self.sync_bn)
+            z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
+            slope = dil[3 * j + 2].weight
+        h = ops.prelu_dropout(z, slope, dil[-1].p, self.training)
+        lin = self.fc[1]
+        b, td = h.shape[0], h.shape[1]
+        return ops.linear_mean(h.reshape(b, td, -1), lin.weight, lin.bias)
+
+    def get_name(self) -> str:
+        return "DCNN"
+
+
+def strip_ddp_prefix(state_dict: dict) -> dict:
+    """Checkpoints of the reference carry ``module.module.`` (double DDP wrap)."""
+    out = {}
+    for k, v in state_dict.items():
+        while k.startswith("module."):
+            k = k[len("module."):]
+        out[k] = v
+    return out
+
+
+def get_model(args: DotDict, model_name: str, nclasses: int = 2, in_channels: int = 1,
+              lead: bool = False) -> nn.Module:
+    """Model factory (reference models.py:710-765); 'modules' instantiates ``args.module``."""
+    if model_name == "modules":
+        model = args.module(args)
+    elif model_name == "lcnn":
+        from .lcnn import LCNN
+
+        model = LCNN(classes=nclasses, in_channels=in_channels,
+                     lstm_channels=args.num_of_scales if args.features == "none" else 60)
+    else:
+        raise NotImplementedError(f"Model {model_name!r} is outside the hot path (SURVEY.md #16)")
+    return model

@@ -1,0 +1,462 @@
+"""torch.autograd bindings of the libafd_hip layer kernels (host plumbing only).
+
+Every function here marshals ``data_ptr()`` + the current HIP stream into one or two C-ABI
+calls (``include/afd_hip.h``); no arithmetic on activations happens in PyTorch.  The small
+per-channel vectors of BatchNorm (mean / invstd / running statistics, C <= 128 values) and
+the cross-rank reductions go through torch / torch.distributed.
+"""
+
+from __future__ import annotations
+
+import itertools
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _native
+
+_ws_cache: dict = {}
+_seed_counter = itertools.count(1)
+
+
+def _lib():
+    return _native.load()
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch buffer per device (conv weight slabs / wgrad partial slabs)."""
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def next_seed() -> int:
+    """Seed of the next dropout mask: a function of torch's seed and a call counter."""
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) \
+        & 0x7FFFFFFFFFFFFFFF
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def normalize_forward(t: torch.Tensor, mean: float, std: float) -> torch.Tensor:
+    """(t - mean) / std, out of place, in the memory order of `t`."""
+    _native.require_gpu()
+    src = t
+    perm = None
+    if not t.is_contiguous():
+        # features come as a permuted view of a dense buffer: normalise the buffer
+        if t.dim() == 4 and t.permute(0, 1, 3, 2).is_contiguous():
+            src = t.permute(0, 1, 3, 2)
+            perm = (0, 1, 3, 2)
+        else:
+            src = t.contiguous()
+    src = src if src.is_cuda else src.cuda()
+    out = torch.empty_like(src)
+    _native.check(_lib().afd_normalize_forward(_native.ptr(src), _native.ptr(out), src.numel(),
+                                               float(mean), float(std), _native.stream_ptr()),
+                  "afd_normalize_forward")
+    return out.permute(*perm) if perm else out
+
+
+def transpose_last2(x: torch.Tensor) -> torch.Tensor:
+    """Contiguous [.., C, R] from contiguous [.., R, C]."""
+    r, c = x.shape[-2], x.shape[-1]
+    planes = x.numel() // (r * c)
+    out = torch.empty(x.shape[:-2] + (c, r), dtype=x.dtype, device=x.device)
+    _native.check(_lib().afd_transpose_last2(_native.ptr(x), _native.ptr(out), planes, r, c,
+                                             _native.stream_ptr()), "afd_transpose_last2")
+    return out
+
+
+class _Transpose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return transpose_last2(_f32c(x))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return transpose_last2(_f32c(dy))
+
+
+def transpose_contiguous(x: torch.Tensor) -> torch.Tensor:
+    return _Transpose.apply(x)
+
+
+# --------------------------------------------------------------------------------------
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, pad, dil):
+        lib = _lib()
+        x = _f32c(x)
+        w = _f32c(w)
+        n, cin, h, wd = x.shape
+        cout, _, k, _ = w.shape
+        ho = h + 2 * pad - dil * (k - 1)
+        wo = wd + 2 * pad - dil * (k - 1)
+        if ho < 1 or wo < 1:
+            raise ValueError(f"conv2d: empty output for input {tuple(x.shape)}, k={k}, pad={pad}, dil={dil}")
+        y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
+        nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
+        ws = _ws(nbytes, x.device)
+        _native.check(lib.afd_conv2d_forward(
+            _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(y), n, cin, h, wd, cout, k,
+            pad, dil, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_forward")
+        ctx.save_for_backward(x, w)
+        ctx.geom = (n, cin, h, wd, cout, k, pad, dil)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, w = ctx.saved_tensors
+        n, cin, h, wd, cout, k, pad, dil = ctx.geom
+        dy = _f32c(dy)
+        nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
+        ws = _ws(nbytes, x.device)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _native.check(lib.afd_conv2d_backward_data(
+                _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
+                _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            _native.check(lib.afd_conv2d_backward_weight(
+                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
+                cout, k, pad, dil, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+                "afd_conv2d_backward_weight")
+        return dx, dw, db, None, None
+
+
+def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1):
+    return _Conv2d.apply(x, w, b, int(padding), int(dilation))
+
+
+# --------------------------------------------------------------------------------------
+class _PReLUPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, slope):
+        lib = _lib()
+        z = _f32c(z)
+        n, c, h, w = z.shape
+        u = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=z.device)
+        idx = torch.empty((n, c, h // 2, w // 2), dtype=torch.uint8, device=z.device)
+        _native.check(lib.afd_prelu_pool_forward(_native.ptr(z), _native.ptr(slope), _native.ptr(u),
+                                                 _native.ptr(idx), n * c, h, w,
+                                                 _native.stream_ptr()), "afd_prelu_pool_forward")
+        ctx.save_for_backward(z, idx, slope if slope is not None else torch.empty(0))
+        ctx.has_slope = slope is not None
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        lib = _lib()
+        z, idx, slope = ctx.saved_tensors
+        slope = slope if ctx.has_slope else None
+        n, c, h, w = z.shape
+        du = _f32c(du)
+        dz = torch.empty_like(z)
+        dslope = torch.zeros(1, dtype=torch.float32, device=z.device) if ctx.has_slope else None
+        _native.check(lib.afd_prelu_pool_backward(
+            _native.ptr(z), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(dz),
+            _native.ptr(dslope), n * c, h, w, _native.stream_ptr()), "afd_prelu_pool_backward")
+        return dz, dslope
+
+
+def prelu_maxpool2x2(z, slope: Optional[torch.Tensor]):
+    """MaxPool2d(2,2)(PReLU(z)); slope=None -> plain max pool."""
+    return _PReLUPool.apply(z, slope)
+
+
+# --------------------------------------------------------------------------------------
+def _dist_on(sync: bool) -> bool:
+    return sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
+                eps, sync):
+        lib = _lib()
+        x = _f32c(x)
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        dev = x.device
+        count = float(n * hw)
+        if training:
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c,
+                                           hw, _native.stream_ptr()), "afd_bn_stats")
+            if _dist_on(sync):
+                sums[2 * c] = count
+                dist.all_reduce(sums)
+                cnt = sums[2 * c]
+            else:
+                cnt = torch.tensor(count, dtype=torch.float64, device=dev)
+            mean64 = sums[:c] / cnt
+            var64 = (sums[c:2 * c] / cnt - mean64 * mean64).clamp_(min=0.0)
+            mean = mean64.float()
+            invstd = torch.rsqrt(var64 + eps).float()
+            if running_mean is not None:
+                with torch.no_grad():
+                    mom = momentum
+                    if nbt is not None:
+                        nbt += 1
+                        if mom is None:
+                            mom = 1.0 / float(nbt)
+                    unbiased = var64 * (cnt / (cnt - 1.0).clamp_(min=1.0))
+                    running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+                    running_var.mul_(1.0 - mom).add_(unbiased.float(), alpha=mom)
+            ctx.count = cnt
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        y = torch.empty_like(x)
+        _native.check(lib.afd_bn_apply_forward(
+            _native.ptr(x), _native.ptr(slope), _native.ptr(mean), _native.ptr(invstd),
+            _native.ptr(gamma), _native.ptr(beta), _native.ptr(y), n, c, hw, _native.stream_ptr()),
+            "afd_bn_apply_forward")
+        empty = torch.empty(0)
+        ctx.save_for_backward(x, slope if slope is not None else empty, mean, invstd,
+                              gamma if gamma is not None else empty)
+        ctx.flags = (slope is not None, gamma is not None, training, sync)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib()
+        x, slope, mean, invstd, gamma = ctx.saved_tensors
+        has_slope, has_gamma, training, sync = ctx.flags
+        if not training:
+            raise RuntimeError("BatchNorm backward in eval mode is not part of the hot path")
+        slope = slope if has_slope else None
+        gamma = gamma if has_gamma else None
+        n, c = x.shape[0], x.shape[1]
+        hw = x.numel() // (n * c)
+        dy = _f32c(dy)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+        _native.check(lib.afd_bn_backward_stats(
+            _native.ptr(x), _native.ptr(slope), _native.ptr(dy), _native.ptr(mean),
+            _native.ptr(invstd), _native.ptr(sums), n, c, hw, _native.stream_ptr()),
+            "afd_bn_backward_stats")
+        dgamma = dbeta = None
+        if has_gamma:
+            dbeta = sums[:c].float()
+            dgamma = sums[c:].float()
+        if _dist_on(sync):
+            sums = sums.clone()
+            dist.all_reduce(sums)
+        mdy = (sums[:c] / ctx.count).float()
+        mdyx = (sums[c:] / ctx.count).float()
+        dx = torch.empty_like(x)
+        dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
+        _native.check(lib.afd_bn_backward_apply(
+            _native.ptr(x), _native.ptr(slope), _native.ptr(dy), _native.ptr(mean),
+            _native.ptr(invstd), _native.ptr(gamma), _native.ptr(mdy), _native.ptr(mdyx),
+            _native.ptr(dx), _native.ptr(dslope), n, c, hw, _native.stream_ptr()),
+            "afd_bn_backward_apply")
+        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True):
+    """BatchNorm (batch statistics across all ranks when a process group is up) of
+    PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats."""
+    training = bn.training or bn.running_mean is None
+    return _BatchNorm.apply(x, slope, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync)
+
+
+# --------------------------------------------------------------------------------------
+class _DropoutPermute(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _f32c(x)
+        b, c, h, w = x.shape
+        y = torch.empty((b, h, c, w), dtype=torch.float32, device=x.device)
+        _native.check(_lib().afd_dropout_permute(_native.ptr(x), _native.ptr(y), b, c, h, w, p, seed,
+                                                 0, _native.stream_ptr()), "afd_dropout_permute")
+        ctx.cfg = (b, c, h, w, p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, h, w, p, seed = ctx.cfg
+        dy = _f32c(dy)
+        dx = torch.empty((b, c, h, w), dtype=torch.float32, device=dy.device)
+        _native.check(_lib().afd_dropout_permute(_native.ptr(dy), _native.ptr(dx), b, c, h, w, p,
+                                                 seed, 1, _native.stream_ptr()),
+                      "afd_dropout_permute(inverse)")
+        return dx, None, None
+
+
+def dropout_permute(x, p: float, training: bool):
+    """Dropout(p)(x).permute(0, 2, 1, 3).contiguous()."""
+    p = float(p) if training else 0.0
+    return _DropoutPermute.apply(x, p, next_seed() if p > 0 else 0)
+
+
+class _PReLUDropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, slope, p, seed):
+        z = _f32c(z)
+        y = torch.empty_like(z)
+        _native.check(_lib().afd_prelu_dropout_forward(_native.ptr(z), _native.ptr(slope),
+                                                       _native.ptr(y), z.numel(), p, seed,
+                                                       _native.stream_ptr()),
+                      "afd_prelu_dropout_forward")
+        ctx.save_for_backward(z, slope)
+        ctx.cfg = (p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, slope = ctx.saved_tensors
+        p, seed = ctx.cfg
+        dy = _f32c(dy)
+        dz = torch.empty_like(z)
+        dslope = torch.zeros(1, dtype=torch.float32, device=z.device)
+        _native.check(_lib().afd_prelu_dropout_backward(
+            _native.ptr(z), _native.ptr(slope), _native.ptr(dy), _native.ptr(dz), _native.ptr(dslope),
+            z.numel(), p, seed, _native.stream_ptr()), "afd_prelu_dropout_backward")
+        return dz, dslope, None, None
+
+
+def prelu_dropout(z, slope, p: float, training: bool):
+    p = float(p) if training else 0.0
+    return _PReLUDropout.apply(z, slope, p, next_seed() if p > 0 else 0)
+
+
+# --------------------------------------------------------------------------------------
+class _LinearMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _f32c(x)
+        bsz, td, f = x.shape
+        o = w.shape[0]
+        y = torch.empty((bsz, o), dtype=torch.float32, device=x.device)
+        _native.check(_lib().afd_linear_mean_forward(_native.ptr(x), _native.ptr(_f32c(w)),
+                                                     _native.ptr(b), _native.ptr(y), bsz, td, f, o,
+                                                     _native.stream_ptr()), "afd_linear_mean_forward")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        bsz, td, f = x.shape
+        o = w.shape[0]
+        dy = _f32c(dy)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(o, dtype=torch.float32, device=x.device)
+        _native.check(_lib().afd_linear_mean_backward(
+            _native.ptr(x), _native.ptr(_f32c(w)), _native.ptr(dy), _native.ptr(dx), _native.ptr(dw),
+            _native.ptr(db), bsz, td, f, o, _native.stream_ptr()), "afd_linear_mean_backward")
+        return dx, dw, db
+
+
+def linear_mean(x, w, b):
+    """(x @ w.T + b).mean(1) for x [B, TD, F]."""
+    return _LinearMean.apply(x, w, b)
+
+
+# --------------------------------------------------------------------------------------
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = _f32c(logits)
+        labels = labels.to(torch.int64).contiguous()
+        b, o = logits.shape
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)  # loss, correct
+        dl = torch.empty_like(logits)
+        _native.check(_lib().afd_cross_entropy(
+            _native.ptr(logits), _native.ptr(labels), _native.ptr(out),
+            _native.ptr(dl), _native.c_p(out.data_ptr() + 4), b, o, _native.stream_ptr()),
+            "afd_cross_entropy")
+        ctx.save_for_backward(dl)
+        ctx.mark_non_differentiable(out)
+        loss = out[0].clone()
+        ctx.stats = out
+        return loss, out
+
+    @staticmethod
+    def backward(ctx, dloss, _dout):
+        (dl,) = ctx.saved_tensors
+        return dl * dloss, None
+
+
+def cross_entropy(logits, labels):
+    """Mean cross entropy; returns (loss, stats) with stats = [loss, #correct]."""
+    return _CrossEntropy.apply(logits, labels)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """Drop-in for torch.nn.CrossEntropyLoss() on [B, O] logits (train_classifier.py:1212)."""
+
+    def forward(self, logits, labels):
+        loss, stats = cross_entropy(logits, labels)
+        self.last_stats = stats
+        return loss
+
+
+# --------------------------------------------------------------------------------------
+class FusedAdam(torch.optim.Optimizer):
+    """Adam with coupled L2 over ONE flat fp32 arena (params, grads, m, v contiguous).
+
+    Same update rule as ``torch.optim.Adam(params, lr, weight_decay=wd)`` (reference
+    train_classifier.py:1215-1219).  The parameters are re-pointed into ``self.flat`` and
+    their ``.grad`` into ``self.flat_grad``: the gradient all-reduce of the data-parallel step
+    is one collective over ``flat_grad`` and the update is one launch.
+    """
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        params = [p for p in params]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._params = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        dev = self._params[0].device
+        total = sum(p.numel() for p in self._params)
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self._offsets = []
+        with torch.no_grad():
+            for p in self._params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + n].view_as(p)
+                self._offsets.append(off)
+                off += n
+        self._relink()
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = False):  # keep the arena views alive
+        self.flat_grad.zero_()
+        self._relink()
+
+    def _relink(self):
+        base = self.flat_grad.data_ptr()
+        for p, off in zip(self._params, self._offsets):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        _native.check(_lib().afd_adam_step(
+            _native.ptr(self.flat), _native.ptr(self.flat_grad), _native.ptr(self.m),
+            _native.ptr(self.v), self.flat.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+            g["weight_decay"], self.step_count, grad_scale, _native.stream_ptr()), "afd_adam_step")
+        return None

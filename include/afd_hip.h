@@ -63,6 +63,95 @@ int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo, const flo
                     int L, int level, unsigned flags, float power, float eps, float mean,
                     float std, float* out, void* ws, size_t ws_bytes, afd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Conv2d, stride 1, square kernel K, zero padding `pad`, dilation `dil`, NCHW fp32.
+ * Replaces: the cuDNN forward / backward-data / backward-weight launches behind every
+ *           nn.Conv2d of DCNN / LCNN (reference src/audiofakedetect/models.py:255-291,
+ *           :85-110).  Exact-f32 MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM.
+ * Geometry arguments always describe the FORWARD convolution:
+ *   x [N][Cin][H][W], w [Cout][Cin][K][K], y [N][Cout][Hout][Wout],
+ *   Hout = H + 2 pad - dil (K - 1).   Limits: Cout <= 128 (and Cin <= 128 for
+ *   backward_data).  `ws` is device scratch of afd_conv2d_workspace_bytes() bytes.
+ * ---------------------------------------------------------------------------------- */
+size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int Cout, int K, int pad, int dil);
+int afd_conv2d_forward(const float* x, const float* w, const float* bias /* may be NULL */,
+                       float* y, int N, int Cin, int H, int W, int Cout, int K, int pad, int dil,
+                       void* ws, size_t ws_bytes, afd_stream_t stream);
+int afd_conv2d_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int H,
+                             int W, int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
+                             afd_stream_t stream);
+int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
+                               float* dbias /* may be NULL */, int N, int Cin, int H, int W,
+                               int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
+                               afd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * HBM-bound layers.  `slope` is the device address of the single shared PReLU parameter
+ * (nn.PReLU(), models.py:258); where it is "may be NULL" the PReLU is skipped.
+ * ---------------------------------------------------------------------------------- */
+/* torchvision Normalize with scalar statistics (wavelet_math.py:380-382): y = (x-mean)/std */
+int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,
+                          afd_stream_t stream);
+/* y[p][c][r] = x[p][r][c]: the .permute(0,1,3,2) of models.py:304 made contiguous */
+int afd_transpose_last2(const float* x, float* y, int planes, int R, int C, afd_stream_t stream);
+
+/* PReLU followed by Dropout(p) (models.py:291-292); the mask is a counter-based function of
+ * (seed, element index) and is regenerated in backward */
+int afd_prelu_dropout_forward(const float* z, const float* slope, float* y, size_t n, float p,
+                              uint64_t seed, afd_stream_t stream);
+int afd_prelu_dropout_backward(const float* z, const float* slope, const float* dy, float* dz,
+                               float* dslope /* += */, size_t n, float p, uint64_t seed,
+                               afd_stream_t stream);
+
+/* PReLU + MaxPool2d(2,2) (models.py:258-259): z [NC][H][W] -> u [NC][H/2][W/2], idx = argmax
+ * position (dy*2+dx) of each window; slope may be NULL (plain max pool) */
+int afd_prelu_pool_forward(const float* z, const float* slope, float* u, uint8_t* idx, int NC,
+                           int H, int W, afd_stream_t stream);
+int afd_prelu_pool_backward(const float* z, const float* slope, const uint8_t* idx,
+                            const float* du, float* dz, float* dslope /* += */, int NC, int H,
+                            int W, afd_stream_t stream);
+
+/* (Sync)BatchNorm over x [N][C][HW] (models.py:260-289), optional PReLU fused on the input.
+ * stats: sums[0..C) = sum, sums[C..2C) = sum of squares (double; the caller all-reduces them
+ * across ranks and derives mean / invstd).  backward_stats: sum(dy), sum(dy * xhat).
+ * backward_apply: dx = gamma invstd (dy - mean_dy - xhat mean_dy_xhat), chained through the
+ * fused PReLU (dslope accumulates). gamma / beta may be NULL (affine=False). */
+int afd_bn_stats(const float* x, const float* slope, double* sums, int N, int C, int HW,
+                 afd_stream_t stream);
+int afd_bn_apply_forward(const float* x, const float* slope, const float* mean,
+                         const float* invstd, const float* gamma, const float* beta, float* y,
+                         int N, int C, int HW, afd_stream_t stream);
+int afd_bn_backward_stats(const float* x, const float* slope, const float* dy, const float* mean,
+                          const float* invstd, double* sums, int N, int C, int HW,
+                          afd_stream_t stream);
+int afd_bn_backward_apply(const float* x, const float* slope, const float* dy, const float* mean,
+                          const float* invstd, const float* gamma, const float* mean_dy,
+                          const float* mean_dy_xhat, float* dx, float* dslope /* += */, int N,
+                          int C, int HW, afd_stream_t stream);
+
+/* Dropout(p) + permute(0,2,1,3).contiguous() (models.py:277,307): x [B][C][H][W] ->
+ * y [B][H][C][W]; inverse != 0 runs the backward (dy [B][H][C][W] -> dx [B][C][H][W]) */
+int afd_dropout_permute(const float* x, float* y, int B, int C, int H, int W, float p,
+                        uint64_t seed, int inverse, afd_stream_t stream);
+
+/* Flatten(2) + Linear(F, O) + mean(1) (models.py:295-298,311): x [B][TD][F] -> y [B][O] */
+int afd_linear_mean_forward(const float* x, const float* w, const float* bias, float* y, int B,
+                            int TD, int F, int O, afd_stream_t stream);
+int afd_linear_mean_backward(const float* x, const float* w, const float* dy, float* dx,
+                             float* dw, float* db, int B, int TD, int F, int O,
+                             afd_stream_t stream);
+
+/* CrossEntropyLoss (mean) + its gradient + number of correct argmax predictions
+ * (train_classifier.py:970-979); dlogits / correct may be NULL */
+int afd_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                      float* correct, int B, int O, afd_stream_t stream);
+
+/* Adam with coupled L2 weight decay over one flat parameter arena
+ * (train_classifier.py:986,1215-1219); grads are multiplied by grad_scale first */
+int afd_adam_step(float* params, const float* grads, float* m, float* v, size_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step,
+                  float grad_scale, afd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,224 @@
+"""GPU parity of the DCNN layer kernels (through the C ABI) against plain PyTorch references.
+
+Each HIP op is compared with the same op computed by torch on the CPU in float64 (forward
+and backward); tolerances are relative to the largest reference magnitude:
+  conv / linear (fp32 MFMA / fma accumulation over K <= 1152 terms): 2e-5
+  elementwise / pooling / batch-norm                                 : 1e-5
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from audiofakedetect import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rtol, what=""):
+    ref = ref.double()
+    got = got.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: err {err:.3e} scale {scale:.3e}"
+
+
+CONV_CASES = [
+    # n, cin, h, w, cout, k, pad, dil      (DCNN on STFT features, reference models.py:255-291)
+    (2, 1, 101, 256, 64, 3, 2, 1),
+    (2, 64, 51, 129, 64, 1, 0, 1),
+    (2, 64, 51, 129, 96, 3, 1, 1),
+    (2, 96, 25, 64, 128, 3, 1, 1),
+    (2, 128, 25, 64, 32, 3, 1, 1),
+    (2, 32, 25, 64, 64, 3, 1, 1),
+    (2, 12, 64, 32, 12, 3, 1, 1),
+    (2, 12, 64, 32, 12, 5, 2, 2),
+    (2, 12, 60, 28, 12, 7, 2, 4),
+    # level-14 shaped (wide) images: RECT tiles
+    (1, 1, 24, 1500, 64, 3, 2, 1),
+    (1, 64, 6, 2050, 96, 3, 1, 1),
+    (1, 3, 64, 1100, 3, 7, 2, 4),
+    (1, 3, 64, 1030, 3, 5, 2, 2),
+    # LCNN shapes (models.py:85-110)
+    (2, 1, 101, 256, 64, 5, 2, 1),
+    (2, 48, 25, 64, 128, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward_backward(case):
+    n, cin, h, w, cout, k, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, wt, b))
+    yr = F.conv2d(xr, wr, br, padding=pad, dilation=dil)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+
+    xg, wg, bg = (t.cuda().requires_grad_() for t in (x, wt, b))
+    yg = ops.conv2d(xg, wg, bg, pad, dil)
+    _close(yg, yr.detach(), 2e-5, "conv fwd")
+    yg.backward(dy.cuda())
+    _close(xg.grad, xr.grad, 2e-5, "conv dgrad")
+    _close(wg.grad, wr.grad, 3e-5, "conv wgrad")
+    _close(bg.grad, br.grad, 2e-5, "conv dbias")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 103, 258), (3, 5, 7, 9), (1, 96, 51, 129), (2, 4, 26, 1002)])
+@pytest.mark.parametrize("slope", [0.25, -0.3, None])
+def test_prelu_maxpool(shape, slope):
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(shape, generator=g)
+    zr = z.double().requires_grad_()
+    ar = torch.tensor([slope if slope is not None else 1.0], dtype=torch.float64, requires_grad=True)
+    act = F.prelu(zr, ar) if slope is not None else zr
+    ur = F.max_pool2d(act, 2, 2)
+    du = torch.randn(ur.shape, generator=g)
+    ur.backward(du.double())
+    zg = z.cuda().requires_grad_()
+    ag = torch.tensor([slope], device="cuda", requires_grad=True) if slope is not None else None
+    ug = ops.prelu_maxpool2x2(zg, ag)
+    _close(ug, ur.detach(), 1e-6, "pool fwd")
+    ug.backward(du.cuda())
+    _close(zg.grad, zr.grad, 1e-6, "pool dz")
+    if slope is not None:
+        _close(ag.grad, ar.grad, 1e-4, "pool dslope")
+
+
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("slope", [None, 0.25])
+def test_batch_norm_train_and_eval(affine, slope):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(4, 12, 9, 31, generator=g) * 2 + 0.7
+    bn_r = torch.nn.BatchNorm2d(12, affine=affine).double()
+    bn_g = torch.nn.BatchNorm2d(12, affine=affine).cuda()
+    if affine:
+        with torch.no_grad():
+            bn_r.weight.copy_(torch.randn(12, generator=g))
+            bn_r.bias.copy_(torch.randn(12, generator=g))
+            bn_g.weight.copy_(bn_r.weight.float())
+            bn_g.bias.copy_(bn_r.bias.float())
+    xr = x.double().requires_grad_()
+    ar = torch.tensor([slope or 1.0], dtype=torch.float64, requires_grad=True)
+    yr = bn_r(F.prelu(xr, ar) if slope else xr)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg = x.cuda().requires_grad_()
+    ag = torch.tensor([slope], device="cuda", requires_grad=True) if slope else None
+    yg = ops.batch_norm(xg, bn_g, ag, sync=False)
+    _close(yg, yr.detach(), 1e-5, "bn fwd")
+    yg.backward(dy.cuda())
+    _close(xg.grad, xr.grad, 2e-5, "bn dx")
+    _close(bn_g.running_mean, bn_r.running_mean, 1e-5, "running_mean")
+    _close(bn_g.running_var, bn_r.running_var, 1e-5, "running_var")
+    assert int(bn_g.num_batches_tracked) == 1
+    if affine:
+        _close(bn_g.weight.grad, bn_r.weight.grad, 2e-5, "dgamma")
+        _close(bn_g.bias.grad, bn_r.bias.grad, 2e-5, "dbeta")
+    if slope:
+        _close(ag.grad, ar.grad, 1e-4, "bn dslope")
+    bn_r.eval()
+    bn_g.eval()
+    with torch.no_grad():
+        ye = bn_r(F.prelu(x.double(), ar.detach()) if slope else x.double())
+        yg = ops.batch_norm(x.cuda(), bn_g, ag.detach() if slope else None, sync=False)
+    _close(yg, ye, 1e-5, "bn eval")
+
+
+def test_dropout_permute_and_prelu_dropout():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 64, 12, 32, generator=g)
+    y = ops.dropout_permute(x.cuda(), 0.6, training=False)
+    assert torch.equal(y.cpu(), x.permute(0, 2, 1, 3).contiguous())
+    xg = x.cuda().requires_grad_()
+    y = ops.dropout_permute(xg, 0.6, training=True)
+    kept = (y != 0).float().mean().item()
+    assert abs(kept - 0.4) < 0.02
+    yp = y.permute(0, 2, 1, 3)
+    mask = (yp != 0)
+    assert torch.allclose(yp[mask], xg.detach()[mask] / 0.4, rtol=1e-6)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    assert torch.allclose(xg.grad, dy.permute(0, 2, 1, 3) * mask / 0.4, rtol=1e-6)
+
+    z = torch.randn(3, 12, 40, 8, generator=g)
+    a = torch.tensor([0.25], device="cuda", requires_grad=True)
+    zg = z.cuda().requires_grad_()
+    y = ops.prelu_dropout(zg, a, 0.2, training=False)
+    _close(y, F.prelu(z.double(), torch.tensor([0.25], dtype=torch.float64)), 1e-6, "prelu")
+    y = ops.prelu_dropout(zg, a, 0.2, training=True)
+    assert abs((y != 0).float().mean().item() - 0.8) < 0.03
+    zr = z.double().requires_grad_()
+    ar = torch.tensor([0.25], dtype=torch.float64, requires_grad=True)
+    mask = (y != 0).cpu().double() / 0.8
+    (F.prelu(zr, ar) * mask).sum().backward()
+    y.sum().backward()
+    _close(zg.grad, zr.grad, 1e-6, "prelu dz")
+    _close(a.grad, ar.grad, 1e-4, "prelu dslope")
+
+
+@pytest.mark.parametrize("td,f", [(12, 320), (3, 5000), (1, 777)])
+def test_linear_mean(td, f):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5, td, f, generator=g)
+    w = torch.randn(2, f, generator=g) / f ** 0.5
+    b = torch.randn(2, generator=g)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    yr = (xr @ wr.t() + br).mean(1)
+    dy = torch.randn(5, 2, generator=g)
+    yr.backward(dy.double())
+    xg, wg, bg = (t.cuda().requires_grad_() for t in (x, w, b))
+    yg = ops.linear_mean(xg, wg, bg)
+    _close(yg, yr.detach(), 1e-5, "linear fwd")
+    yg.backward(dy.cuda())
+    _close(xg.grad, xr.grad, 1e-5, "linear dx")
+    _close(wg.grad, wr.grad, 1e-5, "linear dw")
+    _close(bg.grad, br.grad, 1e-5, "linear db")
+
+
+def test_cross_entropy_and_accuracy():
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(128, 2, generator=g) * 3
+    labels = torch.randint(0, 2, (128,), generator=g)
+    lr = logits.double().requires_grad_()
+    loss_r = F.cross_entropy(lr, labels)
+    loss_r.backward()
+    lg = logits.cuda().requires_grad_()
+    loss, stats = ops.cross_entropy(lg, labels.cuda())
+    _close(loss, loss_r.detach(), 1e-6, "ce")
+    (loss * 2.0).backward()
+    _close(lg.grad, 2.0 * lr.grad, 1e-5, "ce grad")
+    assert int(stats[1].item()) == int((logits.argmax(-1) == labels).sum())
+
+
+def test_fused_adam_matches_torch_adam():
+    g = torch.Generator().manual_seed(6)
+    shapes = [(64, 1, 3, 3), (64,), (1,), (2, 320)]
+    ps_r = [torch.randn(s, generator=g).requires_grad_() for s in shapes]
+    ps_g = [p.detach().clone().cuda().requires_grad_() for p in ps_r]
+    opt_r = torch.optim.Adam(ps_r, lr=4e-4, weight_decay=1e-3)
+    opt_g = ops.FusedAdam(ps_g, lr=4e-4, weight_decay=1e-3)
+    for _ in range(3):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        opt_r.zero_grad()
+        opt_g.zero_grad()
+        for p, q, gr in zip(ps_r, ps_g, grads):
+            p.grad = gr.clone()
+            q.grad.copy_(gr)
+        opt_r.step()
+        opt_g.step()
+    for p, q in zip(ps_r, ps_g):
+        assert torch.allclose(q.detach().cpu(), p.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_normalize_and_transpose():
+    x = torch.randn(2, 1, 95, 256).cuda()
+    view = x.permute(0, 1, 3, 2)
+    y = ops.normalize_forward(view, -3.0, 2.5)
+    assert y.shape == view.shape
+    assert torch.allclose(y, (view + 3.0) / 2.5, atol=1e-6)
+    t = ops.transpose_last2(x)
+    assert torch.equal(t, x.transpose(-1, -2).contiguous())
