@@ -166,6 +166,13 @@ conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __
         __syncthreads();
         const float* arow = wlds + wm * 32 + l31;
         const int ksteps = g.CKP >> 1;
+        // two-level accumulation: a fresh fp32 chain per channel chunk, then one add --
+        // keeps the rounding error of K = Cin*K*K <= 1152 products near sqrt(chunk) * eps
+        f32x16 part[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[i][r] = 0.f;
 #pragma unroll 4
         for (int ks = 0; ks < ksteps; ++ks) {
             const int k = 2 * ks + half;
@@ -174,9 +181,11 @@ conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const float b = patch[off + pbase[i]];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
             }
         }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] += part[i];
     }
 
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -418,6 +427,12 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
         }
         const float* arow = dzl + (m * 32 + l31) * wg.PIXP;
         const int ksteps = g.PIX >> 1;
+        // two-level accumulation (per 64-pixel tile, then across tiles): see forward kernel
+        f32x16 part[NTW];
+#pragma unroll
+        for (int i = 0; i < NTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[i][r] = 0.f;
 #pragma unroll 2
         for (int ks = 0; ks < ksteps; ++ks) {
             const int k = 2 * ks + half;
@@ -427,10 +442,12 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
             for (int i = 0; i < NTW; ++i) {
                 if (nvalid[i]) {
                     const float b = patch[joff[i] + po];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                    part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
                 }
             }
         }
+#pragma unroll
+        for (int i = 0; i < NTW; ++i) acc[i] += part[i];
     }
 
     float* slab = part + ((size_t)split * gridDim.y + chunk) * g.CO_PAD * wg.NCOL;

@@ -1,0 +1,58 @@
+import sys, os, torch
+sys.path.insert(0, "audiodeepfake-detection_amd"); sys.path.insert(0, ".")
+from audiofakedetect import ops
+from audiofakedetect.models import DCNN
+from audiofakedetect.utils import DotDict
+from oracle import torch_ref
+g = torch.load("tests/golden/dcnn_train_step.pt", map_location="cpu")
+a = DotDict(input_dim=list(g["x"].shape), ochannels1=64, ochannels2=64, ochannels3=96, ochannels4=128, ochannels5=32, kernel1=3, dropout_cnn=0.0, dropout_lstm=0.0, time_dim_add=0, flattend_size=320, ddp=False)
+net = DCNN(a); net.load_state_dict(g["state_dict"]); net.cuda().train()
+ref = torch_ref.DCNNRef(g["x"].shape, dropout_cnn=0.0, dropout_lstm=0.0).double()
+ref.load_state_dict({k: (v.double() if v.dtype.is_floating_point else v) for k, v in g["state_dict"].items()}); ref.train()
+
+# reference, layer by layer
+rt = {}
+h = g["x"].double().permute(0, 1, 3, 2)
+for i, m in enumerate(ref.cnn):
+    h = m(h); h.retain_grad(); rt[f"cnn{i}"] = h
+h = h.permute(0, 2, 1, 3).contiguous()
+for i, m in enumerate(ref.dil_conv):
+    h = m(h); h.retain_grad(); rt[f"dil{i}"] = h
+o = ref.fc(h).mean(1)
+torch.nn.functional.cross_entropy(o, g["labels"]).backward()
+
+# gpu, same structure as DCNN.forward
+gt = {}
+x = g["x"].cuda()
+h = ops.transpose_contiguous(x.contiguous())
+cnn = net.cnn
+for conv_i, prelu_i, pooled, bn_i in net._cnn_plan:
+    conv = cnn[conv_i]; slope = cnn[prelu_i].weight
+    z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0]); z.retain_grad(); gt[f"cnn{conv_i}"] = z
+    if pooled:
+        h = ops.prelu_maxpool2x2(z, slope); h.retain_grad(); gt[f"cnn{prelu_i+1}"] = h
+        if bn_i is not None:
+            h = ops.batch_norm(h, cnn[bn_i], None, False); h.retain_grad(); gt[f"cnn{bn_i}"] = h
+    else:
+        h = ops.batch_norm(z, cnn[bn_i], slope, False); h.retain_grad(); gt[f"cnn{bn_i}"] = h
+h = ops.dropout_permute(h, 0.0, True)
+dil = net.dil_conv; slope = None; z = h
+for j in range(3):
+    bn, conv = dil[3*j], dil[3*j+1]
+    h = ops.batch_norm(z, bn, slope, False); h.retain_grad(); gt[f"dil{3*j}"] = h
+    z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0]); z.retain_grad(); gt[f"dil{3*j+1}"] = z
+    slope = dil[3*j+2].weight
+h = ops.prelu_dropout(z, slope, 0.0, True); h.retain_grad(); gt["dil8"] = h
+lin = net.fc[1]
+out = ops.linear_mean(h.reshape(h.shape[0], h.shape[1], -1), lin.weight, lin.bias)
+loss = ops.CrossEntropyLoss()(out, g["labels"].cuda()); loss.backward()
+def rel(a, b):
+    b = b.double(); a = a.detach().cpu().double()
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+for k in gt:
+    print(f"{k:8s} fwd rel err {rel(gt[k], rt[k].detach()):.3e}   grad rel err {rel(gt[k].grad, rt[k].grad):.3e}  shape {tuple(gt[k].shape)}")
+
+r64 = dict(ref.named_parameters())
+for k, p in net.named_parameters():
+    d = (p.grad.cpu().double() - r64[k].grad); d32 = (g["grads"][k].double() - r64[k].grad)
+    print(f"{k:20s} gpu-vs-fp64 L2 {d.norm().item()/r64[k].grad.norm().item():.3e} max {d.abs().max().item()/r64[k].grad.abs().max().item():.3e} | cpu32-vs-fp64 L2 {d32.norm().item()/r64[k].grad.norm().item():.3e} max {d32.abs().max().item()/r64[k].grad.abs().max().item():.3e}")
