@@ -30,6 +30,10 @@ c_ul = ctypes.c_ulonglong
 _SIGNATURES = {
     "afd_last_error": (ctypes.c_char_p, []),
     "afd_version": (c_i, []),
+    "afd_timing_enable": (c_i, [c_i]),
+    "afd_timing_collect": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_l),
+                                 ctypes.POINTER(ctypes.c_double)]),
+    "afd_timing_reset": (c_i, []),
     "afd_wpt_out_len": (c_i, [c_i, c_i, c_i]),
     "afd_wpt_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "afd_wpt_forward": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i,
@@ -103,3 +107,22 @@ def ptr(t: Optional[torch.Tensor]) -> c_p:
 
 def float_array(vals):
     return (c_f * len(vals))(*[float(v) for v in vals])
+
+
+KERNEL_CLASSES = {"wpt": 0, "conv_igemm": 1, "conv_wgrad": 2, "stft": 3}
+
+
+def timing_enable(on: bool) -> None:
+    load().afd_timing_enable(1 if on else 0)
+
+
+def timing_collect(name: str):
+    """(total_ms, launches, total_work) of one kernel class since the last reset."""
+    ms, n, work = ctypes.c_double(), c_l(), ctypes.c_double()
+    check(load().afd_timing_collect(KERNEL_CLASSES[name], ctypes.byref(ms), ctypes.byref(n),
+                                    ctypes.byref(work)), "afd_timing_collect")
+    return ms.value, n.value, work.value
+
+
+def timing_reset() -> None:
+    load().afd_timing_reset()

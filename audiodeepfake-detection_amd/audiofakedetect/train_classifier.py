@@ -1,0 +1,315 @@
+"""Trainer / entry point of the hot path (MI355X host side).
+
+Mirrors the reference's ``src/audiofakedetect/train_classifier.py`` for the symbols on the
+path: ``ddp_setup`` (:44-47), ``create_data_loaders`` samplers (:118-127), ``Trainer``
+(``init_model`` :306-329, ``_run_batch`` :945-995, ``_run_epoch`` :887-912, ``train``
+:1021-1046, ``_save_snapshot``/``load_snapshot`` :997-1019, a batched ``val_test_loop``
+:365-497) and ``main`` (:1084-1368) including the ``--config`` ``get_config()`` protocol, so
+``torchrun ... -m src.audiofakedetect.train_classifier <flags>`` (scripts/train.sh:33-68)
+runs unchanged.
+
+Data parallelism is one process per GPU over RCCL (``backend="nccl"`` is RCCL on ROCm):
+parameters/optimizer state replicated, batches sharded by ``DistributedSampler``; per step
+ONE all-reduce over the flat gradient arena of ``FusedAdam`` (the mean is folded into the
+optimizer kernel) plus the packed BatchNorm statistics exchanges inside the model.  The
+reference wraps the model in DistributedDataParallel twice; here the wrap is
+``DataParallelRCCL`` and happens once.
+"""
+
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+from torch.utils.data.distributed import DistributedSampler
+
+from . import ops
+from .data_loader import get_costum_dataset
+from .models import get_model, strip_ddp_prefix
+from .utils import DotDict, add_default_parser_args, build_new_grid, get_input_dims, set_seed
+from .wavelet_math import fuse_normalization, get_transforms
+
+
+def ddp_setup() -> None:
+    """Join the process group (RCCL) and bind this process to its GPU."""
+    dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+
+
+def is_lead(args: DotDict) -> bool:
+    return (not args.ddp) or int(os.environ.get("RANK", "0")) == 0
+
+
+class DataParallelRCCL(torch.nn.Module):
+    """Replica wrapper: broadcasts rank 0's parameters and buffers at construction.
+
+    Gradient averaging is done by the Trainer in one collective over the optimizer's flat
+    gradient arena (``sync_gradients``), not by per-bucket autograd hooks.
+    """
+
+    def __init__(self, module: torch.nn.Module) -> None:
+        super().__init__()
+        self.module = module
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t.data, src=0)
+
+    def forward(self, *a, **kw):
+        return self.module(*a, **kw)
+
+
+def sync_gradients(model: torch.nn.Module, optimizer) -> float:
+    """Sum the gradients over ranks; returns the scale (1/world) still to be applied.
+
+    With ``FusedAdam`` this is ONE all-reduce over the contiguous arena and the 1/world factor
+    is applied inside the Adam kernel; otherwise gradients are reduced tensor by tensor and
+    scaled here (returns 1.0).
+    """
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return 1.0
+    world = dist.get_world_size()
+    if isinstance(optimizer, ops.FusedAdam):
+        dist.all_reduce(optimizer.flat_grad)
+        return 1.0 / world
+    for p in model.parameters():
+        if p.grad is not None:
+            dist.all_reduce(p.grad)
+            p.grad.mul_(1.0 / world)
+    return 1.0
+
+
+def create_data_loaders(args: DotDict, limit: Optional[int] = None):
+    """Train / val / test loaders with DistributedSampler semantics (reference :50-229)."""
+    loaders = []
+    for split, lim in (("train", args.limit_train[0] if args.limit_train else limit),
+                       ("val", args.limit_train[1] if args.limit_train else limit),
+                       ("test", args.limit_train[2] if args.limit_train else limit)):
+        ds = get_costum_dataset(data_path=args.data_path, ds_type=split, only_use=args.only_use,
+                                save_path=args.save_path, limit=lim, file_type=args.file_type,
+                                resample_rate=args.sample_rate, seconds=args.seconds,
+                                synthetic=bool(args.synthetic))
+        sampler = None
+        if args.ddp:
+            sampler = DistributedSampler(ds, shuffle=(split == "train"), seed=args.seed or 0,
+                                         drop_last=True)
+        loaders.append(DataLoader(ds, batch_size=args.batch_size, shuffle=(sampler is None and split == "train"),
+                                  sampler=sampler, drop_last=True, pin_memory=True,
+                                  num_workers=args.num_workers or 0))
+    return loaders
+
+
+class Trainer:
+    """Training / evaluation driver with the reference's method names."""
+
+    def __init__(self, snapshot_path: str, args: DotDict, normalize, transforms,
+                 test_data_loader, model, train_data_loader, val_data_loader,
+                 cross_loader_val=None, cross_loader_test=None, optimizer=None, loss_fun=None,
+                 writer=None) -> None:
+        self.args = args
+        if self.args.ddp:
+            self.local_rank = int(os.environ["LOCAL_RANK"])
+            self.global_rank = int(os.environ["RANK"])
+            self.world_size = int(os.environ["WORLD_SIZE"])
+        else:
+            self.local_rank = self.global_rank = torch.cuda.current_device()
+            self.world_size = 1
+        self.model = model
+        if model is not None:
+            self._check_model_init()
+        self.train_data_loader = train_data_loader
+        self.val_data_loader = val_data_loader
+        self.test_data_loader = test_data_loader
+        self.cross_loader_val = cross_loader_val
+        self.cross_loader_test = cross_loader_test
+        self.optimizer = optimizer
+        self.loss_fun = loss_fun
+        self.epochs_run = 0
+        self.snapshot_path = snapshot_path + ".pt"
+        self.normalize = normalize
+        self.transforms = transforms
+        self.writer = writer
+        # (x - mean) / std moves into the transform kernel's epilogue when it can
+        if normalize is not None and transforms is not None:
+            fuse_normalization(transforms, normalize)
+        self.validation_list: list = []
+        self.loss_list: list = []
+        self.accuracy_list: list = []
+        self.step_total = 0
+        self.test_results: tuple = ()
+        # device-side step statistics [loss, #correct]; fetched lazily (no per-step host sync)
+        self.last_stats: Optional[torch.Tensor] = None
+        self.sync_every_step = True
+
+    # -- model placement ------------------------------------------------------------------
+    def init_model(self, model) -> None:
+        if model is None:
+            raise RuntimeError("Model to initialize not given.")
+        if isinstance(model, DataParallelRCCL):
+            return
+        if not isinstance(model, torch.nn.Module):
+            raise RuntimeError("Given Model not of type torch.nn.Module.")
+        model.to(self.local_rank, non_blocking=True)
+        if self.args.ddp:
+            self.model = DataParallelRCCL(model)
+
+    def _check_model_init(self) -> None:
+        if self.model is None:
+            raise RuntimeError("Model not initialized.")
+        self.init_model(self.model)
+        if self.args.ddp and not isinstance(self.model, DataParallelRCCL):
+            raise RuntimeError("Model not parallelized.")
+
+    # -- the step -------------------------------------------------------------------------
+    def _features(self, audio: torch.Tensor) -> torch.Tensor:
+        with torch.no_grad():
+            feats, _ = self.transforms(audio)
+            return self.normalize(feats)
+
+    def _run_batch(self, e: int, batch: dict) -> None:
+        """One training step (reference train_classifier.py:945-995)."""
+        key = getattr(self.train_data_loader.dataset, "key", "audio") if self.train_data_loader is not None else "audio"
+        audio = batch[key].to(self.local_rank, non_blocking=True)
+        labels = (batch["label"].to(self.local_rank, non_blocking=True) != 0).type(torch.long)
+        self.optimizer.zero_grad()
+        feats = self._features(audio)
+        out = self.model(feats)
+        loss = self.loss_fun(out, labels)
+        loss.backward()
+        scale = sync_gradients(self.model, self.optimizer)
+        if isinstance(self.optimizer, ops.FusedAdam):
+            self.optimizer.step(grad_scale=scale)
+        else:
+            self.optimizer.step()
+        self.step_total += 1
+        stats = getattr(self.loss_fun, "last_stats", None)
+        self.last_stats = stats
+        if self.sync_every_step:
+            # the reference reads loss.item() / acc.item() every step (:981-989)
+            if stats is not None:
+                lv, correct = stats.tolist()
+                acc = correct / self.args.batch_size
+            else:
+                lv = loss.item()
+                acc = (out.argmax(-1) == labels).sum().item() / self.args.batch_size
+            self.loss_list.append([self.step_total, e, lv])
+            self.accuracy_list.append([self.step_total, e, acc])
+
+    def _run_epoch(self, epoch: int) -> None:
+        sampler = getattr(self.train_data_loader, "sampler", None)
+        if isinstance(sampler, DistributedSampler):
+            sampler.set_epoch(epoch)
+        for batch in self.train_data_loader:
+            self.model.train()
+            self._run_batch(epoch, batch)
+
+    # -- evaluation -----------------------------------------------------------------------
+    def val_test_loop(self, data_loader, name: str = "", pbar: bool = False):
+        """Batched eval: argmax == (label != 0); counts reduced over ranks on the device."""
+        self.model.eval()
+        counts = torch.zeros(2, dtype=torch.float64, device=self.local_rank)  # correct, total
+        preds, truth = [], []
+        key = getattr(data_loader.dataset, "key", "audio")
+        with torch.no_grad():
+            for batch in data_loader:
+                audio = batch[key].to(self.local_rank, non_blocking=True)
+                labels = batch["label"].to(self.local_rank, non_blocking=True) != 0
+                out = self.model(self._features(audio))
+                pred = torch.argmax(out, -1)
+                counts[0] += (pred == labels).sum()
+                counts[1] += labels.numel()
+                preds.append(pred)
+                truth.append(labels)
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(counts)
+        acc = (counts[0] / counts[1].clamp(min=1)).item()
+        return acc, torch.cat(preds) if preds else None, torch.cat(truth) if truth else None
+
+    def testing(self):
+        acc, _, _ = self.val_test_loop(self.test_data_loader, name="test")
+        self.test_results = (acc,)
+        return self.test_results
+
+    # -- snapshots ------------------------------------------------------------------------
+    def _save_snapshot(self, epoch: int) -> None:
+        torch.save({"MODEL_STATE": self.model.state_dict(), "EPOCHS_RUN": epoch}, self.snapshot_path)
+        print(f"Epoch {epoch + 1} | Training snapshot saved at {self.snapshot_path}")
+
+    def load_snapshot(self, snapshot_path: str) -> None:
+        snapshot = torch.load(snapshot_path, map_location=f"cuda:{self.local_rank}")
+        target = self.model.module if isinstance(self.model, DataParallelRCCL) else self.model
+        target.load_state_dict(strip_ddp_prefix(snapshot["MODEL_STATE"]))
+        self.epochs_run = snapshot["EPOCHS_RUN"]
+
+    def train(self, max_epochs: int) -> None:
+        self._check_model_init()
+        for epoch in range(self.epochs_run, max_epochs):
+            self._run_epoch(epoch)
+            if self.global_rank == 0 and self.args.ckpt_every and epoch % self.args.ckpt_every == 0 and epoch > 0:
+                self._save_snapshot(epoch)
+            if self.val_data_loader is not None and self.args.validation_interval and \
+                    (epoch + 1) % self.args.validation_interval == 0:
+                acc, _, _ = self.val_test_loop(self.val_data_loader, name="val")
+                self.validation_list.append([self.step_total, epoch, acc])
+        if self.test_data_loader is not None:
+            self.testing()
+
+
+def _parse_args():
+    parser = argparse.ArgumentParser(description="Train an audio deepfake classifier (MI355X)")
+    return add_default_parser_args(parser).parse_args()
+
+
+def main() -> None:
+    """CLI / experiment loop (reference train_classifier.py:1084-1368)."""
+    parsed = _parse_args()
+    args = DotDict(vars(parsed))
+    args.num_workers = 0
+    if args.ddp:
+        ddp_setup()
+    if args.config:
+        ns: dict = {}
+        with open(args.config) as f:
+            exec(compile(f.read(), args.config, "exec"), ns)  # the reference's plugin protocol
+        config = ns["get_config"]()
+    else:
+        config = {}
+    for k in ("data_path", "save_path", "only_use", "limit_train", "file_type", "seconds"):
+        args.setdefault(k, None)
+    args.seconds = args.seconds or 1
+    griderator = build_new_grid(config, random_seeds=args.random_seeds, seeds=args.init_seeds)
+    num_exp = griderator.get_len()
+    for _ in range(num_exp):
+        args, _step = griderator.update_step(args)
+        set_seed(args.seed)
+        device = f"cuda:{int(os.environ.get('LOCAL_RANK', 0))}"
+        transforms, normalize = get_transforms(args, args.features, device, args.calc_normalization,
+                                               pbar=args.pbar, verbose=is_lead(args))
+        args.input_dim = get_input_dims(args, transforms)
+        in_channels = 2 if args.loss_less == "True" else 1
+        model = get_model(args, args.model, args.nclasses, in_channels, is_lead(args))
+        train_loader, val_loader, test_loader = create_data_loaders(args, limit=args.batch_size * (args.synthetic_steps or 8))
+        model.to(device)
+        optimizer = ops.FusedAdam(model.parameters(), lr=args.learning_rate, weight_decay=args.weight_decay)
+        loss_fun = ops.CrossEntropyLoss()
+        os.makedirs(os.path.join(args.log_dir, "models"), exist_ok=True)
+        snap = os.path.join(args.log_dir, "models", f"model_{args.transform}_{args.wavelet}_{args.seed}")
+        trainer = Trainer(snap, args, normalize, transforms, test_loader, model, train_loader,
+                          val_loader, None, None, optimizer, loss_fun, None)
+        trainer.train(args.epochs)
+        if is_lead(args):
+            last = trainer.loss_list[-1][2] if trainer.loss_list else float("nan")
+            print(f"seed {args.seed}: steps {trainer.step_total}, last loss {last:.6f}, "
+                  f"test acc {trainer.test_results[0] if trainer.test_results else float('nan'):.4f}")
+    if args.ddp:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,22 @@ inline int check_launch(const char* what) {
     return AFD_OK;
 }
 
+// per-kernel HIP-event timing (afd_timing_enable); `work` = algorithmic flops or bytes
+bool timing_on();
+void timing_begin(int id, double work, hipStream_t s);
+void timing_end(hipStream_t s);
+
+struct ScopedTiming {
+    hipStream_t s;
+    bool on;
+    ScopedTiming(int id, double work, hipStream_t st) : s(st), on(timing_on()) {
+        if (on) timing_begin(id, work, s);
+    }
+    ~ScopedTiming() {
+        if (on) timing_end(s);
+    }
+};
+
 constexpr int kWave = 64;
 constexpr int kLdsBytes = 160 * 1024;  // per-CU LDS on gfx950
 

@@ -1,5 +1,7 @@
 // Error reporting and version of libafd_hip.
 #include "afd_common.h"
+
+#include <vector>
 #include "../../include/afd_hip.h"
 
 namespace afd {
@@ -17,7 +19,69 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- optional per-kernel timing with HIP events on the launch stream ------------------
+namespace {
+struct Slot {
+    hipEvent_t a, b;
+    int id;
+    double work;
+};
+std::vector<Slot>& slots() {
+    static std::vector<Slot> v;
+    return v;
+}
+bool g_timing = false;
+}  // namespace
+
+bool timing_on() { return g_timing; }
+
+void timing_begin(int id, double work, hipStream_t s) {
+    Slot sl;
+    sl.id = id;
+    sl.work = work;
+    if (hipEventCreate(&sl.a) != hipSuccess || hipEventCreate(&sl.b) != hipSuccess) return;
+    (void)hipEventRecord(sl.a, s);
+    slots().push_back(sl);
+}
+
+void timing_end(hipStream_t s) {
+    if (!slots().empty()) (void)hipEventRecord(slots().back().b, s);
+}
+
 }  // namespace afd
+
+extern "C" int afd_timing_enable(int on) {
+    afd::g_timing = on != 0;
+    return AFD_OK;
+}
+
+// Sums the recorded launches of kernel class `id` (AFD_K_*); synchronises on their events.
+extern "C" int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work) {
+    double ms = 0.0, work = 0.0;
+    long long n = 0;
+    for (auto& sl : afd::slots()) {
+        if (sl.id != id) continue;
+        if (hipEventSynchronize(sl.b) != hipSuccess) return afd::fail(AFD_ERR_HIP, "timing: event sync failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sl.a, sl.b) != hipSuccess) return afd::fail(AFD_ERR_HIP, "timing: elapsed failed");
+        ms += t;
+        work += sl.work;
+        ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (count) *count = n;
+    if (total_work) *total_work = work;
+    return AFD_OK;
+}
+
+extern "C" int afd_timing_reset(void) {
+    for (auto& sl : afd::slots()) {
+        (void)hipEventDestroy(sl.a);
+        (void)hipEventDestroy(sl.b);
+    }
+    afd::slots().clear();
+    return AFD_OK;
+}
 
 extern "C" const char* afd_last_error(void) { return afd::error_buffer(); }
 extern "C" int afd_version(void) { return 1; }

@@ -318,6 +318,8 @@ int launch_igemm(const ConvGeom& g, const float* x, const float* wp, const float
     if (threads > 512 || threads < 64) return afd::fail(AFD_ERR_UNSUPPORTED, "conv: Cout %d too large", g.Cout);
     const long blocks = (long)g.N * g.tilesX * g.tilesY;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv: grid too large");
+    afd::ScopedTiming timing(AFD_K_CONV_IGEMM,
+                             2.0 * g.N * g.Cout * (double)g.Hout * g.Wout * g.Cin * g.K * g.K, s);
     hipLaunchKernelGGL(conv_igemm_kernel<2>, dim3((unsigned)blocks), dim3(threads),
                        igemm_lds_bytes(g), s, g, x, wp, bias, y);
     return afd::check_launch("conv_igemm_kernel");
@@ -551,6 +553,8 @@ int launch_wgrad_t(const WgradGeom& wg, const float* x, const float* dz, float* 
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
+    afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * wg.c.N * wg.c.Cout * (double)wg.c.Hout *
+                                                   wg.c.Wout * wg.c.Cin * wg.c.K * wg.c.K, s);
     hipLaunchKernelGGL(conv_wgrad_kernel<NTW>, dim3(wg.S, wg.c.nchunks), dim3(wg.MT * wg.NG * 64),
                        wgrad_lds_bytes(wg), s, wg, x, dz, part, partb);
     return afd::check_launch("conv_wgrad_kernel");

@@ -293,6 +293,8 @@ int launch(const WptParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const unsigned grid = (unsigned)p.B << p.K1;
+    const int C = (p.flags & AFD_WPT_SIGN) ? 2 : 1;
+    afd::ScopedTiming timing(AFD_K_WPT, 4.0 * p.B * ((double)p.N + (double)C * p.n[p.level] * (double)(1L << p.level)), stream);
     hipLaunchKernelGGL(wpt_fused_kernel<LT>, dim3(grid), dim3(kThreads), lds_bytes, stream, p);
     return afd::check_launch("wpt_fused_kernel");
 }

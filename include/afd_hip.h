@@ -35,6 +35,18 @@ typedef void* afd_stream_t;
 const char* afd_last_error(void);
 int afd_version(void);
 
+/* Optional measurement hook (bench.py): when enabled, every launch of the kernel classes
+ * below is bracketed by HIP events on its own stream; afd_timing_collect sums the durations,
+ * launch count and algorithmic work (bytes for AFD_K_WPT / AFD_K_STFT, flops for the conv
+ * classes) recorded since the last afd_timing_reset. */
+#define AFD_K_WPT 0
+#define AFD_K_CONV_IGEMM 1 /* forward and backward-data launches of the implicit-GEMM kernel */
+#define AFD_K_CONV_WGRAD 2
+#define AFD_K_STFT 3
+int afd_timing_enable(int on);
+int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work);
+int afd_timing_reset(void);
+
 /* ------------------------------------------------------------------------------------
  * Wavelet-packet front end.
  * Replaces: compute_pytorch_packet_representation + Packets.forward
