@@ -85,18 +85,24 @@ def synthetic_batch(batch: int, rank: int, device):
     return {"audio": audio.to(device), "label": labels.to(device)}
 
 
-def cpu_baseline(workload: str, frames: int):
-    """The reference's algorithm on torch CPU (oracle 'port'), bounded sample."""
+def cpu_baseline(workload: str, frames: int, crop_packets: int = 4096):
+    """The reference's algorithm on torch CPU (oracle 'port'), on a bounded sample.
+
+    Front end: `frames` full frames (per-node pad+conv1d recursion, Welford on, as the
+    reference runs it).  DCNN train step: the same frames; for the level-14 workloads the
+    packet axis is cropped to `crop_packets` of P packets and the time scaled by P/crop (the
+    convolutions are translation invariant along that axis, cost is linear in it) -- one full
+    level-14 frame is 64 GFLOP of fp32 convolutions, minutes of CPU time.
+    """
     from oracle import torch_ref, wpt_oracle
 
     transform, wavelet, scales, add, _ = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(99)
     x = (0.1 * torch.randn(frames, 1, 22050, generator=g)).clamp_(-1, 1)
     labels = torch.randint(0, 2, (frames,), generator=g)
     level = scales.bit_length() - 1
-    net = None
     t0 = time.perf_counter()
     if transform == "packets":
         feats, _ = torch_ref.packets_torch(x, wpt_oracle.TAPS[wavelet], level, log_scale=True,
@@ -105,20 +111,29 @@ def cpu_baseline(workload: str, frames: int):
         feats = torch_ref.stft_torch(x, 2 * scales - 1, 220, log_scale=True)
     feats = torch_ref.normalize_torch(feats, 0.0, 1.0)
     t_fe = time.perf_counter() - t0
-    p8 = feats.shape[2] // 8
-    net = torch_ref.DCNNRef(feats.shape, time_dim_add=add, flattend_size=40 * (p8 - 24))
+    log(f"cpu baseline: front end {t_fe:.2f} s for {frames} frames ({cores} threads)")
+    packets = feats.shape[2]
+    crop = packets if packets <= 1024 else crop_packets
+    fc = feats[:, :, :crop, :].contiguous()
+    net = torch_ref.DCNNRef(fc.shape, time_dim_add=add, flattend_size=40 * (crop // 8 - 24))
     opt = torch.optim.Adam(net.parameters(), lr=4e-4, weight_decay=1e-3)
     net.train()
     t1 = time.perf_counter()
-    torch_ref.train_step_torch(net, opt, feats, labels)
-    t_step = time.perf_counter() - t1
+    torch_ref.train_step_torch(net, opt, fc, labels)
+    t_step = (time.perf_counter() - t1) * (packets / crop)
     total = t_fe + t_step
+    crop_note = "" if crop == packets else f" measured on packets[0:{crop}] of {packets} and scaled x{packets // crop}"
     return {
         "value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": f"{frames} frames of the same workload, 1 un-warmed step: front end "
-                  f"{t_fe:.2f} s (per-node pad+conv1d recursion, Welford on) + DCNN fwd/bwd/Adam "
-                  f"{t_step:.2f} s on torch CPU ({cores} threads)",
+        "sample": f"{frames} frame(s) of the same workload, one step: front end {t_fe:.2f} s "
+                  f"(per-node pad+conv1d recursion, Welford on) + DCNN fwd/bwd/Adam {t_step:.2f} s"
+                  f"{crop_note}; torch CPU, {cores} threads",
     }
+
+
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main() -> None:
@@ -128,9 +143,13 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
-    ap.add_argument("--cpu-frames", type=int, default=2, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
     a = ap.parse_args()
 
+    if a.cpu_only:
+        print(json.dumps(cpu_baseline(a.workload, max(1, a.cpu_frames))), flush=True)
+        return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,8 +177,11 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    log(f"built {a.workload}: features {args.input_dim}, batch/GPU {a.batch}, world {world}")
+    for i in range(a.warmup):
         trainer._run_batch(0, batch)
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -171,6 +193,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    log(f"timed {a.steps} steps: {1e3 * elapsed / a.steps:.2f} ms/step")
     # ---- per-kernel-class timing of one more step (HIP events on the launch stream) ----
     kernels = {}
     _native.timing_reset()
@@ -208,8 +231,10 @@ def main() -> None:
                     "frac_of_hbm_peak": gbs / PEAK_HBM_GBS}
 
     cpu = None
+    log(f"kernel classes: { {k: round(v['total_ms'], 3) for k, v in kernels.items()} }")
     if rank == 0 and world == 1 and a.cpu_frames > 0:
         cpu = cpu_baseline(a.workload, a.cpu_frames)
+        log(f"cpu baseline: {cpu['value']:.4f} frames/s")
 
     if rank == 0:
         loss = trainer.loss_list[-1][2] if trainer.loss_list else None
