@@ -23,6 +23,8 @@
 #include "afd_common.h"
 #include "../../include/afd_hip.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -38,6 +40,9 @@ struct ConvGeom {
     int PR, PC;      // patch rows / cols
     int CI_T, nchunks, CKP, CO_PAD;
     int patchFloats;
+    int MW, NW, WNB;  // wave tile (MW x NW 32x32 tiles), waves along the pixel axis
+    int fast_stage;   // 1: a chunk's staging loads fit one register round per thread
+    int two_level;
 };
 
 __device__ __forceinline__ void tile_origin(const ConvGeom& g, int t, int& oy0, int& ox0,
@@ -67,35 +72,129 @@ __device__ __forceinline__ void tile_pixel(const ConvGeom& g, int pj, int oy0, i
     }
 }
 
-// stage input patch rows: rows go to waves, columns to lanes (coalesced along x)
+// Stage the input patch [CI_T][PR][PC]: columns go to lanes (coalesced along x), rows to
+// waves in groups of R.  All R loads of a group are issued before the first LDS store, so a
+// wave keeps R global loads in flight (a load-store-load-store chain is latency bound).
+template <int R>
 __device__ __forceinline__ void stage_patch(const ConvGeom& g, const float* __restrict__ x, int n,
-                                            int cin_total, int Hin, int Win, int chunk, int iy0,
-                                            int ix0, float* patch, int nthreads) {
+                                            int chunk, int iy0, int ix0, float* patch,
+                                            int nthreads) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int nwaves = nthreads >> 6;
     const int rows = g.CI_T * g.PR;
-    for (int row = wave; row < rows; row += nwaves) {
-        const int ci_l = row / g.PR;
-        const int pr = row - ci_l * g.PR;
+    const size_t plane = (size_t)g.H * g.W;
+    const float* xn = x + (size_t)n * g.Cin * plane;
+    for (int pc0 = 0; pc0 < g.PC; pc0 += 64) {
+        const int pc = pc0 + lane;
+        const int ix = ix0 + pc;
+        const bool colok = pc < g.PC;
+        const bool inx = colok && ix >= 0 && ix < g.W;
+        for (int row0 = wave * R; row0 < rows; row0 += nwaves * R) {
+            float v[R];
+            int ci_l = row0 / g.PR;
+            int pr = row0 - ci_l * g.PR;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int ci = chunk * g.CI_T + ci_l;
+                const int iy = iy0 + pr;
+                const bool ok = inx && (row0 + r < rows) && (ci < g.Cin) && (iy >= 0) && (iy < g.H);
+                v[r] = ok ? xn[(size_t)ci * plane + (size_t)iy * g.W + ix] : 0.f;
+                if (++pr == g.PR) {
+                    pr = 0;
+                    ++ci_l;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (colok && row0 + r < rows) patch[(row0 + r) * g.PC + pc] = v[r];
+        }
+    }
+}
+
+// q = e / d, r = e % d for 0 <= e < 2^23 through a float reciprocal (exact after one fix-up)
+__device__ __forceinline__ void divmod_small(int e, int d, float inv, int& q, int& r) {
+    q = (int)((float)e * inv);
+    r = e - q * d;
+    if (r < 0) {
+        r += d;
+        --q;
+    } else if (r >= d) {
+        r -= d;
+        ++q;
+    }
+}
+
+// Register prefetch of one channel chunk (weight slab + input patch): the loads are issued
+// right after the barrier that publishes the PREVIOUS chunk and stay in flight behind its
+// MFMAs; they are written to LDS one phase later (issue-early / write-late).
+constexpr int kZV = 16;  // wgrad: dz floats per thread (rows per wave)
+constexpr int kPW = 18;  // wgrad: patch floats per thread
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int kWV = 6;   // float4 of weights per thread
+constexpr int kPV = 12;  // patch floats per thread
+
+__device__ __forceinline__ void prefetch_chunk(const ConvGeom& g, const float* __restrict__ xn,
+                                               const float* __restrict__ wp, int chunk, int iy0,
+                                               int ix0, float invPC, float invPR, int tid,
+                                               int nthreads, float4 (&w)[kWV], float (&p)[kPV]) {
+    const int wslab = g.CKP * g.CO_PAD;
+    const int nvec = wslab >> 2;
+    const float4* src = reinterpret_cast<const float4*>(wp + (size_t)chunk * wslab);
+#pragma unroll
+    for (int u = 0; u < kWV; ++u) {
+        const int i = tid + u * nthreads;
+        w[u] = i < nvec ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int total = g.CI_T * g.PR * g.PC;
+    const size_t plane = (size_t)g.H * g.W;
+#pragma unroll
+    for (int u = 0; u < kPV; ++u) {
+        const int e = tid + u * nthreads;
+        int row, pc, ci_l, pr;
+        divmod_small(e, g.PC, invPC, row, pc);
+        divmod_small(row, g.PR, invPR, ci_l, pr);
         const int ci = chunk * g.CI_T + ci_l;
         const int iy = iy0 + pr;
-        const bool rowok = (ci < cin_total) && (iy >= 0) && (iy < Hin);
-        const float* src = x + ((size_t)(n * cin_total + (rowok ? ci : 0)) * Hin + (rowok ? iy : 0)) * Win;
-        float* dst = patch + row * g.PC;
-        for (int pc = lane; pc < g.PC; pc += 64) {
-            const int ix = ix0 + pc;
-            float v = 0.f;
-            if (rowok && ix >= 0 && ix < Win) v = src[ix];
-            dst[pc] = v;
-        }
+        const int ix = ix0 + pc;
+        const bool ok = (e < total) && (ci < g.Cin) && (iy >= 0) && (iy < g.H) && (ix >= 0) && (ix < g.W);
+        p[u] = ok ? xn[(size_t)ci * plane + (size_t)iy * g.W + ix] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void store_chunk(const ConvGeom& g, float* wlds, float* patch, int tid,
+                                            int nthreads, const float4 (&w)[kWV],
+                                            const float (&p)[kPV]) {
+    const int nvec = (g.CKP * g.CO_PAD) >> 2;
+    float4* dst = reinterpret_cast<float4*>(wlds);
+#pragma unroll
+    for (int u = 0; u < kWV; ++u) {
+        const int i = tid + u * nthreads;
+        if (i < nvec) dst[i] = w[u];
+    }
+    const int total = g.CI_T * g.PR * g.PC;
+#pragma unroll
+    for (int u = 0; u < kPV; ++u) {
+        const int e = tid + u * nthreads;
+        if (e < total) patch[e] = p[u];
     }
 }
 
 // ---------------------------------------------------------------------------------------
 // forward / backward-data
 // ---------------------------------------------------------------------------------------
-template <int NT>
+constexpr int igemm_min_waves(int mw, int nw, bool two) {
+    const int acc = mw * nw * 16 * (two ? 2 : 1);
+    return acc <= 64 ? 4 : (acc <= 100 ? 3 : 2);
+}
+
+template <int MW, int NW, bool TWO>
 __global__ void __launch_bounds__(512)
 conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __restrict__ wp,
                   const float* __restrict__ bias, float* __restrict__ y) {
@@ -108,9 +207,9 @@ conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __
     const int nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int WM = g.CO_PAD >> 5;
-    const int wm = wave % WM;
-    const int wn = wave / WM;
+    const int WMB = (g.CO_PAD >> 5) / MW;  // waves along the channel axis
+    const int wmb = wave % WMB;
+    const int wnb = wave / WMB;
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
@@ -122,11 +221,11 @@ conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __
     const int iy0 = oy0 - g.pad;
     const int ix0 = ox0 - g.pad;
 
-    int pbase[NT];
-    int oyv[NT], oxv[NT];
+    int pbase[NW];
+    int oyv[NW], oxv[NW];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int pj = (wn * NT + i) * 32 + l31;
+    for (int i = 0; i < NW; ++i) {
+        const int pj = (wnb * NW + i) * 32 + l31;
         int oy, ox;
         tile_pixel(g, pj, oy0, ox0, p0, oy, ox);
         const bool ok = (oy < g.Hout) && (ox < g.Wout);
@@ -148,58 +247,99 @@ conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __
         koff[kl] = o;
     }
 
-    f32x16 acc[NT];
+    f32x16 acc[MW][NW];
 #pragma unroll
-    for (int i = 0; i < NT; ++i)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
 
+    const float invPC = 1.0f / (float)g.PC;
+    const float invPR = 1.0f / (float)g.PR;
+    const float* xn = x + (size_t)n * g.Cin * g.H * g.W;
     const int wslab = g.CKP * g.CO_PAD;
     for (int chunk = 0; chunk < g.nchunks; ++chunk) {
-        __syncthreads();
-        {
+        __syncthreads();  // the previous chunk's fragments have been read
+        if (g.fast_stage) {
+            // every staging load of this thread is in flight before the first LDS store:
+            // one global-latency round per chunk instead of one per row group
+            float4 pfw[kWV];
+            float pfp[kPV];
+            prefetch_chunk(g, xn, wp, chunk, iy0, ix0, invPC, invPR, tid, nthreads, pfw, pfp);
+            store_chunk(g, wlds, patch, tid, nthreads, pfw, pfp);
+        } else {
             const float4* src = reinterpret_cast<const float4*>(wp + (size_t)chunk * wslab);
             float4* dst = reinterpret_cast<float4*>(wlds);
             for (int i = tid; i < (wslab >> 2); i += nthreads) dst[i] = src[i];
+            stage_patch<6>(g, x, n, chunk, iy0, ix0, patch, nthreads);
         }
-        stage_patch(g, x, n, g.Cin, g.H, g.W, chunk, iy0, ix0, patch, nthreads);
         __syncthreads();
-        const float* arow = wlds + wm * 32 + l31;
+        const float* arow = wlds + wmb * MW * 32 + l31;
         const int ksteps = g.CKP >> 1;
-        // two-level accumulation: a fresh fp32 chain per channel chunk, then one add --
-        // keeps the rounding error of K = Cin*K*K <= 1152 products near sqrt(chunk) * eps
-        f32x16 part[NT];
+        if (TWO) {
+            // two-level accumulation: a fresh fp32 chain per channel chunk, then one add --
+            // keeps the rounding error of K = Cin*K*K <= 1152 products near sqrt(chunk) * eps
+            f32x16 part[MW][NW];
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[i][r] = 0.f;
+                for (int i = 0; i < NW; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) part[m][i][r] = 0.f;
 #pragma unroll 4
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int k = 2 * ks + half;
-            const float a = arow[k * g.CO_PAD];
-            const int off = koff[k];
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int k = 2 * ks + half;
+                const int off = koff[k];
+                float a[MW], b[NW];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const float b = patch[off + pbase[i]];
-                part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
+                for (int m = 0; m < MW; ++m) a[m] = arow[k * g.CO_PAD + m * 32];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) b[i] = patch[off + pbase[i]];
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                    for (int i = 0; i < NW; ++i)
+                        part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[i], part[m][i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int i = 0; i < NW; ++i) acc[m][i] += part[m][i];
+        } else {
+#pragma unroll 4
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int k = 2 * ks + half;
+                const int off = koff[k];
+                float a[MW], b[NW];
+#pragma unroll
+                for (int m = 0; m < MW; ++m) a[m] = arow[k * g.CO_PAD + m * 32];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) b[i] = patch[off + pbase[i]];
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+#pragma unroll
+                    for (int i = 0; i < NW; ++i)
+                        acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[i], acc[m][i], 0, 0, 0);
             }
         }
-#pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] += part[i];
     }
 
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const size_t plane = (size_t)g.Hout * g.Wout;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
+    for (int i = 0; i < NW; ++i) {
         if (oyv[i] < 0) continue;
         const size_t pix = (size_t)oyv[i] * g.Wout + oxv[i];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < g.Cout) {
-                const float bv = bias ? bias[co] : 0.f;
-                y[((size_t)n * g.Cout + co) * plane + pix] = acc[i][r] + bv;
+        for (int m = 0; m < MW; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (wmb * MW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < g.Cout) {
+                    const float bv = bias ? bias[co] : 0.f;
+                    y[((size_t)n * g.Cout + co) * plane + pix] = acc[m][i][r] + bv;
+                }
             }
         }
     }
@@ -272,14 +412,40 @@ int ilog2_floor(int v) {
     return l;
 }
 
+// wave tiling per padded channel count: (MW x NW) 32x32 tiles per wave, WNB waves along pixels
+struct IgemmCfg {
+    int MW, NW, WNB, two;
+};
+
+IgemmCfg pick_cfg(int co_pad) {
+    IgemmCfg c;
+    switch (co_pad / 32) {
+        case 1: c = {1, 2, 4, 1}; break;   // 32 ch  x 256 px, 4 waves
+        case 2: c = {1, 2, 2, 1}; break;   // 64 ch  x 128 px, 2 x 2 waves
+        case 3: c = {3, 1, 4, 1}; break;   // 96 ch  x 128 px, 4 waves
+        default: c = {2, 2, 2, 1}; break;  // 128 ch x 128 px, 2 x 2 waves
+    }
+    // development override: AFD_IGEMM_CFG="MW,NW,WNB,two"
+    if (const char* e = getenv("AFD_IGEMM_CFG")) {
+        int a, b, d, t;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &t) == 4 && (co_pad / 32) % a == 0) c = {a, b, d, t};
+    }
+    return c;
+}
+
 // geometry for a conv whose input is [N][Cin][H][W] and output [N][Cout][Hout][Wout]
 int plan_igemm(ConvGeom& g, int N, int Cin, int H, int W, int Cout, int K, int pad, int dil,
-               int Hout, int Wout, int pix) {
+               int Hout, int Wout) {
     g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.K = K; g.pad = pad; g.dil = dil;
-    g.Hout = Hout; g.Wout = Wout; g.PIX = pix;
+    g.Hout = Hout; g.Wout = Wout;
     g.CO_PAD = ((Cout + 31) / 32) * 32;
+    const IgemmCfg cfg = pick_cfg(g.CO_PAD);
+    g.MW = cfg.MW; g.NW = cfg.NW; g.WNB = cfg.WNB; g.two_level = cfg.two;
+    const int pix = cfg.NW * cfg.WNB * 32;
+    g.PIX = pix;
+    const int nthreads = (g.CO_PAD / 32 / cfg.MW) * cfg.WNB * 64;
     const int KK = K * K;
-    int best = 0;
+    int best = 0, best_fast = 0;
     for (int attempt = 0; attempt < 2 && best == 0; ++attempt) {
         const bool rect = (Wout >= 4 * pix) != (attempt == 1);
         if (rect && Wout < pix) continue;
@@ -288,10 +454,20 @@ int plan_igemm(ConvGeom& g, int N, int Cin, int H, int W, int Cout, int K, int p
         for (int ct = 1; ct <= Cin && ct <= 32; ++ct) {
             const int ckp = (ct * KK + 1) & ~1;
             const long bytes = 4L * ((long)ckp * g.CO_PAD + (long)ct * g.PR * g.PC + 4 + ckp);
-            if (bytes <= kLdsBudget) best = ct;
+            const bool regs_ok = ((long)ckp * g.CO_PAD / 4 <= (long)kWV * nthreads) &&
+                                 ((long)ct * g.PR * g.PC <= (long)kPV * nthreads);
+            if (bytes <= kLdsBudget) {
+                best = ct;
+                if (regs_ok) best_fast = ct;
+            }
         }
     }
     if (best == 0) return afd::fail(AFD_ERR_UNSUPPORTED, "conv: tile does not fit LDS (K=%d dil=%d W=%d)", K, dil, W);
+    g.fast_stage = 0;
+    if (best_fast * 2 >= best || best_fast >= 8) {  // one-round staging unless it halves the chunk
+        best = best_fast;
+        g.fast_stage = 1;
+    }
     // prefer a chunk size that divides Cin (no zero-padded k rows)
     int ct = best;
     for (int c = best; c >= 1 && c * 2 > best; --c)
@@ -309,29 +485,36 @@ size_t igemm_lds_bytes(const ConvGeom& g) {
 
 size_t repack_floats(const ConvGeom& g) { return (size_t)g.nchunks * g.CKP * g.CO_PAD; }
 
+template <int MW, int NW>
+void launch_igemm_t(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y,
+                    unsigned blocks, int threads, hipStream_t s) {
+    if (g.two_level)
+        hipLaunchKernelGGL((conv_igemm_kernel<MW, NW, true>), dim3(blocks), dim3(threads),
+                           igemm_lds_bytes(g), s, g, x, wp, bias, y);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<MW, NW, false>), dim3(blocks), dim3(threads),
+                           igemm_lds_bytes(g), s, g, x, wp, bias, y);
+}
+
 int launch_igemm(const ConvGeom& g, const float* x, const float* wp, const float* bias, float* y,
                  hipStream_t s) {
-    const int WM = g.CO_PAD / 32;
-    const int NT = 2;
-    int WN = g.PIX / (32 * NT);
-    const int threads = WM * WN * 64;
+    const int threads = (g.CO_PAD / 32 / g.MW) * g.WNB * 64;
     if (threads > 512 || threads < 64) return afd::fail(AFD_ERR_UNSUPPORTED, "conv: Cout %d too large", g.Cout);
     const long blocks = (long)g.N * g.tilesX * g.tilesY;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv: grid too large");
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM,
                              2.0 * g.N * g.Cout * (double)g.Hout * g.Wout * g.Cin * g.K * g.K, s);
-    hipLaunchKernelGGL(conv_igemm_kernel<2>, dim3((unsigned)blocks), dim3(threads),
-                       igemm_lds_bytes(g), s, g, x, wp, bias, y);
+    const int key = g.MW * 10 + g.NW;
+    switch (key) {
+        case 12: launch_igemm_t<1, 2>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
+        case 14: launch_igemm_t<1, 4>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
+        case 21: launch_igemm_t<2, 1>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
+        case 22: launch_igemm_t<2, 2>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
+        case 31: launch_igemm_t<3, 1>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
+        case 41: launch_igemm_t<4, 1>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
+        default: return afd::fail(AFD_ERR_UNSUPPORTED, "conv: wave tile %dx%d not built", g.MW, g.NW);
+    }
     return afd::check_launch("conv_igemm_kernel");
-}
-
-// pixel tile width so that a workgroup has 4..8 waves
-int pick_pix(int co_pad) {
-    const int WM = co_pad / 32;
-    if (WM == 1) return 256;  // 1 x 4 waves
-    if (WM == 2) return 128;  // 2 x 2
-    if (WM == 3) return 128;  // 3 x 2
-    return 128;               // 4 x 2
 }
 
 // ---------------------------------------------------------------------------------------
@@ -344,6 +527,7 @@ struct WgradGeom {
     int NCOL;      // NTILES * 32
     int S;         // splits
     int PIXP;      // padded dz row
+    int fast_stage;
     long totalTiles;
 };
 
@@ -356,12 +540,16 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
     float* dzl = smem;                                  // [CO_PAD][PIXP]
     float* patch = dzl + g.CO_PAD * wg.PIXP;            // [CI_T][PR][PC]
     int* pixoff = reinterpret_cast<int*>(patch + g.patchFloats);  // [PIX]
+    float* bsum_lds = reinterpret_cast<float*>(pixoff + g.PIX);    // [CO_PAD]
 
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int nwaves = nthreads >> 6;
+    const float invPC = 1.0f / (float)g.PC;
+    const float invPR = 1.0f / (float)g.PR;
+    for (int i = tid; i < g.CO_PAD; i += nthreads) bsum_lds[i] = 0.f;
     const int m = wave % wg.MT;
     const int grp = wave / wg.MT;
     const int half = lane >> 5;
@@ -393,8 +581,6 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
     for (int i = 0; i < NTW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    float bsum = 0.f;
-
     const int tpi = g.tilesX * g.tilesY;
     for (long tile = split; tile < wg.totalTiles; tile += wg.S) {
         const int n = (int)(tile / tpi);
@@ -402,31 +588,85 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
         int oy0, ox0, p0;
         tile_origin(g, t, oy0, ox0, p0);
         __syncthreads();
-        // dz tile: rows (channels) to waves, pixels to lanes
-        for (int co = wave; co < g.CO_PAD; co += nwaves) {
-            for (int pj = lane; pj < g.PIX; pj += 64) {
-                int oy, ox;
-                tile_pixel(g, pj, oy0, ox0, p0, oy, ox);
-                float v = 0.f;
-                if (co < g.Cout && oy < g.Hout && ox < g.Wout)
-                    v = dz[(((size_t)n * g.Cout + co) * g.Hout + oy) * g.Wout + ox];
-                dzl[co * wg.PIXP + pj] = v;
+        if (wg.fast_stage) {
+            // one global-latency round per tile: every dz and patch load of this thread is in
+            // flight before the first LDS store.  dz element e -> (channel e / 64, pixel e % 64)
+            int oy, ox;
+            tile_pixel(g, lane, oy0, ox0, p0, oy, ox);
+            const bool pok = (oy < g.Hout) && (ox < g.Wout);
+            const unsigned oplane = (unsigned)(g.Hout * g.Wout);
+            const float* dzn = dz + (size_t)n * g.Cout * oplane;
+            const unsigned pixo = pok ? (unsigned)(oy * g.Wout + ox) : 0u;
+            if (wave == 0) pixoff[lane] = pok ? (oy - oy0) * g.PC + (ox - ox0) : 0;
+            float vz[kZV];
+#pragma unroll
+            for (int u = 0; u < kZV; ++u) {
+                const int co = wave + u * nwaves;
+                vz[u] = (pok && co < g.Cout) ? dzn[(unsigned)co * oplane + pixo] : 0.f;
+            }
+            const int total = g.CI_T * g.PR * g.PC;
+            const unsigned plane = (unsigned)(g.H * g.W);
+            const float* xn = x + (size_t)n * g.Cin * plane;
+            const int iy0 = oy0 - g.pad, ix0 = ox0 - g.pad;
+            float vp[kPW];
+#pragma unroll
+            for (int u = 0; u < kPW; ++u) {
+                const int e = tid + u * nthreads;
+                int row, pc, ci_l, pr;
+                divmod_small(e, g.PC, invPC, row, pc);
+                divmod_small(row, g.PR, invPR, ci_l, pr);
+                const int ci = chunk * g.CI_T + ci_l;
+                const int iy = iy0 + pr;
+                const int ix = ix0 + pc;
+                const bool ok = (e < total) && (ci < g.Cin) && (iy >= 0) && (iy < g.H) && (ix >= 0) && (ix < g.W);
+                vp[u] = ok ? xn[(unsigned)ci * plane + (unsigned)(iy * g.W + ix)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kZV; ++u) {
+                const int co = wave + u * nwaves;
+                if (co < g.CO_PAD) dzl[co * wg.PIXP + lane] = vz[u];
+            }
+#pragma unroll
+            for (int u = 0; u < kPW; ++u) {
+                const int e = tid + u * nthreads;
+                if (e < total) patch[e] = vp[u];
+            }
+            if (chunk == 0) {  // bias gradient: row sums of the staged dz tile
+#pragma unroll
+                for (int u = 0; u < kZV; ++u) {
+                    const int co = wave + u * nwaves;
+                    const float sm = wave_sum64(vz[u]);
+                    if (lane == 0 && co < g.CO_PAD) bsum_lds[co] += sm;  // one wave owns a row
+                }
+            }
+        } else {
+            int oy, ox;
+            tile_pixel(g, lane, oy0, ox0, p0, oy, ox);
+            const bool pok = (oy < g.Hout) && (ox < g.Wout);
+            const size_t oplane = (size_t)g.Hout * g.Wout;
+            const float* dzn = dz + (size_t)n * g.Cout * oplane + (pok ? (size_t)oy * g.Wout + ox : 0);
+            if (wave == 0) pixoff[lane] = pok ? (oy - oy0) * g.PC + (ox - ox0) : 0;
+            for (int co0 = wave * 8; co0 < g.CO_PAD; co0 += nwaves * 8) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int co = co0 + r;
+                    v[r] = (pok && co < g.Cout) ? dzn[(size_t)co * oplane] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    if (co0 + r < g.CO_PAD) dzl[(co0 + r) * wg.PIXP + lane] = v[r];
+            }
+            stage_patch<6>(g, x, n, chunk, oy0 - g.pad, ox0 - g.pad, patch, nthreads);
+            __syncthreads();
+            if (chunk == 0 && tid < g.CO_PAD) {
+                const float* row = dzl + tid * wg.PIXP;
+                float sm = 0.f;
+                for (int pj = 0; pj < g.PIX; ++pj) sm += row[pj];
+                bsum_lds[tid] += sm;
             }
         }
-        for (int pj = tid; pj < g.PIX; pj += nthreads) {
-            int oy, ox;
-            tile_pixel(g, pj, oy0, ox0, p0, oy, ox);
-            const bool ok = (oy < g.Hout) && (ox < g.Wout);
-            pixoff[pj] = ok ? (oy - oy0) * g.PC + (ox - ox0) : 0;
-        }
-        stage_patch(g, x, n, g.Cin, g.H, g.W, chunk, oy0 - g.pad, ox0 - g.pad, patch, nthreads);
         __syncthreads();
-        if (chunk == 0 && tid < g.CO_PAD) {
-            const float* row = dzl + tid * wg.PIXP;
-            float s = 0.f;
-            for (int pj = 0; pj < g.PIX; ++pj) s += row[pj];
-            bsum += s;
-        }
         const float* arow = dzl + (m * 32 + l31) * wg.PIXP;
         const int ksteps = g.PIX >> 1;
         // two-level accumulation (per 64-pixel tile, then across tiles): see forward kernel
@@ -442,10 +682,10 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
             const int po = pixoff[k];
 #pragma unroll
             for (int i = 0; i < NTW; ++i) {
-                if (nvalid[i]) {
-                    const float b = patch[joff[i] + po];
-                    part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
-                }
+                // no branch here: a column tile past NTILES reads offset 0 and feeds an
+                // accumulator that is never stored (a branch per MFMA blocks the scheduler)
+                const float b = patch[joff[i] + po];
+                part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -463,7 +703,8 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
             slab[(size_t)co * wg.NCOL + nt * 32 + l31] = acc[i][r];
         }
     }
-    if (chunk == 0 && tid < g.CO_PAD) partb[(size_t)split * g.CO_PAD + tid] = bsum;
+    __syncthreads();
+    if (chunk == 0 && tid < g.CO_PAD) partb[(size_t)split * g.CO_PAD + tid] = bsum_lds[tid];
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ partb,
@@ -503,7 +744,7 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
     wg.PIXP = pix + 1;
     wg.MT = g.CO_PAD / 32;
     const int ngmax = 8 / wg.MT > 1 ? 8 / wg.MT : 1;
-    const long fixed = 4L * ((long)g.CO_PAD * wg.PIXP + pix + 8);
+    const long fixed = 4L * ((long)g.CO_PAD * wg.PIXP + pix + 8 + g.CO_PAD);
     int best = 0;
     for (int attempt = 0; attempt < 2 && best == 0; ++attempt) {
         const bool rect = (Wout >= 4 * pix) != (attempt == 1);
@@ -528,6 +769,11 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
     int NG = ngmax;
     if (NG > wg.NTILES) NG = wg.NTILES;
     wg.NG = NG;
+    {
+        const int nthreads = wg.MT * wg.NG * 64;
+        wg.fast_stage = getenv("AFD_WGRAD_FAST") != nullptr && (g.CO_PAD <= kZV * (nthreads / 64)) &&
+                        ((long)ct * g.PR * g.PC <= (long)kPW * nthreads) && pix == 64;
+    }
     wg.totalTiles = (long)N * g.tilesX * g.tilesY;
     long S = 1024 / g.nchunks;
     if (S < 1) S = 1;
@@ -537,7 +783,7 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
 }
 
 size_t wgrad_lds_bytes(const WgradGeom& wg) {
-    return 4 * ((size_t)wg.c.CO_PAD * wg.PIXP + wg.c.patchFloats + wg.c.PIX);
+    return 4 * ((size_t)wg.c.CO_PAD * wg.PIXP + wg.c.patchFloats + wg.c.PIX + wg.c.CO_PAD);
 }
 
 size_t wgrad_ws_floats(const WgradGeom& wg) {
@@ -571,13 +817,11 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
     if (Hout < 1 || Wout < 1) return 0;
     size_t need = 0;
     ConvGeom g;
-    if (plan_igemm(g, N, Cin, H, W, Cout, K, pad, dil, Hout, Wout,
-                   pick_pix(((Cout + 31) / 32) * 32)) == AFD_OK)
+    if (plan_igemm(g, N, Cin, H, W, Cout, K, pad, dil, Hout, Wout) == AFD_OK)
         need = align_up(repack_floats(g) * 4);
     ConvGeom gd;
     const int padd = dil * (K - 1) - pad;
-    if (plan_igemm(gd, N, Cout, Hout, Wout, Cin, K, padd, dil, H, W,
-                   pick_pix(((Cin + 31) / 32) * 32)) == AFD_OK) {
+    if (plan_igemm(gd, N, Cout, Hout, Wout, Cin, K, padd, dil, H, W) == AFD_OK) {
         const size_t b = align_up(repack_floats(gd) * 4);
         if (b > need) need = b;
     }
@@ -608,7 +852,7 @@ extern "C" int afd_conv2d_forward(const float* x, const float* w, const float* b
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     ConvGeom g;
-    rc = plan_igemm(g, N, Cin, H, W, Cout, K, pad, dil, Hout, Wout, pick_pix(((Cout + 31) / 32) * 32));
+    rc = plan_igemm(g, N, Cin, H, W, Cout, K, pad, dil, Hout, Wout);
     if (rc) return rc;
     if (!ws || ws_bytes < repack_floats(g) * 4) return afd::fail(AFD_ERR_WORKSPACE, "conv fwd: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -631,7 +875,7 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
     const int Wout = W + 2 * pad - dil * (K - 1);
     const int padd = dil * (K - 1) - pad;
     ConvGeom g;
-    rc = plan_igemm(g, N, Cout, Hout, Wout, Cin, K, padd, dil, H, W, pick_pix(((Cin + 31) / 32) * 32));
+    rc = plan_igemm(g, N, Cout, Hout, Wout, Cin, K, padd, dil, H, W);
     if (rc) return rc;
     if (!ws || ws_bytes < repack_floats(g) * 4) return afd::fail(AFD_ERR_WORKSPACE, "conv dgrad: workspace too small");
     hipStream_t s = static_cast<hipStream_t>(stream);
