@@ -154,21 +154,24 @@ class _PReLUPool(torch.autograd.Function):
         _native.check(lib.afd_prelu_pool_forward(_native.ptr(z), _native.ptr(slope), _native.ptr(u),
                                                  _native.ptr(idx), n * c, h, w,
                                                  _native.stream_ptr()), "afd_prelu_pool_forward")
-        ctx.save_for_backward(z, idx, slope if slope is not None else torch.empty(0))
+        # backward needs only the pooled output and the 3-bit argmax code: the 4x larger
+        # pre-pool tensor z is not kept alive
+        ctx.save_for_backward(u, idx, slope if slope is not None else torch.empty(0))
         ctx.has_slope = slope is not None
+        ctx.zshape = (n, c, h, w)
         return u
 
     @staticmethod
     def backward(ctx, du):
         lib = _lib()
-        z, idx, slope = ctx.saved_tensors
+        u, idx, slope = ctx.saved_tensors
         slope = slope if ctx.has_slope else None
-        n, c, h, w = z.shape
+        n, c, h, w = ctx.zshape
         du = _f32c(du)
-        dz = torch.empty_like(z)
-        dslope = torch.zeros(1, dtype=torch.float32, device=z.device) if ctx.has_slope else None
+        dz = torch.empty((n, c, h, w), dtype=torch.float32, device=u.device)
+        dslope = torch.zeros(1, dtype=torch.float32, device=u.device) if ctx.has_slope else None
         _native.check(lib.afd_prelu_pool_backward(
-            _native.ptr(z), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(dz),
+            _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(dz),
             _native.ptr(dslope), n * c, h, w, _native.stream_ptr()), "afd_prelu_pool_backward")
         return dz, dslope
 

@@ -109,89 +109,100 @@ __global__ void prelu_dropout_bwd_kernel(const float* __restrict__ z, const floa
 }
 
 // ------------------------------- PReLU + MaxPool 2x2 -----------------------------------
-// z [NC][H][W] -> u [NC][Hp][Wp] (= max of prelu over the window, first max wins like
-// torch), idx = argmax position 0..3 (dy*2+dx)
+// q = e / d, r = e % d for 0 <= e < 2^23 through a float reciprocal (exact after one fix-up)
+__device__ __forceinline__ void divmod_small(int e, int d, float inv, int& q, int& r) {
+    q = (int)((float)e * inv);
+    r = e - q * d;
+    if (r < 0) {
+        r += d;
+        --q;
+    } else if (r >= d) {
+        r -= d;
+        ++q;
+    }
+}
+
+// z [NC][H][W] -> u [NC][Hp][Wp] = max of prelu over the 2x2 window (first max wins, like
+// torch); idx bits 0-1 = argmax position dy*2+dx, bit 2 = the winning z was <= 0 (so the
+// backward pass needs neither z nor a second look at the window).  VEC: float2 row loads.
+template <bool VEC>
 __global__ void prelu_pool_fwd_kernel(const float* __restrict__ z, const float* __restrict__ slope,
                                       float* __restrict__ u, unsigned char* __restrict__ idx, int H,
-                                      int W, int Hp, int Wp) {
+                                      int W, int Hp, int Wp, float invWp) {
     const float a = slope ? slope[0] : 1.f;
     const size_t plane = blockIdx.y;
     const float* zp = z + plane * (size_t)H * W;
     const size_t obase = plane * (size_t)Hp * Wp;
     const int total = Hp * Wp;
     for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
-        const int py = i / Wp, px = i - py * Wp;
+        int py, px;
+        divmod_small(i, Wp, invWp, py, px);
         const float* r0 = zp + (size_t)(2 * py) * W + 2 * px;
-        const float2 t = *reinterpret_cast<const float2*>(r0);
-        const float2 b = *reinterpret_cast<const float2*>(r0 + W);
-        float best = slope ? prelu(t.x, a) : t.x;
+        float z0, z1, z2, z3;
+        if (VEC) {
+            const float2 t = *reinterpret_cast<const float2*>(r0);
+            const float2 b = *reinterpret_cast<const float2*>(r0 + W);
+            z0 = t.x; z1 = t.y; z2 = b.x; z3 = b.y;
+        } else {
+            z0 = r0[0]; z1 = r0[1]; z2 = r0[W]; z3 = r0[W + 1];
+        }
+        float best = slope ? prelu(z0, a) : z0, zb = z0;
         int bi = 0;
-        float v = slope ? prelu(t.y, a) : t.y;
-        if (v > best) { best = v; bi = 1; }
-        v = slope ? prelu(b.x, a) : b.x;
-        if (v > best) { best = v; bi = 2; }
-        v = slope ? prelu(b.y, a) : b.y;
-        if (v > best) { best = v; bi = 3; }
+        float v = slope ? prelu(z1, a) : z1;
+        if (v > best) { best = v; bi = 1; zb = z1; }
+        v = slope ? prelu(z2, a) : z2;
+        if (v > best) { best = v; bi = 2; zb = z2; }
+        v = slope ? prelu(z3, a) : z3;
+        if (v > best) { best = v; bi = 3; zb = z3; }
         u[obase + i] = best;
-        idx[obase + i] = (unsigned char)bi;
+        idx[obase + i] = (unsigned char)(bi | ((slope && zb <= 0.f) ? 4 : 0));
     }
 }
 
-// unaligned-safe variant (odd W or odd plane offsets): scalar loads
-__global__ void prelu_pool_fwd_kernel_s(const float* __restrict__ z, const float* __restrict__ slope,
-                                        float* __restrict__ u, unsigned char* __restrict__ idx,
-                                        int H, int W, int Hp, int Wp) {
-    const float a = slope ? slope[0] : 1.f;
-    const size_t plane = blockIdx.y;
-    const float* zp = z + plane * (size_t)H * W;
-    const size_t obase = plane * (size_t)Hp * Wp;
-    const int total = Hp * Wp;
-    for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
-        const int py = i / Wp, px = i - py * Wp;
-        const float* r0 = zp + (size_t)(2 * py) * W + 2 * px;
-        float best = slope ? prelu(r0[0], a) : r0[0];
-        int bi = 0;
-        float v = slope ? prelu(r0[1], a) : r0[1];
-        if (v > best) { best = v; bi = 1; }
-        v = slope ? prelu(r0[W], a) : r0[W];
-        if (v > best) { best = v; bi = 2; }
-        v = slope ? prelu(r0[W + 1], a) : r0[W + 1];
-        if (v > best) { best = v; bi = 3; }
-        u[obase + i] = best;
-        idx[obase + i] = (unsigned char)bi;
-    }
-}
-
-// dz [NC][H][W] fully written (zeros outside the argmax, incl. the odd last row/col)
-__global__ void prelu_pool_bwd_kernel(const float* __restrict__ z, const float* __restrict__ slope,
+// du [NC][Hp][Wp] -> dz [NC][H][W], fully written (zeros off the argmax and in the odd last
+// row / column).  Through the PReLU: dz = a g and dslope += g z with z = u / a where bit 2 of
+// idx is set (slope exactly 0 loses that term: z is not recoverable from u = 0).
+template <bool VEC>
+__global__ void prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slope,
                                       const unsigned char* __restrict__ idx,
                                       const float* __restrict__ du, float* __restrict__ dz,
-                                      float* __restrict__ dslope, int H, int W, int Hp, int Wp) {
+                                      float* __restrict__ dslope, int H, int W, int Hp, int Wp,
+                                      float invWp) {
     const float a = slope ? slope[0] : 1.f;
+    const float inva = (slope && a != 0.f) ? 1.f / a : 0.f;
     const size_t plane = blockIdx.y;
-    const float* zp = z + plane * (size_t)H * W;
     float* dzp = dz + plane * (size_t)H * W;
     const size_t pbase = plane * (size_t)Hp * Wp;
-    const int total = H * W;
+    const int total = Hp * Wp;
     float ds = 0.f, u0 = 0.f, u1 = 0.f;
     for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
-        const int y = i / W, x = i - y * W;
-        const int py = y >> 1, px = x >> 1;
-        float g = 0.f;
-        if (py < Hp && px < Wp) {
-            const int pos = ((y & 1) << 1) | (x & 1);
-            if (idx[pbase + (size_t)py * Wp + px] == pos) {
-                g = du[pbase + (size_t)py * Wp + px];
-                if (slope) {
-                    const float zz = zp[i];
-                    if (zz <= 0.f) {
-                        ds += g * zz;
-                        g *= a;
-                    }
-                }
-            }
+        int py, px;
+        divmod_small(i, Wp, invWp, py, px);
+        const int code = idx[pbase + i];
+        float g = du[pbase + i];
+        if (code & 4) {
+            ds += g * u[pbase + i] * inva;
+            g *= a;
         }
-        dzp[i] = g;
+        const int pos = code & 3;
+        float* r0 = dzp + (size_t)(2 * py) * W + 2 * px;
+        const float g0 = pos == 0 ? g : 0.f, g1 = pos == 1 ? g : 0.f;
+        const float g2 = pos == 2 ? g : 0.f, g3 = pos == 3 ? g : 0.f;
+        if (VEC) {
+            *reinterpret_cast<float2*>(r0) = make_float2(g0, g1);
+            *reinterpret_cast<float2*>(r0 + W) = make_float2(g2, g3);
+        } else {
+            r0[0] = g0; r0[1] = g1; r0[W] = g2; r0[W + 1] = g3;
+        }
+        if ((W & 1) && px == Wp - 1) {  // odd width: last column belongs to no window
+            dzp[(size_t)(2 * py) * W + W - 1] = 0.f;
+            dzp[(size_t)(2 * py + 1) * W + W - 1] = 0.f;
+        }
+        if ((H & 1) && py == Hp - 1) {  // odd height: last row
+            dzp[(size_t)(H - 1) * W + 2 * px] = 0.f;
+            dzp[(size_t)(H - 1) * W + 2 * px + 1] = 0.f;
+            if ((W & 1) && px == Wp - 1) dzp[(size_t)(H - 1) * W + W - 1] = 0.f;
+        }
     }
     if (slope) {
         block_sum3(ds, u0, u1);
@@ -200,25 +211,53 @@ __global__ void prelu_pool_bwd_kernel(const float* __restrict__ z, const float* 
 }
 
 // ------------------------------- BatchNorm ---------------------------------------------
+// Visits the HW elements of one (n, c) plane with 16-byte accesses: a scalar head up to the
+// first 16-byte boundary of the tensor, float4 body, scalar tail.  f1(i) / f4(i) receive the
+// element index inside the plane; blocks along x share the plane.
+template <typename F1, typename F4>
+__device__ __forceinline__ void plane_loop(size_t plane_base, int HW, int bx, int nbx, F1 f1, F4 f4) {
+    int head = (int)((4 - (plane_base & 3)) & 3);
+    if (head > HW) head = HW;
+    const int nvec = (HW - head) >> 2;
+    for (int v = bx * kT + threadIdx.x; v < nvec; v += nbx * kT) f4(head + 4 * v);
+    if (bx == 0) {
+        if ((int)threadIdx.x < head) f1((int)threadIdx.x);
+        const int t = head + 4 * nvec + (int)threadIdx.x;
+        if (threadIdx.x < 4 && t < HW) f1(t);
+    }
+}
+
 // per-channel sum and sum of squares of (optionally PReLU'd) x [N][C][HW]; double atomics
 __global__ void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ slope,
                                 double* __restrict__ sums, int N, int C, int HW) {
     const int c = blockIdx.x;
-    const float a = slope ? slope[0] : 1.f;
-    float s = 0.f, q = 0.f, u = 0.f;
+    const bool act = slope != nullptr;
+    const float a = act ? slope[0] : 1.f;
+    float s = 0.f, q = 0.f, un = 0.f;
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
-        const float* p = x + ((size_t)n * C + c) * HW;
+        const size_t base = ((size_t)n * C + c) * HW;
+        const float* p = x + base;
         float ls = 0.f, lq = 0.f;
-        for (int i = threadIdx.x; i < HW; i += kT) {
-            float v = p[i];
-            if (slope) v = prelu(v, a);
-            ls += v;
-            lq += v * v;
-        }
+        plane_loop(base, HW, 0, 1,
+                   [&](int i) {
+                       float v = p[i];
+                       if (act) v = prelu(v, a);
+                       ls += v;
+                       lq += v * v;
+                   },
+                   [&](int i) {
+                       float4 v = *reinterpret_cast<const float4*>(p + i);
+                       if (act) {
+                           v.x = prelu(v.x, a); v.y = prelu(v.y, a);
+                           v.z = prelu(v.z, a); v.w = prelu(v.w, a);
+                       }
+                       ls += (v.x + v.y) + (v.z + v.w);
+                       lq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                   });
         s += ls;
         q += lq;
     }
-    block_sum3(s, q, u);
+    block_sum3(s, q, un);
     if (threadIdx.x == 0) {
         atomicAdd(&sums[c], (double)s);
         atomicAdd(&sums[C + c], (double)q);
@@ -232,17 +271,20 @@ __global__ void bn_apply_fwd_kernel(const float* __restrict__ x, const float* __
                                     float* __restrict__ y, int C, int HW) {
     const size_t plane = blockIdx.y;
     const int c = (int)(plane % C);
-    const float a = slope ? slope[0] : 1.f;
+    const bool act = slope != nullptr;
+    const float a = act ? slope[0] : 1.f;
     const float m = mean[c];
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
     const float sh = beta ? beta[c] : 0.f;
-    const float* xp = x + plane * (size_t)HW;
-    float* yp = y + plane * (size_t)HW;
-    for (int i = blockIdx.x * kT + threadIdx.x; i < HW; i += gridDim.x * kT) {
-        float v = xp[i];
-        if (slope) v = prelu(v, a);
-        yp[i] = (v - m) * sc + sh;
-    }
+    const size_t base = plane * (size_t)HW;
+    const float* xp = x + base;
+    float* yp = y + base;
+    auto one = [&](float v) { return ((act ? prelu(v, a) : v) - m) * sc + sh; };
+    plane_loop(base, HW, blockIdx.x, gridDim.x, [&](int i) { yp[i] = one(xp[i]); },
+               [&](int i) {
+                   const float4 v = *reinterpret_cast<const float4*>(xp + i);
+                   *reinterpret_cast<float4*>(yp + i) = make_float4(one(v.x), one(v.y), one(v.z), one(v.w));
+               });
 }
 
 // per-channel sum(dy), sum(dy * xhat)
@@ -251,23 +293,30 @@ __global__ void bn_bwd_stats_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ invstd, double* __restrict__ sums,
                                     int N, int C, int HW) {
     const int c = blockIdx.x;
-    const float a = slope ? slope[0] : 1.f;
+    const bool act = slope != nullptr;
+    const float a = act ? slope[0] : 1.f;
     const float m = mean[c], is = invstd[c];
-    float s = 0.f, q = 0.f, u = 0.f;
+    float s = 0.f, q = 0.f, un = 0.f;
     for (int n = blockIdx.y; n < N; n += gridDim.y) {
-        const size_t off = ((size_t)n * C + c) * HW;
+        const size_t base = ((size_t)n * C + c) * HW;
+        const float* xp = x + base;
+        const float* gp = dy + base;
         float ls = 0.f, lq = 0.f;
-        for (int i = threadIdx.x; i < HW; i += kT) {
-            float v = x[off + i];
-            if (slope) v = prelu(v, a);
-            const float g = dy[off + i];
+        auto one = [&](float v, float g) {
+            if (act) v = prelu(v, a);
             ls += g;
             lq += g * (v - m) * is;
-        }
+        };
+        plane_loop(base, HW, 0, 1, [&](int i) { one(xp[i], gp[i]); },
+                   [&](int i) {
+                       const float4 v = *reinterpret_cast<const float4*>(xp + i);
+                       const float4 g = *reinterpret_cast<const float4*>(gp + i);
+                       one(v.x, g.x); one(v.y, g.y); one(v.z, g.z); one(v.w, g.w);
+                   });
         s += ls;
         q += lq;
     }
-    block_sum3(s, q, u);
+    block_sum3(s, q, un);
     if (threadIdx.x == 0) {
         atomicAdd(&sums[c], (double)s);
         atomicAdd(&sums[C + c], (double)q);
@@ -283,24 +332,34 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     int HW) {
     const size_t plane = blockIdx.y;
     const int c = (int)(plane % C);
-    const float a = slope ? slope[0] : 1.f;
+    const bool act = slope != nullptr;
+    const float a = act ? slope[0] : 1.f;
     const float m = mean[c], is = invstd[c];
     const float gs = is * (gamma ? gamma[c] : 1.f);
     const float k0 = mdy[c], k1 = mdyx[c];
-    const size_t off = plane * (size_t)HW;
+    const size_t base = plane * (size_t)HW;
+    const float* xp = x + base;
+    const float* gp = dy + base;
+    float* op = dx + base;
     float ds = 0.f, u0 = 0.f, u1 = 0.f;
-    for (int i = blockIdx.x * kT + threadIdx.x; i < HW; i += gridDim.x * kT) {
-        const float zz = x[off + i];
-        const float v = slope ? prelu(zz, a) : zz;
+    auto one = [&](float zz, float gy) {
+        const float v = act ? prelu(zz, a) : zz;
         const float xh = (v - m) * is;
-        float g = gs * (dy[off + i] - k0 - xh * k1);
-        if (slope && zz <= 0.f) {
+        float g = gs * (gy - k0 - xh * k1);
+        if (act && zz <= 0.f) {
             ds += g * zz;
             g *= a;
         }
-        dx[off + i] = g;
-    }
-    if (slope) {
+        return g;
+    };
+    plane_loop(base, HW, blockIdx.x, gridDim.x, [&](int i) { op[i] = one(xp[i], gp[i]); },
+               [&](int i) {
+                   const float4 v = *reinterpret_cast<const float4*>(xp + i);
+                   const float4 g = *reinterpret_cast<const float4*>(gp + i);
+                   *reinterpret_cast<float4*>(op + i) =
+                       make_float4(one(v.x, g.x), one(v.y, g.y), one(v.z, g.z), one(v.w, g.w));
+               });
+    if (act) {
         block_sum3(ds, u0, u1);
         if (threadIdx.x == 0 && ds != 0.f) atomicAdd(dslope, ds);
     }
@@ -493,35 +552,39 @@ extern "C" int afd_prelu_dropout_backward(const float* z, const float* slope, co
 extern "C" int afd_prelu_pool_forward(const float* z, const float* slope, float* u, uint8_t* idx,
                                       int NC, int H, int W, afd_stream_t stream) {
     if (!z || !u || !idx || NC < 1 || H < 2 || W < 2) return afd::fail(AFD_ERR_ARG, "pool fwd: bad argument");
-    if (NC > 65535 * 16) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: too many planes");
     const int Hp = H / 2, Wp = W / 2;
-    const unsigned gx = grid1d((size_t)Hp * Wp, 256);
-    // float2 loads need 8-byte aligned rows: even W and an even plane size
-    const bool aligned = (W % 2 == 0) && (((size_t)H * W) % 2 == 0) && (((uintptr_t)z & 7) == 0);
+    if ((long)Hp * Wp >= (1L << 23)) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: plane too large");
+    const unsigned gx = grid1d((size_t)Hp * Wp, 64);
+    // float2 rows need 8-byte alignment: even W, even plane size, 8-byte aligned base
+    const bool vec = (W % 2 == 0) && (((size_t)H * W) % 2 == 0) && (((uintptr_t)z & 7) == 0);
     for (int p0 = 0; p0 < NC; p0 += 65535) {
         const int np = NC - p0 < 65535 ? NC - p0 : 65535;
         const float* zp = z + (size_t)p0 * H * W;
         float* up = u + (size_t)p0 * Hp * Wp;
         uint8_t* ip = idx + (size_t)p0 * Hp * Wp;
-        if (aligned)
-            hipLaunchKernelGGL(prelu_pool_fwd_kernel, dim3(gx, np), dim3(kT), 0, AFD_STREAM, zp, slope, up, ip, H, W, Hp, Wp);
+        if (vec)
+            hipLaunchKernelGGL(prelu_pool_fwd_kernel<true>, dim3(gx, np), dim3(kT), 0, AFD_STREAM, zp, slope, up, ip, H, W, Hp, Wp, 1.0f / Wp);
         else
-            hipLaunchKernelGGL(prelu_pool_fwd_kernel_s, dim3(gx, np), dim3(kT), 0, AFD_STREAM, zp, slope, up, ip, H, W, Hp, Wp);
+            hipLaunchKernelGGL(prelu_pool_fwd_kernel<false>, dim3(gx, np), dim3(kT), 0, AFD_STREAM, zp, slope, up, ip, H, W, Hp, Wp, 1.0f / Wp);
     }
     return afd::check_launch("prelu_pool_fwd_kernel");
 }
 
-extern "C" int afd_prelu_pool_backward(const float* z, const float* slope, const uint8_t* idx,
+extern "C" int afd_prelu_pool_backward(const float* u, const float* slope, const uint8_t* idx,
                                        const float* du, float* dz, float* dslope, int NC, int H,
                                        int W, afd_stream_t stream) {
-    if (!z || !idx || !du || !dz || (slope && !dslope)) return afd::fail(AFD_ERR_ARG, "pool bwd: null pointer");
+    if (!u || !idx || !du || !dz || (slope && !dslope)) return afd::fail(AFD_ERR_ARG, "pool bwd: null pointer");
     const int Hp = H / 2, Wp = W / 2;
-    const unsigned gx = grid1d((size_t)H * W, 256);
+    if ((long)Hp * Wp >= (1L << 23)) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: plane too large");
+    const unsigned gx = grid1d((size_t)Hp * Wp, 64);
+    const bool vec = (W % 2 == 0) && (((size_t)H * W) % 2 == 0) && (((uintptr_t)dz & 7) == 0);
     for (int p0 = 0; p0 < NC; p0 += 65535) {
         const int np = NC - p0 < 65535 ? NC - p0 : 65535;
-        hipLaunchKernelGGL(prelu_pool_bwd_kernel, dim3(gx, np), dim3(kT), 0, AFD_STREAM,
-                           z + (size_t)p0 * H * W, slope, idx + (size_t)p0 * Hp * Wp,
-                           du + (size_t)p0 * Hp * Wp, dz + (size_t)p0 * H * W, dslope, H, W, Hp, Wp);
+        const size_t po = (size_t)p0 * Hp * Wp;
+        if (vec)
+            hipLaunchKernelGGL(prelu_pool_bwd_kernel<true>, dim3(gx, np), dim3(kT), 0, AFD_STREAM, u + po, slope, idx + po, du + po, dz + (size_t)p0 * H * W, dslope, H, W, Hp, Wp, 1.0f / Wp);
+        else
+            hipLaunchKernelGGL(prelu_pool_bwd_kernel<false>, dim3(gx, np), dim3(kT), 0, AFD_STREAM, u + po, slope, idx + po, du + po, dz + (size_t)p0 * H * W, dslope, H, W, Hp, Wp, 1.0f / Wp);
     }
     return afd::check_launch("prelu_pool_bwd_kernel");
 }
@@ -542,7 +605,7 @@ extern "C" int afd_bn_apply_forward(const float* x, const float* slope, const fl
                                     float* y, int N, int C, int HW, afd_stream_t stream) {
     if (!x || !mean || !invstd || !y) return afd::fail(AFD_ERR_ARG, "bn apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn apply: N*C > 65535");
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid1d(HW, 64), N * C), dim3(kT), 0, AFD_STREAM, x,
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid1d((size_t)HW / 16 + 1, 16), N * C), dim3(kT), 0, AFD_STREAM, x,
                        slope, mean, invstd, gamma, beta, y, C, HW);
     return afd::check_launch("bn_apply_fwd_kernel");
 }
@@ -567,7 +630,7 @@ extern "C" int afd_bn_backward_apply(const float* x, const float* slope, const f
     if (!x || !dy || !mean || !invstd || !mean_dy || !mean_dy_xhat || !dx || (slope && !dslope))
         return afd::fail(AFD_ERR_ARG, "bn bwd apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn bwd apply: N*C > 65535");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d(HW, 64), N * C), dim3(kT), 0, AFD_STREAM, x,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d((size_t)HW / 16 + 1, 16), N * C), dim3(kT), 0, AFD_STREAM, x,
                        slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, C, HW);
     return afd::check_launch("bn_bwd_apply_kernel");
 }

@@ -115,11 +115,13 @@ int afd_prelu_dropout_backward(const float* z, const float* slope, const float* 
                                float* dslope /* += */, size_t n, float p, uint64_t seed,
                                afd_stream_t stream);
 
-/* PReLU + MaxPool2d(2,2) (models.py:258-259): z [NC][H][W] -> u [NC][H/2][W/2], idx = argmax
- * position (dy*2+dx) of each window; slope may be NULL (plain max pool) */
+/* PReLU + MaxPool2d(2,2) (models.py:258-259): z [NC][H][W] -> u [NC][H/2][W/2]; idx bits 0-1 =
+ * argmax position (dy*2+dx) of each window, bit 2 = the winning z was <= 0; slope may be NULL
+ * (plain max pool).  Backward takes the pooled OUTPUT u (not z): dz [NC][H][W] is fully
+ * written; with a slope of exactly 0 the dslope term of pooled positions is lost. */
 int afd_prelu_pool_forward(const float* z, const float* slope, float* u, uint8_t* idx, int NC,
                            int H, int W, afd_stream_t stream);
-int afd_prelu_pool_backward(const float* z, const float* slope, const uint8_t* idx,
+int afd_prelu_pool_backward(const float* u, const float* slope, const uint8_t* idx,
                             const float* du, float* dz, float* dslope /* += */, int NC, int H,
                             int W, afd_stream_t stream);
 
