@@ -76,6 +76,24 @@ int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo, const flo
                     float std, float* out, void* ws, size_t ws_bytes, afd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * STFT power spectrogram front end.
+ * Replaces: STFTLayer.forward = torchaudio Spectrogram(n_fft, hop_length, power) + log
+ *           (reference src/audiofakedetect/wavelet_math.py:47,63-68) and Normalize (:380-382).
+ *           Periodic Hann window of n_fft, centre, reflect pad n_fft/2, one-sided.
+ * afd_stft_dims   : F = n_fft/2+1 bins, T = 1 + N/hop frames, shape of the basis matrix.
+ * afd_stft_basis  : fills the [basis_rows][basis_cols] windowed DFT basis on the HOST; the
+ *                   caller uploads it once and passes the device copy to afd_stft_forward.
+ * afd_stft_forward: x [dev] [B][N] -> out [dev] [B][1][F][T] (T fastest).
+ * ---------------------------------------------------------------------------------- */
+#define AFD_STFT_LOG 1u  /* log(|X|^power + eps) */
+#define AFD_STFT_NORM 4u /* (v - mean) / std     */
+int afd_stft_dims(int N, int n_fft, int hop, int* F, int* T, int* basis_rows, int* basis_cols);
+int afd_stft_basis(int n_fft, float* basis /* [host] */);
+int afd_stft_forward(const float* x, int B, int N, int n_fft, int hop, const float* basis,
+                     unsigned flags, float power, float eps, float mean, float std, float* out,
+                     afd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Conv2d, stride 1, square kernel K, zero padding `pad`, dilation `dil`, NCHW fp32.
  * Replaces: the cuDNN forward / backward-data / backward-weight launches behind every
  *           nn.Conv2d of DCNN / LCNN (reference src/audiofakedetect/models.py:255-291,
