@@ -186,6 +186,38 @@ def _dist_on(sync: bool) -> bool:
     return sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=None, nbt=None,
+                momentum=0.1):
+    """Batch statistics from the packed per-channel [sum | sum of squares | count] vector.
+
+    With a process group up (and `sync`) the packed vector is all-reduced first, so mean and
+    variance are those of the GLOBAL batch with per-rank counts, as nn.SyncBatchNorm computes
+    them (reference models.py:260-289).  Updates the running statistics in place (unbiased
+    variance, reference momentum).  Device agnostic: also used by the CPU gloo tests.
+    """
+    if _dist_on(sync):
+        sums[2 * c] = local_count
+        dist.all_reduce(sums)
+        cnt = sums[2 * c].clone()
+    else:
+        cnt = torch.tensor(float(local_count), dtype=torch.float64, device=sums.device)
+    mean64 = sums[:c] / cnt
+    var64 = (sums[c:2 * c] / cnt - mean64 * mean64).clamp_(min=0.0)
+    mean = mean64.float()
+    invstd = torch.rsqrt(var64 + eps).float()
+    if running_mean is not None:
+        with torch.no_grad():
+            mom = momentum
+            if nbt is not None:
+                nbt += 1
+                if mom is None:
+                    mom = 1.0 / float(nbt)
+            unbiased = var64 * (cnt / (cnt - 1.0).clamp_(min=1.0))
+            running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            running_var.mul_(1.0 - mom).add_(unbiased.float(), alpha=mom)
+    return mean, invstd, cnt
+
+
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
@@ -200,26 +232,8 @@ class _BatchNorm(torch.autograd.Function):
             sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
             _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c,
                                            hw, _native.stream_ptr()), "afd_bn_stats")
-            if _dist_on(sync):
-                sums[2 * c] = count
-                dist.all_reduce(sums)
-                cnt = sums[2 * c]
-            else:
-                cnt = torch.tensor(count, dtype=torch.float64, device=dev)
-            mean64 = sums[:c] / cnt
-            var64 = (sums[c:2 * c] / cnt - mean64 * mean64).clamp_(min=0.0)
-            mean = mean64.float()
-            invstd = torch.rsqrt(var64 + eps).float()
-            if running_mean is not None:
-                with torch.no_grad():
-                    mom = momentum
-                    if nbt is not None:
-                        nbt += 1
-                        if mom is None:
-                            mom = 1.0 / float(nbt)
-                    unbiased = var64 * (cnt / (cnt - 1.0).clamp_(min=1.0))
-                    running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
-                    running_var.mul_(1.0 - mom).add_(unbiased.float(), alpha=mom)
+            mean, invstd, cnt = bn_finalize(sums, c, count, eps, sync, running_mean, running_var,
+                                            nbt, momentum)
             ctx.count = cnt
         else:
             mean = running_mean

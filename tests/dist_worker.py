@@ -1,0 +1,127 @@
+"""Worker of tests/test_distributed.py: one rank of a world_size-2 job (gloo rendezvous on 127.0.0.1)."""
+
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "audiodeepfake-detection_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def cpu_sync(rank, world):
+    """Host-side data-parallel logic on CPU tensors: replica broadcast, flat-arena gradient
+    all-reduce == full-batch gradient, packed BatchNorm statistics == global-batch statistics,
+    sampler shards are disjoint."""
+    from audiofakedetect import ops
+    from audiofakedetect.train_classifier import DataParallelRCCL, sync_gradients
+    from audiofakedetect.data_loader import SyntheticFrames
+    from torch.utils.data.distributed import DistributedSampler
+
+    torch.manual_seed(100 + rank)  # replicas start different ...
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    wrapped = DataParallelRCCL(net)  # ... and are made equal by the broadcast
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    gather = [torch.zeros(47) for _ in range(world)]
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    dist.all_gather(gather, flat)
+    assert all(torch.equal(g, gather[0]) for g in gather), "replicas differ after broadcast"
+    ref.load_state_dict(net.state_dict())
+
+    opt = ops.FusedAdam(net.parameters(), lr=1e-3)  # arena logic is device agnostic
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(8, 6, generator=g)
+    y = torch.randint(0, 2, (8,), generator=g)
+    xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+    opt.zero_grad()
+    torch.nn.functional.cross_entropy(wrapped(xs), ys).backward()
+    scale = sync_gradients(wrapped, opt)
+    assert abs(scale - 1.0 / world) < 1e-12
+    torch.nn.functional.cross_entropy(ref(x), y).backward()
+    full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    assert torch.allclose(opt.flat_grad * scale, full, atol=1e-6), "all-reduced grads != full-batch grads"
+
+    # packed BN statistics: [sum | sumsq | count] all-reduce -> global mean / biased var
+    c = 3
+    data = torch.randn(8, c, 5, generator=torch.Generator().manual_seed(9)).double()
+    local = data[rank * 4:(rank + 1) * 4]
+    sums = torch.zeros(2 * c + 1, dtype=torch.float64)
+    sums[:c] = local.sum((0, 2))
+    sums[c:2 * c] = (local * local).sum((0, 2))
+    rm, rv = torch.zeros(c), torch.ones(c)
+    mean, invstd, cnt = ops.bn_finalize(sums, c, float(local.numel() // c), 1e-5, True, rm, rv,
+                                        torch.zeros((), dtype=torch.long), 0.1)
+    assert float(cnt) == data.numel() // c
+    assert torch.allclose(mean.double(), data.mean((0, 2)), atol=1e-6)
+    var = data.var((0, 2), unbiased=False)
+    assert torch.allclose(invstd.double(), torch.rsqrt(var + 1e-5), atol=1e-5)
+    assert torch.allclose(rv.double(), 0.9 + 0.1 * data.var((0, 2), unbiased=True), atol=1e-6)
+
+    # sampler: disjoint shards that cover the set (reference train_classifier.py:119-127)
+    ds = SyntheticFrames(16, 64)
+    sampler = DistributedSampler(ds, shuffle=True, seed=0, drop_last=True)
+    sampler.set_epoch(1)
+    mine = torch.tensor(list(iter(sampler)))
+    allidx = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allidx, mine)
+    assert sorted(torch.cat(allidx).tolist()) == list(range(16))
+
+
+def gpu_dcnn(rank, world):
+    """Both ranks on cuda:0 (gloo moves the GPU tensors): sharded DCNN step with cross-rank
+    BatchNorm statistics and the flat gradient all-reduce == single-process full-batch step."""
+    from audiofakedetect import ops
+    from audiofakedetect.models import DCNN
+    from audiofakedetect.train_classifier import DataParallelRCCL, sync_gradients
+    from audiofakedetect.utils import DotDict
+
+    torch.cuda.set_device(0)
+
+    def make(ddp):
+        torch.manual_seed(3)
+        a = DotDict(input_dim=[4, 1, 256, 95], ochannels1=64, ochannels2=64, ochannels3=96,
+                    ochannels4=128, ochannels5=32, kernel1=3, dropout_cnn=0.0, dropout_lstm=0.0,
+                    time_dim_add=1, flattend_size=320, ddp=ddp)
+        return DCNN(a).cuda().train()
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 1, 256, 95, generator=g).cuda()
+    y = torch.randint(0, 2, (8,), generator=g).cuda()
+    net = make(True)
+    wrapped = DataParallelRCCL(net)
+    opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=1e-3)
+    opt.zero_grad()
+    out = wrapped(x[rank * 4:(rank + 1) * 4])
+    ops.CrossEntropyLoss()(out, y[rank * 4:(rank + 1) * 4]).backward()
+    scale = sync_gradients(wrapped, opt)
+    grads = (opt.flat_grad * scale).clone()
+    bn_rm = net.cnn[3].running_mean.clone()
+
+    ref = make(False)  # no cross-rank statistics: plain full-batch step in this process
+    ropt = ops.FusedAdam(ref.parameters(), lr=4e-4, weight_decay=1e-3)
+    ropt.zero_grad()
+    rout = ref(x)
+    ops.CrossEntropyLoss()(rout, y).backward()
+    err = (out - rout[rank * 4:(rank + 1) * 4]).abs().max().item()
+    assert err <= 1e-4, f"sharded logits differ from full-batch logits: {err}"
+    rel = ((grads - ropt.flat_grad).norm() / ropt.flat_grad.norm()).item()
+    assert rel <= 3e-3, f"all-reduced gradients differ from full-batch gradients: {rel}"
+    assert torch.allclose(bn_rm, ref.cnn[3].running_mean, atol=1e-5)
+    opt.step(grad_scale=scale)
+    ropt.step()
+    d = (opt.flat - ropt.flat).abs()
+    assert int((d > 2e-5).sum()) <= d.numel() // 100, "Adam update differs"
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        {"cpu_sync": cpu_sync, "gpu_dcnn": gpu_dcnn}[mode](rank, world)
+    finally:
+        dist.destroy_process_group()
+    print(f"rank {rank} ok")

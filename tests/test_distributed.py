@@ -1,0 +1,52 @@
+"""Data-parallel path on world_size 2 (gloo, 127.0.0.1): host logic on CPU, full DCNN step on GPU.
+
+The reference tests its DDP aggregation only with hand-built "gathered" literals
+(tests/test_trainer.py:14-117); here two real processes run the collectives.
+"""
+
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_world2(mode, timeout=300):
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                   WORLD_SIZE="2", LOCAL_RANK="0", OMP_NUM_THREADS="2",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+        assert f"rank {rank} ok" in out
+
+
+def test_world2_gloo_cpu_gradient_allreduce_bn_stats_sampler():
+    _run_world2("cpu_sync")
+
+
+@pytest.mark.gpu
+def test_world2_sharded_dcnn_step_equals_full_batch_step():
+    _run_world2("gpu_dcnn")
