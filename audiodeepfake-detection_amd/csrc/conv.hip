@@ -235,7 +235,7 @@ conv_igemm_kernel(const ConvGeom g, const float* __restrict__ x, const float* __
     }
 
     const int KK = g.K * g.K;
-    for (int kl = tid; kl < g.CKP; kl += nthreads) {
+    for (int kl = tid; kl < g.CKP + 6; kl += nthreads) {
         int o = 0;
         if (kl < g.CI_T * KK) {
             const int ci_l = kl / KK;
@@ -452,8 +452,8 @@ int plan_igemm(ConvGeom& g, int N, int Cin, int H, int W, int Cout, int K, int p
         set_tiling(g, pix, rect);
         // largest channel chunk whose weights + patch fit the LDS budget
         for (int ct = 1; ct <= Cin && ct <= 32; ++ct) {
-            const int ckp = (ct * KK + 1) & ~1;
-            const long bytes = 4L * ((long)ckp * g.CO_PAD + (long)ct * g.PR * g.PC + 4 + ckp);
+            const int ckp = (ct * KK + 3) & ~3;
+            const long bytes = 4L * ((long)ckp * g.CO_PAD + (long)ct * g.PR * g.PC + 12 + ckp + 6L * g.CO_PAD);
             const bool regs_ok = ((long)ckp * g.CO_PAD / 4 <= (long)kWV * nthreads) &&
                                  ((long)ct * g.PR * g.PC <= (long)kPV * nthreads);
             if (bytes <= kLdsBudget) {
@@ -474,13 +474,13 @@ int plan_igemm(ConvGeom& g, int N, int Cin, int H, int W, int Cout, int K, int p
         if (Cin % c == 0) { ct = c; break; }
     g.CI_T = ct;
     g.nchunks = (Cin + ct - 1) / ct;
-    g.CKP = (ct * KK + 1) & ~1;
+    g.CKP = (ct * KK + 3) & ~3;
     g.patchFloats = ((ct * g.PR * g.PC + 3) / 4) * 4;
     return AFD_OK;
 }
 
 size_t igemm_lds_bytes(const ConvGeom& g) {
-    return 4 * ((size_t)g.CKP * g.CO_PAD + g.patchFloats + g.CKP);
+    return 4 * ((size_t)g.CKP * g.CO_PAD + g.patchFloats + g.CKP + 8 + 6 * (size_t)g.CO_PAD);
 }
 
 size_t repack_floats(const ConvGeom& g) { return (size_t)g.nchunks * g.CKP * g.CO_PAD; }
@@ -588,108 +588,76 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
         int oy0, ox0, p0;
         tile_origin(g, t, oy0, ox0, p0);
         __syncthreads();
-        if (wg.fast_stage) {
-            // one global-latency round per tile: every dz and patch load of this thread is in
-            // flight before the first LDS store.  dz element e -> (channel e / 64, pixel e % 64)
-            int oy, ox;
-            tile_pixel(g, lane, oy0, ox0, p0, oy, ox);
-            const bool pok = (oy < g.Hout) && (ox < g.Wout);
-            const unsigned oplane = (unsigned)(g.Hout * g.Wout);
-            const float* dzn = dz + (size_t)n * g.Cout * oplane;
-            const unsigned pixo = pok ? (unsigned)(oy * g.Wout + ox) : 0u;
-            if (wave == 0) pixoff[lane] = pok ? (oy - oy0) * g.PC + (ox - ox0) : 0;
-            float vz[kZV];
+        {
+        int oy, ox;
+        tile_pixel(g, lane, oy0, ox0, p0, oy, ox);
+        const bool pok = (oy < g.Hout) && (ox < g.Wout);
+        const size_t oplane = (size_t)g.Hout * g.Wout;
+        const float* dzn = dz + (size_t)n * g.Cout * oplane + (pok ? (size_t)oy * g.Wout + ox : 0);
+        if (wave == 0) pixoff[lane] = pok ? (oy - oy0) * g.PC + (ox - ox0) : 0;
+        // rows wave, wave + nwaves, ...: up to 16 loads in flight per wave, then the stores
+        for (int j0 = 0; wave + j0 * nwaves < g.CO_PAD; j0 += 16) {
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < kZV; ++u) {
-                const int co = wave + u * nwaves;
-                vz[u] = (pok && co < g.Cout) ? dzn[(unsigned)co * oplane + pixo] : 0.f;
-            }
-            const int total = g.CI_T * g.PR * g.PC;
-            const unsigned plane = (unsigned)(g.H * g.W);
-            const float* xn = x + (size_t)n * g.Cin * plane;
-            const int iy0 = oy0 - g.pad, ix0 = ox0 - g.pad;
-            float vp[kPW];
-#pragma unroll
-            for (int u = 0; u < kPW; ++u) {
-                const int e = tid + u * nthreads;
-                int row, pc, ci_l, pr;
-                divmod_small(e, g.PC, invPC, row, pc);
-                divmod_small(row, g.PR, invPR, ci_l, pr);
-                const int ci = chunk * g.CI_T + ci_l;
-                const int iy = iy0 + pr;
-                const int ix = ix0 + pc;
-                const bool ok = (e < total) && (ci < g.Cin) && (iy >= 0) && (iy < g.H) && (ix >= 0) && (ix < g.W);
-                vp[u] = ok ? xn[(unsigned)ci * plane + (unsigned)(iy * g.W + ix)] : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const int co = wave + (j0 + r) * nwaves;
+                v[r] = (pok && co < g.Cout) ? dzn[(size_t)co * oplane] : 0.f;
             }
 #pragma unroll
-            for (int u = 0; u < kZV; ++u) {
-                const int co = wave + u * nwaves;
-                if (co < g.CO_PAD) dzl[co * wg.PIXP + lane] = vz[u];
+            for (int r = 0; r < 16; ++r) {
+                const int co = wave + (j0 + r) * nwaves;
+                if (co < g.CO_PAD) dzl[co * wg.PIXP + lane] = v[r];
             }
-#pragma unroll
-            for (int u = 0; u < kPW; ++u) {
-                const int e = tid + u * nthreads;
-                if (e < total) patch[e] = vp[u];
-            }
-            if (chunk == 0) {  // bias gradient: row sums of the staged dz tile
-#pragma unroll
-                for (int u = 0; u < kZV; ++u) {
-                    const int co = wave + u * nwaves;
-                    const float sm = wave_sum64(vz[u]);
-                    if (lane == 0 && co < g.CO_PAD) bsum_lds[co] += sm;  // one wave owns a row
-                }
-            }
-        } else {
-            int oy, ox;
-            tile_pixel(g, lane, oy0, ox0, p0, oy, ox);
-            const bool pok = (oy < g.Hout) && (ox < g.Wout);
-            const size_t oplane = (size_t)g.Hout * g.Wout;
-            const float* dzn = dz + (size_t)n * g.Cout * oplane + (pok ? (size_t)oy * g.Wout + ox : 0);
-            if (wave == 0) pixoff[lane] = pok ? (oy - oy0) * g.PC + (ox - ox0) : 0;
-            for (int co0 = wave * 8; co0 < g.CO_PAD; co0 += nwaves * 8) {
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int co = co0 + r;
-                    v[r] = (pok && co < g.Cout) ? dzn[(size_t)co * oplane] : 0.f;
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r)
-                    if (co0 + r < g.CO_PAD) dzl[(co0 + r) * wg.PIXP + lane] = v[r];
-            }
-            stage_patch<6>(g, x, n, chunk, oy0 - g.pad, ox0 - g.pad, patch, nthreads);
-            __syncthreads();
-            if (chunk == 0 && tid < g.CO_PAD) {
-                const float* row = dzl + tid * wg.PIXP;
-                float sm = 0.f;
-                for (int pj = 0; pj < g.PIX; ++pj) sm += row[pj];
-                bsum_lds[tid] += sm;
-            }
+        }
+        stage_patch<8>(g, x, n, chunk, oy0 - g.pad, ox0 - g.pad, patch, nthreads);
+        __syncthreads();
+        if (chunk == 0 && tid < g.CO_PAD) {
+            const float* row = dzl + tid * wg.PIXP;
+            float sm = 0.f;
+            for (int pj = 0; pj < g.PIX; ++pj) sm += row[pj];
+            bsum_lds[tid] += sm;
+        }
         }
         __syncthreads();
         const float* arow = dzl + (m * 32 + l31) * wg.PIXP;
         const int ksteps = g.PIX >> 1;
-        // two-level accumulation (per 64-pixel tile, then across tiles): see forward kernel
-        f32x16 part[NTW];
+        if (NTW <= 3) {
+            // two-level accumulation (per 64-pixel tile, then across tiles): see forward kernel
+            f32x16 part[NTW];
 #pragma unroll
-        for (int i = 0; i < NTW; ++i)
+            for (int i = 0; i < NTW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[i][r] = 0.f;
+                for (int r = 0; r < 16; ++r) part[i][r] = 0.f;
 #pragma unroll 2
-        for (int ks = 0; ks < ksteps; ++ks) {
-            const int k = 2 * ks + half;
-            const float a = arow[k];
-            const int po = pixoff[k];
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int k = 2 * ks + half;
+                const float a = arow[k];
+                const int po = pixoff[k];
 #pragma unroll
-            for (int i = 0; i < NTW; ++i) {
-                // no branch here: a column tile past NTILES reads offset 0 and feeds an
-                // accumulator that is never stored (a branch per MFMA blocks the scheduler)
-                const float b = patch[joff[i] + po];
-                part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
+                for (int i = 0; i < NTW; ++i) {
+                    // no branch here: a column tile past NTILES reads offset 0 and feeds an
+                    // accumulator that is never stored (a branch per MFMA blocks the scheduler)
+                    const float b = patch[joff[i] + po];
+                    part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) acc[i] += part[i];
+        } else {
+            // 5+ column tiles per wave: a second accumulator set would not fit the register
+            // file at two waves per SIMD; single chain over this workgroup's tiles
+#pragma unroll 2
+            for (int ks = 0; ks < ksteps; ++ks) {
+                const int k = 2 * ks + half;
+                const float a = arow[k];
+                const int po = pixoff[k];
+#pragma unroll
+                for (int i = 0; i < NTW; ++i) {
+                    const float b = patch[joff[i] + po];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+                }
             }
         }
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) acc[i] += part[i];
     }
 
     float* slab = part + ((size_t)split * gridDim.y + chunk) * g.CO_PAD * wg.NCOL;
@@ -750,6 +718,12 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
         const bool rect = (Wout >= 4 * pix) != (attempt == 1);
         if (rect && Wout < pix) continue;
         set_tiling(g, pix, rect);
+        // LDS pitch of the patch: the 32 lanes of a B read are 32 different (ci,ky,kx)
+        // columns at offsets ci*PR*PC + ky*PC + kx; PC = 3 (mod 32) for 3x3 (and an odd
+        // channel stride for 1x1) spreads them over 32 banks.  The extra columns are staged
+        // like any other input column and never read.
+        if (K == 3 && dil == 1) g.PC += (3 - g.PC % 32 + 32) % 32;
+        if (K == 1 && ((g.PR * g.PC) & 1) == 0) g.PC += 1;
         for (int ct = 1; ct <= Cin && ct <= 32; ++ct) {
             const long bytes = fixed + 4L * ct * g.PR * g.PC;
             if (bytes <= 72 * 1024 && (ct * KK + 31) / 32 <= 9 * ngmax) best = ct;
