@@ -540,7 +540,7 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
     float* dzl = smem;                                  // [CO_PAD][PIXP]
     float* patch = dzl + g.CO_PAD * wg.PIXP;            // [CI_T][PR][PC]
     int* pixoff = reinterpret_cast<int*>(patch + g.patchFloats);  // [PIX]
-    float* bsum_lds = reinterpret_cast<float*>(pixoff + g.PIX);    // [CO_PAD]
+    float* bsum_lds = reinterpret_cast<float*>(pixoff + g.PIX + 8);  // [CO_PAD]; pixoff padded
 
     const int tid = threadIdx.x;
     const int nthreads = blockDim.x;
@@ -550,6 +550,7 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
     const float invPC = 1.0f / (float)g.PC;
     const float invPR = 1.0f / (float)g.PR;
     for (int i = tid; i < g.CO_PAD; i += nthreads) bsum_lds[i] = 0.f;
+    if (tid < 8) pixoff[g.PIX + tid] = 0;
     const int m = wave % wg.MT;
     const int grp = wave / wg.MT;
     const int half = lane >> 5;
@@ -620,43 +621,59 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
         }
         __syncthreads();
         const float* arow = dzl + (m * 32 + l31) * wg.PIXP;
-        const int ksteps = g.PIX >> 1;
-        if (NTW <= 3) {
-            // two-level accumulation (per 64-pixel tile, then across tiles): see forward kernel
-            f32x16 part[NTW];
+        const int ksteps = g.PIX >> 1;  // 32
+        // two-level accumulation (per 64-pixel tile, then across tiles) while the second
+        // accumulator set fits (NTW <= 3); see the forward kernel
+        constexpr bool kTwo = NTW <= 3;
+        f32x16 part[kTwo ? NTW : 1];
+        if (kTwo) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) part[i][r] = 0.f;
-#pragma unroll 2
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const int k = 2 * ks + half;
-                const float a = arow[k];
-                const int po = pixoff[k];
+        }
+        // Two-deep software pipeline with ping-pong fragment registers: fragments of pixel
+        // step s+1 and the patch offset of step s+2 are requested before the MFMAs of step s
+        // (hipcc otherwise emits read -> wait -> MFMA chains; with 1.5-3 waves per SIMD the
+        // other waves do not cover that).  pixoff is padded, dz rows have slack: the tail
+        // prefetches in-bounds garbage, no branches.
+        float a0, a1, b0[NTW], b1[NTW];
+        {
+            const int po0 = pixoff[half];
+            a0 = arow[half];
 #pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    // no branch here: a column tile past NTILES reads offset 0 and feeds an
-                    // accumulator that is never stored (a branch per MFMA blocks the scheduler)
-                    const float b = patch[joff[i] + po];
-                    part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, part[i], 0, 0, 0);
-                }
+            for (int i = 0; i < NTW; ++i) b0[i] = patch[joff[i] + po0];
+        }
+        int pon = pixoff[2 + half];
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            const int k1 = 2 * ks + 2 + half;
+            a1 = arow[k1];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) b1[i] = patch[joff[i] + pon];
+            const int ponn = pixoff[k1 + 2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                if (kTwo) part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[i], part[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[i], acc[i], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            const int k2 = k1 + 2;
+            a0 = arow[k2];
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) b0[i] = patch[joff[i] + ponn];
+            pon = pixoff[k2 + 2];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NTW; ++i) {
+                if (kTwo) part[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[i], part[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[i], acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kTwo) {
 #pragma unroll
             for (int i = 0; i < NTW; ++i) acc[i] += part[i];
-        } else {
-            // 5+ column tiles per wave: a second accumulator set would not fit the register
-            // file at two waves per SIMD; single chain over this workgroup's tiles
-#pragma unroll 2
-            for (int ks = 0; ks < ksteps; ++ks) {
-                const int k = 2 * ks + half;
-                const float a = arow[k];
-                const int po = pixoff[k];
-#pragma unroll
-                for (int i = 0; i < NTW; ++i) {
-                    const float b = patch[joff[i] + po];
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
-                }
-            }
         }
     }
 
@@ -712,7 +729,7 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
     wg.PIXP = pix + 1;
     wg.MT = g.CO_PAD / 32;
     const int ngmax = 8 / wg.MT > 1 ? 8 / wg.MT : 1;
-    const long fixed = 4L * ((long)g.CO_PAD * wg.PIXP + pix + 8 + g.CO_PAD);
+    const long fixed = 4L * ((long)g.CO_PAD * wg.PIXP + pix + 16 + g.CO_PAD);
     int best = 0;
     for (int attempt = 0; attempt < 2 && best == 0; ++attempt) {
         const bool rect = (Wout >= 4 * pix) != (attempt == 1);
@@ -757,7 +774,7 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
 }
 
 size_t wgrad_lds_bytes(const WgradGeom& wg) {
-    return 4 * ((size_t)wg.c.CO_PAD * wg.PIXP + wg.c.patchFloats + wg.c.PIX + wg.c.CO_PAD);
+    return 4 * ((size_t)wg.c.CO_PAD * wg.PIXP + wg.c.patchFloats + wg.c.PIX + 8 + wg.c.CO_PAD);
 }
 
 size_t wgrad_ws_floats(const WgradGeom& wg) {
