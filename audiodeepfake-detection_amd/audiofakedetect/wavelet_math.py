@@ -26,6 +26,18 @@ _WPT_LOG, _WPT_SIGN, _WPT_NORM = 1, 2, 4
 _STFT_LOG, _STFT_NORM = 1, 4
 
 
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only device scratch for the level-8 node hand-off of deep transforms."""
+    buf = _ws_cache.get(device.index)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _ws_cache[device.index] = buf
+    return buf
+
+
 def _as_frames(x: torch.Tensor) -> torch.Tensor:
     """[B,1,N] / [B,N] / [1,N] / [N] -> contiguous f32 [B,N] on the GPU."""
     _native.require_gpu()
@@ -70,11 +82,13 @@ def wpt_forward(
     if mean is not None:
         flags |= _WPT_NORM
     out = torch.empty((b, nch, t_len, 1 << max_lev), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.afd_wpt_workspace_bytes(b, n, length, max_lev)
+    ws = _workspace(ws_bytes, x.device) if ws_bytes else None
     rc = lib.afd_wpt_forward(
         _native.ptr(x), b, n, _native.float_array(wavelet.dec_lo),
         _native.float_array(wavelet.dec_hi), length, max_lev, flags, float(power), 1e-12,
         float(mean or 0.0), float(std if std is not None else 1.0), _native.ptr(out),
-        None, 0, _native.stream_ptr(),
+        _native.ptr(ws), ws_bytes, _native.stream_ptr(),
     )
     _native.check(rc, "afd_wpt_forward")
     return out

@@ -19,6 +19,8 @@
 #include "afd_common.h"
 #include "../../include/afd_hip.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kMaxLevel = 16;
@@ -155,7 +157,20 @@ __global__ void __launch_bounds__(kThreads) wpt_fused_kernel(const WptParams p) 
     const int j1 = blockIdx.x / p.B;
 
     const float* xg = p.x + (size_t)b * p.N;
-    for (int i = tid; i < p.N; i += kThreads) lds[i] = xg[i];
+    // 8 loads in flight per thread (a load -> store chain pays one memory latency per element)
+    for (int base = 0; base < p.N; base += kThreads * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kThreads + tid;
+            v[u] = i < p.N ? xg[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * kThreads + tid;
+            if (i < p.N) lds[i] = v[u];
+        }
+    }
     __syncthreads();
 
     float* cur = lds;
@@ -311,12 +326,22 @@ extern "C" int afd_wpt_out_len(int N, int L, int level) {
     return n;
 }
 
-extern "C" size_t afd_wpt_workspace_bytes(int, int, int, int) { return 0; }
+namespace afd {
+size_t wpt2_workspace_bytes(int B, int N, int L, int level);
+int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
+                 int level, unsigned flags, float power, float eps, float mean, float std, float* out,
+                 void* ws, size_t ws_bytes, hipStream_t stream);
+}  // namespace afd
+
+extern "C" size_t afd_wpt_workspace_bytes(int B, int N, int L, int level) {
+    if (B < 1 || N < 2 || L < 2 || (L & 1) || L > kMaxTaps || level < 1 || level > kMaxLevel) return 0;
+    return afd::wpt2_workspace_bytes(B, N, L, level);
+}
 
 extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo,
                                const float* dec_hi, int L, int level, unsigned flags, float power,
-                               float eps, float mean, float std, float* out, void*, size_t,
-                               afd_stream_t stream) {
+                               float eps, float mean, float std, float* out, void* ws,
+                               size_t ws_bytes, afd_stream_t stream) {
     if (!x || !out || !dec_lo || !dec_hi) return afd::fail(AFD_ERR_ARG, "wpt: null pointer");
     if (B < 1 || N < 2) return afd::fail(AFD_ERR_ARG, "wpt: bad shape B=%d N=%d", B, N);
     if (L < 2 || L > kMaxTaps || (L & 1))
@@ -327,6 +352,16 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
     if ((flags & AFD_WPT_NORM) && std == 0.f) return afd::fail(AFD_ERR_ARG, "wpt: std == 0");
     if ((long)B << (level >= 3 ? 2 : level - 1) > 0x7fffffffL)
         return afd::fail(AFD_ERR_ARG, "wpt: batch too large");
+    // Deep transforms (level >= 11) run on the second-generation kernels (wpt2.hip: register
+    // window + packed FMAs, dense compile-time deep levels): measured 389 vs 627 us on coif4
+    // level 14, B = 128; up to level 10 the single-launch kernel below is faster (94 vs 117 us
+    // at level 8).  AFD_WPT_V1 / AFD_WPT_V2 force one or the other (development).
+    if ((level >= 11 || getenv("AFD_WPT_V2")) && !getenv("AFD_WPT_V1")) {
+        // 1 = geometry left to the kernel below
+        const int rc2 = afd::wpt2_forward(x, B, N, dec_lo, dec_hi, L, level, flags, power, eps, mean,
+                                          std, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+        if (rc2 != 1) return rc2;
+    }
     WptParams p{};
     p.x = x;
     p.out = out;
