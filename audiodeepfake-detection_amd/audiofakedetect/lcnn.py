@@ -1,0 +1,172 @@
+"""LCNN (ASVspoof-2021 LA baseline head) on libafd_hip -- reference models.py:68-131.
+
+Layer objects hold parameters / buffers under the reference's state_dict keys (``lcnn.N.*``,
+``lstm.K.l_blstm.*``, ``fc.*``); ``forward`` drives HIP kernels: conv (MFMA implicit GEMM),
+max-feature-map, max-pool, BatchNorm, dropout+permute, and the two bidirectional LSTM layers as
+input/recurrent projections on ``afd_gemm_nt`` plus the fused cell kernel.  The convolutional
+trunk supports backward; the LSTM backward pass is not built yet (config 5 of BASELINE.json is
+an evaluation workload) and raises if a gradient is requested through it.
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _native, ops
+
+
+class MaxFeatureMap2D(nn.Module):
+    """Max over the two channel halves (reference models.py:161-209)."""
+
+    def __init__(self, max_dim: int = 1) -> None:
+        super().__init__()
+        self.max_dim = max_dim
+
+    def forward(self, inputs: torch.Tensor) -> torch.Tensor:
+        return max_feature_map(inputs)
+
+
+class _MFM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = ops._f32c(x)
+        n, c = x.shape[0], x.shape[1]
+        if c % 2:
+            raise ValueError("MaxFeatureMap: odd number of channels")
+        hw = x.numel() // (n * c)
+        y = torch.empty((n, c // 2) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        sel = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
+        _native.check(_native.load().afd_mfm_forward(_native.ptr(x), _native.ptr(y), _native.ptr(sel),
+                                                     n, c, hw, _native.stream_ptr()), "afd_mfm_forward")
+        ctx.save_for_backward(sel)
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (sel,) = ctx.saved_tensors
+        n, c = ctx.shape[0], ctx.shape[1]
+        hw = sel.numel() // (n * (c // 2))
+        dx = torch.empty(ctx.shape, dtype=torch.float32, device=dy.device)
+        _native.check(_native.load().afd_mfm_backward(_native.ptr(ops._f32c(dy)), _native.ptr(sel),
+                                                      _native.ptr(dx), n, c, hw, _native.stream_ptr()),
+                      "afd_mfm_backward")
+        return dx
+
+
+def max_feature_map(x: torch.Tensor) -> torch.Tensor:
+    return _MFM.apply(x)
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate: bool = False):
+    """out[M,N] (+)= a[M,K] @ b[N,K].T + bias; `a`/`out` may be row-strided views."""
+    m, k = a.shape
+    n = b.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
+    _native.check(_native.load().afd_gemm_nt(
+        _native.ptr(a), _native.ptr(b), _native.ptr(bias), _native.ptr(out), m, n, k, a.stride(0),
+        b.stride(0), out.stride(0), 1 if accumulate else 0, _native.stream_ptr()), "afd_gemm_nt")
+    return out
+
+
+class _BLSTM(torch.autograd.Function):
+    """Bidirectional single-layer LSTM forward, x [B,T,D] -> [B,T,2H] (nn.LSTM semantics)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        lib = _native.load()
+        bsz, steps, d = x.shape
+        h = w_hh.shape[1]
+        xt = x.permute(1, 0, 2).contiguous().view(steps * bsz, d)  # [T*B, D]
+        out = torch.empty((steps, bsz, 2 * h), dtype=torch.float32, device=x.device)
+        for direction, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh),
+                                                      (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
+            pre = gemm_nt(xt, ops._f32c(wi), bi + bh).view(steps, bsz, 4 * h)
+            hs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+            cs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+            whc = ops._f32c(wh)
+            order = range(steps) if direction == 0 else range(steps - 1, -1, -1)
+            for t in order:
+                gates = pre[t]
+                gemm_nt(hs, whc, None, out=gates, accumulate=True)
+                hout = out[t, :, direction * h:(direction + 1) * h]
+                _native.check(lib.afd_lstm_cell(_native.ptr(gates), _native.ptr(cs), _native.ptr(hout),
+                                                _native.ptr(hs), bsz, h, 2 * h, _native.stream_ptr()),
+                              "afd_lstm_cell")
+        return out.permute(1, 0, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError(
+            "LCNN: the LSTM backward pass is not built yet (BASELINE config 5 is an evaluation "
+            "workload); run LCNN under torch.no_grad() / eval")
+
+
+class BLSTMLayer(nn.Module):
+    """Bi-directional LSTM wrapper (reference models.py:212-237)."""
+
+    def __init__(self, input_dim: int, output_dim: int) -> None:
+        super().__init__()
+        if output_dim % 2 != 0:
+            raise ValueError("BLSTMLayer expects an even layer size")
+        self.l_blstm = nn.LSTM(input_dim, output_dim // 2, bidirectional=True)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        m = self.l_blstm
+        return _BLSTM.apply(ops._f32c(x), m.weight_ih_l0, m.weight_hh_l0, m.bias_ih_l0, m.bias_hh_l0,
+                            m.weight_ih_l0_reverse, m.weight_hh_l0_reverse, m.bias_ih_l0_reverse,
+                            m.bias_hh_l0_reverse)
+
+
+class LCNN(nn.Module):
+    """Light CNN + 2 x BLSTM + Linear (reference models.py:68-131)."""
+
+    def __init__(self, classes: int = 2, in_channels: int = 1, lstm_channels: int = 256) -> None:
+        super().__init__()
+        # (cin, cout, k, pad, pooled, bn channels or 0)
+        spec = ((in_channels, 64, 5, 2, True, 0), (32, 64, 1, 0, False, 32), (32, 96, 3, 1, True, 48),
+                (48, 96, 1, 0, False, 48), (48, 128, 3, 1, True, 0), (64, 128, 1, 0, False, 64),
+                (64, 64, 3, 1, False, 32), (32, 64, 1, 0, False, 32), (32, 64, 3, 1, True, 0))
+        layers = []
+        self._plan = []  # (conv idx, pooled, bn idx or None)
+        for cin, cout, k, pad, pooled, bn in spec:
+            conv_i = len(layers)
+            layers += [nn.Conv2d(cin, cout, k, 1, padding=pad), MaxFeatureMap2D()]
+            if pooled:
+                layers.append(nn.MaxPool2d(2, 2))
+            bn_i = None
+            if bn:
+                bn_i = len(layers)
+                layers.append(nn.BatchNorm2d(bn, affine=False))
+            self._plan.append((conv_i, pooled, bn_i))
+        layers.append(nn.Dropout(0.7))
+        self.lcnn = nn.Sequential(*layers)
+        hid = (lstm_channels // 16) * 32
+        self.lstm = nn.Sequential(BLSTMLayer(hid, hid), BLSTMLayer(hid, hid))
+        self.fc = nn.Linear(hid, classes)
+        self.sync_bn = True
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = x.permute(0, 1, 3, 2)
+        if not h.is_contiguous():
+            h = ops.transpose_contiguous(x.contiguous())
+        net = self.lcnn
+        for conv_i, pooled, bn_i in self._plan:
+            conv = net[conv_i]
+            h = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
+            h = max_feature_map(h)
+            if pooled:
+                h = ops.prelu_maxpool2x2(h, None)
+            if bn_i is not None:
+                h = ops.batch_norm(h, net[bn_i], None, self.sync_bn)
+        h = ops.dropout_permute(h, net[-1].p, self.training)  # [B, T', C, W']
+        h = h.reshape(h.shape[0], h.shape[1], -1)
+        for layer in self.lstm:
+            h = layer(h)
+        return ops.linear_mean(h, self.fc.weight, self.fc.bias)
+
+    def get_name(self) -> str:
+        return "LCNN"

@@ -173,6 +173,22 @@ int afd_linear_mean_backward(const float* x, const float* w, const float* dy, fl
                              float* dw, float* db, int B, int TD, int F, int O,
                              afd_stream_t stream);
 
+/* LCNN layers (reference models.py:68-131, 161-237).
+ * afd_mfm_*    : MaxFeatureMap2D, y[n][c] = max(x[n][c], x[n][c + C/2]) over x [N][C][HW];
+ *                sel (may be NULL in forward) records which half won, for the backward.
+ * afd_gemm_nt  : C[M][N] = A[M][K] . B[N][K]^T + bias[N] (+ C when accumulate != 0), row-major
+ *                with leading dimensions, exact-f32 MFMA: the input and recurrent projections
+ *                of nn.LSTM (and any nn.Linear).
+ * afd_lstm_cell: gates [B][4H] in torch order (i|f|g|o) -> c (in place), h (hstate [B][H] and
+ *                a strided copy hout, the layer output slice). */
+int afd_mfm_forward(const float* x, float* y, uint8_t* sel, int N, int C, int HW, afd_stream_t stream);
+int afd_mfm_backward(const float* dy, const uint8_t* sel, float* dx, int N, int C, int HW,
+                     afd_stream_t stream);
+int afd_gemm_nt(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                int lda, int ldb, int ldc, int accumulate, afd_stream_t stream);
+int afd_lstm_cell(const float* gates, float* c, float* hout, float* hstate, int B, int H, int ldh,
+                  afd_stream_t stream);
+
 /* CrossEntropyLoss (mean) + its gradient + number of correct argmax predictions
  * (train_classifier.py:970-979); dlogits / correct may be NULL */
 int afd_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
