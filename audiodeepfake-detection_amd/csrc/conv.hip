@@ -692,28 +692,66 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
     if (chunk == 0 && tid < g.CO_PAD) partb[(size_t)split * g.CO_PAD + tid] = bsum_lds[tid];
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ partb,
-                                    float* __restrict__ dw, float* __restrict__ db, int Cin,
-                                    int Cout, int KK, int CI_T, int nchunks, int CO_PAD, int NCOL,
-                                    int S) {
+// Sums the S partial slabs.  Block = 32 gradient elements x 8 slab groups: lane group g sums
+// slabs g, g+8, ... with four independent chains (loads in flight), LDS combines the groups --
+// a one-thread-per-element loop over S strided loads is a pure latency chain.
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ partb,
+                    float* __restrict__ dw, float* __restrict__ db, int Cin, int Cout, int KK,
+                    int CI_T, int nchunks, int CO_PAD, int NCOL, int S) {
+    __shared__ float red[8][33];
     const int total = Cout * Cin * KK;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        const int r = i % KK;
-        const int ci = (i / KK) % Cin;
-        const int co = i / (KK * Cin);
-        const int chunk = ci / CI_T;
-        const int col = (ci - chunk * CI_T) * KK + r;
-        const size_t stride = (size_t)nchunks * CO_PAD * NCOL;
-        const float* p = part + ((size_t)chunk * CO_PAD + co) * NCOL + col;
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += p[(size_t)k * stride];
-        dw[i] = s;
+    const int e = threadIdx.x & 31;
+    const int g = threadIdx.x >> 5;
+    const int nblk_w = (total + 31) / 32;
+    const size_t stride = (size_t)nchunks * CO_PAD * NCOL;
+    float sum = 0.f;
+    bool valid = false;
+    const float* p = nullptr;
+    size_t step = 0;
+    int out_i = -1;
+    if ((int)blockIdx.x < nblk_w) {
+        const int i = blockIdx.x * 32 + e;
+        if (i < total) {
+            const int r = i % KK;
+            const int ci = (i / KK) % Cin;
+            const int co = i / (KK * Cin);
+            const int chunk = ci / CI_T;
+            const int col = (ci - chunk * CI_T) * KK + r;
+            p = part + ((size_t)chunk * CO_PAD + co) * NCOL + col;
+            step = stride;
+            valid = true;
+            out_i = i;
+        }
+    } else if (db) {  // trailing blocks: bias gradient
+        const int i = (blockIdx.x - nblk_w) * 32 + e;
+        if (i < Cout) {
+            p = partb + i;
+            step = CO_PAD;
+            valid = true;
+            out_i = i;
+        }
     }
-    if (db && i < Cout) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partb[(size_t)k * CO_PAD + i];
-        db[i] = s;
+    if (valid) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = g;
+        for (; k + 24 < S; k += 32) {
+            s0 += p[(size_t)k * step];
+            s1 += p[(size_t)(k + 8) * step];
+            s2 += p[(size_t)(k + 16) * step];
+            s3 += p[(size_t)(k + 24) * step];
+        }
+        for (; k < S; k += 8) s0 += p[(size_t)k * step];
+        sum = (s0 + s1) + (s2 + s3);
+    }
+    red[g][e] = sum;
+    __syncthreads();
+    if (g == 0 && valid) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += red[j][e];
+        if ((int)blockIdx.x < nblk_w) dw[out_i] = t;
+        else db[out_i] = t;
     }
 }
 
@@ -900,8 +938,8 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
     else return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad: %d column tiles per wave", ntw);
     if (rc) return rc;
     const int total = Cout * Cin * K * K;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, partb,
-                       dw, dbias, Cin, Cout, K * K, wg.c.CI_T, wg.c.nchunks, wg.c.CO_PAD, wg.NCOL,
-                       wg.S);
+    const int nblk = (total + 31) / 32 + (dbias ? (Cout + 31) / 32 : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk), dim3(256), 0, s, part, partb, dw, dbias, Cin,
+                       Cout, K * K, wg.c.CI_T, wg.c.nchunks, wg.c.CO_PAD, wg.NCOL, wg.S);
     return afd::check_launch("wgrad_reduce_kernel");
 }

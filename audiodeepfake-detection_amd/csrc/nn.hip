@@ -435,27 +435,45 @@ __global__ void linear_mean_bwd_x_kernel(const float* __restrict__ dy, const flo
 }
 
 // dw[o][f] = (1/TD) sum_b dy[b][o] sum_t x[b][t][f];  db[o] = sum_b dy[b][o]
+// block = 64 features x 4 batch groups (F is 320 in the shipped configs: one thread per
+// feature looping over the whole batch would be two workgroups of serial loads)
 template <int O>
-__global__ void linear_mean_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                         float* __restrict__ dw, float* __restrict__ db, int B,
-                                         int TD, int F) {
-    for (int f = blockIdx.x * kT + threadIdx.x; f < F; f += gridDim.x * kT) {
-        float acc[O];
+__global__ void __launch_bounds__(256)
+linear_mean_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                         float* __restrict__ dw, float* __restrict__ db, int B, int TD, int F) {
+    __shared__ float red[O][4][65];
+    const int fl = threadIdx.x & 63;
+    const int g = threadIdx.x >> 6;
+    const int f = blockIdx.x * 64 + fl;
+    float acc[O];
 #pragma unroll
-        for (int o = 0; o < O; ++o) acc[o] = 0.f;
-        for (int b = 0; b < B; ++b) {
-            float s = 0.f;
-            for (int t = 0; t < TD; ++t) s += x[((size_t)b * TD + t) * F + f];
+    for (int o = 0; o < O; ++o) acc[o] = 0.f;
+    if (f < F) {
+        for (int b = g; b < B; b += 4) {
+            float s0 = 0.f, s1 = 0.f;
+            int t = 0;
+            for (; t + 1 < TD; t += 2) {
+                s0 += x[((size_t)b * TD + t) * F + f];
+                s1 += x[((size_t)b * TD + t + 1) * F + f];
+            }
+            if (t < TD) s0 += x[((size_t)b * TD + t) * F + f];
+            const float sx = s0 + s1;
 #pragma unroll
-            for (int o = 0; o < O; ++o) acc[o] = fmaf(s, dy[(size_t)b * O + o], acc[o]);
+            for (int o = 0; o < O; ++o) acc[o] = fmaf(sx, dy[(size_t)b * O + o], acc[o]);
         }
+    }
 #pragma unroll
-        for (int o = 0; o < O; ++o) dw[(size_t)o * F + f] = acc[o] / (float)TD;
+    for (int o = 0; o < O; ++o) red[o][g][fl] = acc[o];
+    __syncthreads();
+    if (g == 0 && f < F) {
+#pragma unroll
+        for (int o = 0; o < O; ++o)
+            dw[(size_t)o * F + f] = (red[o][0][fl] + red[o][1][fl] + red[o][2][fl] + red[o][3][fl]) / (float)TD;
     }
     if (blockIdx.x == 0 && threadIdx.x < O) {
-        float s = 0.f;
-        for (int b = 0; b < B; ++b) s += dy[(size_t)b * O + threadIdx.x];
-        db[threadIdx.x] = s;
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += dy[(size_t)b * O + threadIdx.x];
+        db[threadIdx.x] = sb;
     }
 }
 
@@ -660,7 +678,7 @@ extern "C" int afd_linear_mean_backward(const float* x, const float* w, const fl
     if (B > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "linear: batch > 65535");
     hipLaunchKernelGGL(linear_mean_bwd_x_kernel<2>, dim3(grid1d(F, 64), B), dim3(kT), 0, AFD_STREAM,
                        dy, w, dx, TD, F);
-    hipLaunchKernelGGL(linear_mean_bwd_w_kernel<2>, dim3(grid1d(F, 1024)), dim3(kT), 0, AFD_STREAM, x,
+    hipLaunchKernelGGL(linear_mean_bwd_w_kernel<2>, dim3((F + 63) / 64), dim3(kT), 0, AFD_STREAM, x,
                        dy, dw, db, B, TD, F);
     return afd::check_launch("linear_mean_bwd kernels");
 }

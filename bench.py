@@ -45,6 +45,8 @@ WORKLOADS = {
     "sym5-l8": ("packets", "sym5", 256, 1, "packets-sym5 level-8 + DCNN train step"),
     "sym5-l14": ("packets", "sym5", 16384, 0, "packets-sym5 level-14 + DCNN train step"),
     "stft": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + DCNN train step"),
+    # BASELINE configs[4]: evaluation (forward + argmax) of the LCNN head on STFT features
+    "stft-lcnn-eval": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + LCNN eval forward (fp32)"),
 }
 
 
@@ -71,7 +73,12 @@ def build(workload: str, batch: int, ddp: bool, device):
     # flattened size of the dil_conv output: [time_dim, 64-24=40, P/8-24]
     p8 = args.input_dim[2] // 8
     args.flattend_size = (64 - 24) * (p8 - 24)
-    model = DCNN(args).to(device)
+    if workload.endswith("lcnn-eval"):
+        from audiofakedetect.lcnn import LCNN
+
+        model = LCNN(classes=2, in_channels=1, lstm_channels=scales).to(device)
+    else:
+        model = DCNN(args).to(device)
     opt = ops.FusedAdam(model.parameters(), lr=args.learning_rate, weight_decay=args.weight_decay)
     trainer = Trainer("/tmp/afd_bench/snap", args, normalize, transforms, None, model, None, None,
                       None, None, opt, ops.CrossEntropyLoss(), None)
@@ -81,7 +88,9 @@ def build(workload: str, batch: int, ddp: bool, device):
 def synthetic_batch(batch: int, rank: int, device):
     g = torch.Generator().manual_seed(1234 + rank)
     audio = (0.1 * torch.randn(batch, 1, 22050, generator=g)).clamp_(-1.0, 1.0)
-    labels = torch.randint(0, 2, (batch,), generator=g, dtype=torch.int64)
+    # cross-generator style labels {0: real, 1: B_melgan, 2: C_hifigan}; the step binarises
+    # them with `!= 0` as the reference does (train_classifier.py:955-957)
+    labels = torch.randint(0, 3, (batch,), generator=g, dtype=torch.int64)
     return {"audio": audio.to(device), "label": labels.to(device)}
 
 
@@ -178,14 +187,29 @@ def main() -> None:
         torch.cuda.synchronize()
 
     log(f"built {a.workload}: features {args.input_dim}, batch/GPU {a.batch}, world {world}")
+    eval_only = a.workload.endswith("eval")
+    correct = torch.zeros((), dtype=torch.float64, device=device)
+
+    def step():
+        if not eval_only:
+            trainer._run_batch(0, batch)
+            return
+        # evaluation step (reference val_test_loop, train_classifier.py:365-497): features,
+        # forward, argmax, compare with the binarised label; counts stay on the device
+        with torch.no_grad():
+            out = trainer.model(trainer._features(batch["audio"]))
+            correct.add_((out.argmax(-1) == (batch["label"] != 0)).sum())
+
+    if eval_only:
+        trainer.model.eval()
     for i in range(a.warmup):
-        trainer._run_batch(0, batch)
+        step()
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        trainer._run_batch(0, batch)
+        step()
     sync()
     elapsed = time.perf_counter() - t0
     if ddp:
@@ -198,7 +222,7 @@ def main() -> None:
     kernels = {}
     _native.timing_reset()
     _native.timing_enable(True)
-    trainer._run_batch(0, batch)
+    step()
     torch.cuda.synchronize()
     _native.timing_enable(False)
     for name in ("wpt", "conv_igemm", "conv_wgrad", "stft"):
@@ -232,7 +256,7 @@ def main() -> None:
 
     cpu = None
     log(f"kernel classes: { {k: round(v['total_ms'], 3) for k, v in kernels.items()} }")
-    if rank == 0 and world == 1 and a.cpu_frames > 0:
+    if rank == 0 and world == 1 and a.cpu_frames > 0 and not eval_only:
         cpu = cpu_baseline(a.workload, a.cpu_frames)
         log(f"cpu baseline: {cpu['value']:.4f} frames/s")
 
