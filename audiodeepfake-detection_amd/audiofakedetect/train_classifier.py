@@ -210,30 +210,106 @@ class Trainer:
             self._run_batch(epoch, batch)
 
     # -- evaluation -----------------------------------------------------------------------
+    @staticmethod
+    def calculate_eer(y_true, y_score) -> float:
+        """Equal error rate of a binary classifier output (reference :347-363).
+
+        The reference feeds sklearn's ``roc_curve`` + ``brentq`` on a linear interpolation of
+        the ROC; the same point is found here directly: sort by score, build the ROC, and
+        intersect its polyline with tpr = 1 - fpr.
+        """
+        y_true = np.asarray(y_true).astype(bool).reshape(-1)
+        y_score = np.asarray(y_score, dtype=np.float64).reshape(-1)
+        pos = max(int(y_true.sum()), 1)
+        neg = max(int((~y_true).sum()), 1)
+        order = np.argsort(-y_score, kind="stable")
+        ys, ss = y_true[order], y_score[order]
+        last = np.r_[np.nonzero(np.diff(ss))[0], ss.size - 1]  # last index of each threshold
+        tpr = np.r_[0.0, np.cumsum(ys)[last] / pos]
+        fpr = np.r_[0.0, np.cumsum(~ys)[last] / neg]
+        f = 1.0 - fpr - tpr  # decreasing along the curve; root = EER
+        k = int(np.argmax(f <= 0))
+        if f[k] == 0 or k == 0:
+            return float(fpr[k])
+        x0, x1, f0, f1 = fpr[k - 1], fpr[k], f[k - 1], f[k]
+        return float(x0 + (x1 - x0) * f0 / (f0 - f1))
+
+    @staticmethod
+    def calculate_acc_label(count_dict_gathered: list, ok_dict_gathered: list, key: int) -> float:
+        """Accuracy of one label over the per-rank gathered lists (reference :528-574)."""
+        keys = set()
+        for d in count_dict_gathered:
+            keys.update(d.keys())
+        for d in ok_dict_gathered:
+            keys.update(d.keys())
+        for d in list(count_dict_gathered) + list(ok_dict_gathered):
+            keys &= set(d.keys())
+        if key not in keys:
+            raise KeyError(f"Key {key} does not exist in both dictionaries. Only available keys: {sorted(keys)}.")
+        acc = sum(sum(d[key]) for d in ok_dict_gathered) / sum(d[key] for d in count_dict_gathered)
+        if isinstance(acc, torch.Tensor):
+            return acc.item()
+        if isinstance(acc, float):
+            return acc
+        raise TypeError("Result should either be float or tensor.")
+
+    @staticmethod
+    def caculate_acc_dict(data_loader, common_keys, ok_dict_gathered: list,
+                          count_dict_gathered: list) -> list:
+        """[(label name, accuracy)] for every label (reference :499-526; name kept as is)."""
+        return [(data_loader.dataset.get_label_name(k),
+                 Trainer.calculate_acc_label(count_dict_gathered, ok_dict_gathered, k))
+                for k in common_keys]
+
     def val_test_loop(self, data_loader, name: str = "", pbar: bool = False):
-        """Batched eval: argmax == (label != 0); counts reduced over ranks on the device."""
+        """Batched evaluation (reference :365-497): argmax == (label != 0).
+
+        The reference walks the batch sample by sample on the host (:420-429); here the
+        per-label correct / total counts are bincounts on the device, summed over ranks with
+        one all-reduce, and predictions / truths are all-gathered for the EER, which (like the
+        reference, :479-481) is computed on the hard predictions.  Returns (accuracy, eer);
+        ``self.last_eval`` keeps predictions, truths and the per-label accuracies.
+        """
         self.model.eval()
-        counts = torch.zeros(2, dtype=torch.float64, device=self.local_rank)  # correct, total
+        nlab = 64
+        counts = torch.zeros((2, nlab), dtype=torch.float64, device=self.local_rank)
         preds, truth = [], []
         key = getattr(data_loader.dataset, "key", "audio")
         with torch.no_grad():
             for batch in data_loader:
                 audio = batch[key].to(self.local_rank, non_blocking=True)
-                labels = batch["label"].to(self.local_rank, non_blocking=True) != 0
+                raw = batch["label"].to(self.local_rank, non_blocking=True).to(torch.int64)
+                labels = raw != 0
                 out = self.model(self._features(audio))
                 pred = torch.argmax(out, -1)
-                counts[0] += (pred == labels).sum()
-                counts[1] += labels.numel()
+                ok = (pred == labels).to(torch.float64)
+                counts[0] += torch.bincount(raw.clamp(0, nlab - 1), weights=ok, minlength=nlab)
+                counts[1] += torch.bincount(raw.clamp(0, nlab - 1), minlength=nlab).to(torch.float64)
                 preds.append(pred)
                 truth.append(labels)
+        preds_t = torch.cat(preds) if preds else torch.zeros(0, dtype=torch.int64, device=self.local_rank)
+        truth_t = torch.cat(truth) if truth else torch.zeros(0, dtype=torch.bool, device=self.local_rank)
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(counts)
-        acc = (counts[0] / counts[1].clamp(min=1)).item()
-        return acc, torch.cat(preds) if preds else None, torch.cat(truth) if truth else None
+            world = dist.get_world_size()
+            gp = [torch.empty_like(preds_t) for _ in range(world)]
+            gt = [torch.empty_like(truth_t) for _ in range(world)]
+            dist.all_gather(gp, preds_t)
+            dist.all_gather(gt, truth_t)
+            preds_t, truth_t = torch.cat(gp), torch.cat(gt)
+        total = counts[1].sum().clamp(min=1)
+        acc = (counts[0].sum() / total).item()
+        per_label = {int(k): (counts[0, k] / counts[1, k]).item()
+                     for k in torch.nonzero(counts[1]).flatten().tolist()}
+        eer = 0.0
+        if self.global_rank == 0 and preds_t.numel() and truth_t.any() and (~truth_t).any():
+            eer = Trainer.calculate_eer(truth_t.cpu().numpy(), preds_t.cpu().numpy())
+        self.last_eval = {"pred": preds_t, "truth": truth_t, "per_label": per_label, "name": name}
+        return acc, eer
 
     def testing(self):
-        acc, _, _ = self.val_test_loop(self.test_data_loader, name="test")
-        self.test_results = (acc,)
+        acc, eer = self.val_test_loop(self.test_data_loader, name="test")
+        self.test_results = (acc, eer)
         return self.test_results
 
     # -- snapshots ------------------------------------------------------------------------
@@ -255,8 +331,8 @@ class Trainer:
                 self._save_snapshot(epoch)
             if self.val_data_loader is not None and self.args.validation_interval and \
                     (epoch + 1) % self.args.validation_interval == 0:
-                acc, _, _ = self.val_test_loop(self.val_data_loader, name="val")
-                self.validation_list.append([self.step_total, epoch, acc])
+                acc, eer = self.val_test_loop(self.val_data_loader, name="val")
+                self.validation_list.append([self.step_total, epoch, acc, eer])
         if self.test_data_loader is not None:
             self.testing()
 
