@@ -68,6 +68,13 @@ class DCNN(nn.Module):
         for conv_i, prelu_i, pooled, bn_i in self._cnn_plan:
             conv = cnn[conv_i]
             slope = cnn[prelu_i].weight
+            if (pooled and conv.in_channels == 1 and conv.kernel_size == (3, 3)
+                    and conv.dilation == (1, 1) and not h.requires_grad):
+                # single-channel first block: conv + PReLU + pool in one kernel
+                h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0])
+                if bn_i is not None:
+                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
+                continue
             z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
             if pooled:
                 h = ops.prelu_maxpool2x2(z, slope)

@@ -176,6 +176,49 @@ class _PReLUPool(torch.autograd.Function):
         return dz, dslope
 
 
+class _Conv1PReLUPool(torch.autograd.Function):
+    """Conv2d(1 -> Cout, 3x3, pad) + PReLU + MaxPool2d(2,2), fused (single-channel first block)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope, pad):
+        lib = _lib()
+        x = _f32c(x)
+        w = _f32c(w)
+        n, _, h, wd = x.shape
+        cout = w.shape[0]
+        hp, wp = (h + 2 * pad - 2) // 2, (wd + 2 * pad - 2) // 2
+        u = torch.empty((n, cout, hp, wp), dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, cout, hp, wp), dtype=torch.uint8, device=x.device)
+        _native.check(lib.afd_conv1_pool_forward(
+            _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
+            _native.ptr(idx), n, h, wd, cout, pad, _native.stream_ptr()), "afd_conv1_pool_forward")
+        ctx.save_for_backward(x, u, idx, slope)
+        ctx.cfg = (n, h, wd, cout, pad, b is not None, tuple(w.shape))
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        lib = _lib()
+        x, u, idx, slope = ctx.saved_tensors
+        n, h, wd, cout, pad, has_bias, wshape = ctx.cfg
+        du = _f32c(du)
+        dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        dslope = torch.zeros(1, dtype=torch.float32, device=x.device)
+        ws = _ws(lib.afd_conv1_pool_workspace_bytes(n, h, wd, cout, pad), x.device)
+        _native.check(lib.afd_conv1_pool_backward(
+            _native.ptr(x), _native.ptr(du), _native.ptr(idx), _native.ptr(u), _native.ptr(slope),
+            _native.ptr(dw), _native.ptr(db), _native.ptr(dslope), n, h, wd, cout, pad,
+            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv1_pool_backward")
+        return None, dw, db, dslope, None
+
+
+def conv1_prelu_maxpool(x, w, b, slope, padding: int):
+    """Fused first block for single-channel inputs (no gradient w.r.t. x: the features are
+    produced under no_grad, reference train_classifier.py:965-967)."""
+    return _Conv1PReLUPool.apply(x, w, b, slope, int(padding))
+
+
 def prelu_maxpool2x2(z, slope: Optional[torch.Tensor]):
     """MaxPool2d(2,2)(PReLU(z)); slope=None -> plain max pool."""
     return _PReLUPool.apply(z, slope)

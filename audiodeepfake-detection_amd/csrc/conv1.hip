@@ -1,0 +1,236 @@
+// First DCNN / LCNN block for single-channel inputs, fused: Conv2d(1 -> Cout, 3x3, pad p) +
+// PReLU + MaxPool2d(2,2) forward, and the matching backward (pool routing + PReLU + weight,
+// bias and slope gradients) without ever materialising the pre-pool tensor.
+//
+// Replaces cnn[0..2] of the reference DCNN (src/audiofakedetect/models.py:255-259) for
+// args.input_dim[1] == 1.  At level 14 (B = 128) the pre-pool activation is 14 GB: the
+// unfused path writes it, reads it for the pool, writes a 14 GB gradient in the backward pool
+// and reads that again for the weight gradient.  Here both passes touch only the pooled
+// tensors (u 3.5 GB, 3-bit codes 0.9 GB) and the 0.2 GB input.  With K*K = 9 taps the MFMA
+// K dimension would be 90 % padding; this is f32 VALU work, memory bound.
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kCG = 8;  // channels per backward workgroup
+
+__device__ __forceinline__ float prelu1(float z, float a) { return z > 0.f ? z : a * z; }
+
+// 4x4 input patch of pooled pixel (py, px): rows 2py-pad .. +3, cols 2px-pad .. +3, zero padded
+__device__ __forceinline__ void load_patch(const float* __restrict__ xn, int H, int W, int py, int px,
+                                           int pad, float (&p)[4][4]) {
+    const int r0 = 2 * py - pad, c0 = 2 * px - pad;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = r0 + j;
+        const bool rok = (r >= 0) && (r < H);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + i;
+            p[j][i] = (rok && c >= 0 && c < W) ? xn[(size_t)r * W + c] : 0.f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kT)
+conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                      const float* __restrict__ bias, const float* __restrict__ slope,
+                      float* __restrict__ u, unsigned char* __restrict__ idx, int H, int W, int Cout,
+                      int pad, int Hp, int Wp) {
+    const int px = blockIdx.x * kT + threadIdx.x;
+    const int py = blockIdx.y;
+    const int n = blockIdx.z;
+    if (px >= Wp) return;
+    const float a = slope[0];
+    float p[4][4];
+    load_patch(x + (size_t)n * H * W, H, W, py, px, pad, p);
+    const size_t plane = (size_t)Hp * Wp;
+    size_t o = ((size_t)n * Cout * Hp + py) * Wp + px;
+    for (int co = 0; co < Cout; ++co, o += plane) {
+        const float* wc = w + co * 9;  // uniform address: scalar loads
+        const float b = bias ? bias[co] : 0.f;
+        float z0 = b, z1 = b, z2 = b, z3 = b;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float wv = wc[ky * 3 + kx];
+                z0 = fmaf(wv, p[ky][kx], z0);
+                z1 = fmaf(wv, p[ky][kx + 1], z1);
+                z2 = fmaf(wv, p[ky + 1][kx], z2);
+                z3 = fmaf(wv, p[ky + 1][kx + 1], z3);
+            }
+        float best = prelu1(z0, a), zb = z0;
+        int bi = 0;
+        float v = prelu1(z1, a);
+        if (v > best) { best = v; bi = 1; zb = z1; }
+        v = prelu1(z2, a);
+        if (v > best) { best = v; bi = 2; zb = z2; }
+        v = prelu1(z3, a);
+        if (v > best) { best = v; bi = 3; zb = z3; }
+        u[o] = best;
+        idx[o] = (unsigned char)(bi | (zb <= 0.f ? 4 : 0));
+    }
+}
+
+// partial[split][cg][kCG][11]: 9 weight gradients, bias gradient, slope gradient
+__global__ void __launch_bounds__(kT)
+conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                      const unsigned char* __restrict__ idx, const float* __restrict__ u,
+                      const float* __restrict__ slope, float* __restrict__ partial, int N, int H,
+                      int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalTiles) {
+    __shared__ float red[kT / 64][kCG * 11];
+    const int cg = blockIdx.x;
+    const int split = blockIdx.y;
+    const int S = gridDim.y;
+    const float a = slope[0];
+    const float inva = a != 0.f ? 1.f / a : 0.f;
+    float acc[kCG][9];
+    float accb[kCG], accs[kCG];
+#pragma unroll
+    for (int c = 0; c < kCG; ++c) {
+        accb[c] = 0.f;
+        accs[c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
+    }
+    const size_t plane = (size_t)Hp * Wp;
+    for (long t = split; t < totalTiles; t += S) {
+        const int xc = (int)(t % tilesX);
+        const long row = t / tilesX;
+        const int py = (int)(row % Hp);
+        const int n = (int)(row / Hp);
+        const int px = xc * kT + threadIdx.x;
+        if (px >= Wp) continue;
+        float p[4][4];
+        load_patch(x + (size_t)n * H * W, H, W, py, px, pad, p);
+        size_t o = (((size_t)n * Cout + cg * kCG) * Hp + py) * Wp + px;
+#pragma unroll
+        for (int c = 0; c < kCG; ++c, o += plane) {
+            if (cg * kCG + c >= Cout) break;
+            const int code = idx[o];
+            float g = du[o];
+            if (code & 4) {
+                accs[c] += g * u[o] * inva;
+                g *= a;
+            }
+            accb[c] += g;
+            const int pos = code & 3;
+            const float g0 = pos == 0 ? g : 0.f, g1 = pos == 1 ? g : 0.f;
+            const float g2 = pos == 2 ? g : 0.f, g3 = pos == 3 ? g : 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float s = acc[c][ky * 3 + kx];
+                    s = fmaf(g0, p[ky][kx], s);
+                    s = fmaf(g1, p[ky][kx + 1], s);
+                    s = fmaf(g2, p[ky + 1][kx], s);
+                    s = fmaf(g3, p[ky + 1][kx + 1], s);
+                    acc[c][ky * 3 + kx] = s;
+                }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < kCG; ++c) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            float v = k < 9 ? acc[c][k] : (k == 9 ? accb[c] : accs[c]);
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wave][c * 11 + k] = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kCG * 11) {
+        float v = 0.f;
+        for (int wv = 0; wv < kT / 64; ++wv) v += red[wv][threadIdx.x];
+        partial[((size_t)split * gridDim.x + cg) * (kCG * 11) + threadIdx.x] = v;
+    }
+}
+
+__global__ void conv1_bwd_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                        float* __restrict__ dbias, float* __restrict__ dslope, int Cout,
+                                        int CG, int S) {
+    // one thread per (cg, c, k)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = kCG * 11;
+    float sl = 0.f;
+    if (i < CG * per) {
+        float s0 = 0.f, s1 = 0.f;
+        int sp = 0;
+        for (; sp + 1 < S; sp += 2) {
+            s0 += partial[(size_t)sp * CG * per + i];
+            s1 += partial[(size_t)(sp + 1) * CG * per + i];
+        }
+        if (sp < S) s0 += partial[(size_t)sp * CG * per + i];
+        const float s = s0 + s1;
+        const int cg = i / per, r = i % per, c = r / 11, k = r % 11;
+        const int co = cg * kCG + c;
+        if (co < Cout) {
+            if (k < 9) dw[co * 9 + k] = s;
+            else if (k == 9) { if (dbias) dbias[co] = s; }
+            else sl = s;
+        }
+    }
+    // slope gradient: sum over channels
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sl += __shfl_down(sl, off, 64);
+    if ((threadIdx.x & 63) == 0 && sl != 0.f) atomicAdd(dslope, sl);
+}
+
+int bwd_splits(long totalTiles, int CG) {
+    long S = 2048 / CG;
+    if (S > totalTiles) S = totalTiles;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+}  // namespace
+
+#define AFD_STREAM static_cast<hipStream_t>(stream)
+
+extern "C" size_t afd_conv1_pool_workspace_bytes(int N, int H, int W, int Cout, int pad) {
+    const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
+    if (Hp < 1 || Wp < 1) return 0;
+    const int CG = (Cout + kCG - 1) / kCG;
+    const long tiles = (long)N * Hp * ((Wp + kT - 1) / kT);
+    return (size_t)bwd_splits(tiles, CG) * CG * kCG * 11 * sizeof(float);
+}
+
+extern "C" int afd_conv1_pool_forward(const float* x, const float* w, const float* bias,
+                                      const float* slope, float* u, uint8_t* idx, int N, int H, int W,
+                                      int Cout, int pad, afd_stream_t stream) {
+    if (!x || !w || !slope || !u || !idx) return afd::fail(AFD_ERR_ARG, "conv1 fwd: null pointer");
+    const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
+    if (N < 1 || Cout < 1 || Hp < 1 || Wp < 1 || pad < 0) return afd::fail(AFD_ERR_ARG, "conv1 fwd: bad geometry");
+    if (Hp > 65535 || N > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 fwd: grid too large");
+    hipLaunchKernelGGL(conv1_pool_fwd_kernel, dim3((Wp + kT - 1) / kT, Hp, N), dim3(kT), 0, AFD_STREAM,
+                       x, w, bias, slope, u, idx, H, W, Cout, pad, Hp, Wp);
+    return afd::check_launch("conv1_pool_fwd_kernel");
+}
+
+extern "C" int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx,
+                                       const float* u, const float* slope, float* dw, float* dbias,
+                                       float* dslope, int N, int H, int W, int Cout, int pad, void* ws,
+                                       size_t ws_bytes, afd_stream_t stream) {
+    if (!x || !du || !idx || !u || !slope || !dw || !dslope) return afd::fail(AFD_ERR_ARG, "conv1 bwd: null pointer");
+    const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
+    if (N < 1 || Cout < 1 || Hp < 1 || Wp < 1) return afd::fail(AFD_ERR_ARG, "conv1 bwd: bad geometry");
+    const int CG = (Cout + kCG - 1) / kCG;
+    const int tilesX = (Wp + kT - 1) / kT;
+    const long tiles = (long)N * Hp * tilesX;
+    const int S = bwd_splits(tiles, CG);
+    if (!ws || ws_bytes < (size_t)S * CG * kCG * 11 * sizeof(float))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv1 bwd: workspace too small");
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL(conv1_pool_bwd_kernel, dim3(CG, S), dim3(kT), 0, AFD_STREAM, x, du, idx, u, slope,
+                       partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles);
+    const int total = CG * kCG * 11;
+    hipLaunchKernelGGL(conv1_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, AFD_STREAM, partial,
+                       dw, dbias, dslope, Cout, CG, S);
+    return afd::check_launch("conv1_pool_bwd kernels");
+}

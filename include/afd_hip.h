@@ -115,6 +115,21 @@ int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
                                afd_stream_t stream);
 
+/* First block for single-channel inputs, fused: Conv2d(1 -> Cout, 3x3, pad) + PReLU +
+ * MaxPool2d(2,2) (reference models.py:255-259 with args.input_dim[1] == 1).  Forward writes
+ * only the pooled tensor u [N][Cout][Hp][Wp] and the 3-bit code idx (as afd_prelu_pool_*);
+ * backward consumes du, idx, u and x and produces dw [Cout][1][3][3], dbias [Cout] (may be
+ * NULL) and dslope (+=); the pre-pool activation and its gradient are never materialised.
+ * Hp = (H + 2 pad - 2) / 2. */
+size_t afd_conv1_pool_workspace_bytes(int N, int H, int W, int Cout, int pad);
+int afd_conv1_pool_forward(const float* x, const float* w, const float* bias, const float* slope,
+                           float* u, uint8_t* idx, int N, int H, int W, int Cout, int pad,
+                           afd_stream_t stream);
+int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx, const float* u,
+                            const float* slope, float* dw, float* dbias, float* dslope /* += */,
+                            int N, int H, int W, int Cout, int pad, void* ws, size_t ws_bytes,
+                            afd_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * HBM-bound layers.  `slope` is the device address of the single shared PReLU parameter
  * (nn.PReLU(), models.py:258); where it is "may be NULL" the PReLU is skipped.

@@ -222,3 +222,27 @@ def test_normalize_and_transpose():
     assert torch.allclose(y, (view + 3.0) / 2.5, atol=1e-6)
     t = ops.transpose_last2(x)
     assert torch.equal(t, x.transpose(-1, -2).contiguous())
+
+
+@pytest.mark.parametrize("shape,cout,pad", [((3, 1, 24, 300), 64, 2), ((2, 1, 109, 256), 64, 2),
+                                            ((2, 1, 11, 37), 20, 1)])
+@pytest.mark.parametrize("slope", [0.25, -0.4])
+def test_fused_conv1_prelu_pool(shape, cout, pad, slope):
+    """Single-channel first block fused (conv 3x3 + PReLU + MaxPool2d) vs the three torch ops."""
+    g = torch.Generator().manual_seed(sum(shape) + cout)
+    x = torch.randn(shape, generator=g)
+    w = torch.randn(cout, 1, 3, 3, generator=g) / 3
+    b = torch.randn(cout, generator=g)
+    wr, br = w.double().requires_grad_(), b.double().requires_grad_()
+    ar = torch.tensor([slope], dtype=torch.float64, requires_grad=True)
+    ur = F.max_pool2d(F.prelu(F.conv2d(x.double(), wr, br, padding=pad), ar), 2, 2)
+    du = torch.randn(ur.shape, generator=g)
+    ur.backward(du.double())
+    wg, bg = w.cuda().requires_grad_(), b.cuda().requires_grad_()
+    ag = torch.tensor([slope], device="cuda", requires_grad=True)
+    ug = ops.conv1_prelu_maxpool(x.cuda(), wg, bg, ag, pad)
+    _close(ug, ur.detach(), 2e-6, "conv1 fused fwd")
+    ug.backward(du.cuda())
+    _close(wg.grad, wr.grad, 2e-5, "conv1 fused dw")
+    _close(bg.grad, br.grad, 2e-5, "conv1 fused db")
+    _close(ag.grad, ar.grad, 1e-4, "conv1 fused dslope")
