@@ -794,9 +794,21 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
     g.patchFloats = ((ct * g.PR * g.PC + 3) / 4) * 4;
     wg.NTILES = (ct * KK + 31) / 32;
     wg.NCOL = wg.NTILES * 32;
-    // waves = MT * NG, at most 8; per-wave column tiles NTW in {1,3,5,9}
-    int NG = ngmax;
-    if (NG > wg.NTILES) NG = wg.NTILES;
+    // waves = MT * NG (at most 8); every wave computes NTW = ceil(NTILES / NG) column tiles,
+    // tiles past NTILES are wasted MFMAs: take the NG with the fewest wasted slots (ties: more
+    // waves), e.g. 9 tiles -> NG 3 x 3 tiles rather than NG 4 x 3 (3 idle slots).
+    int NG = 1;
+    double best_eff = -1.0;
+    for (int cand = 1; cand <= ngmax && cand <= wg.NTILES; ++cand) {
+        const int ntw = (wg.NTILES + cand - 1) / cand;
+        if (ntw > 9) continue;
+        const int bucket = ntw <= 6 ? ntw : 9;
+        const double eff = (double)wg.NTILES / (bucket * cand) + 1e-3 * cand;
+        if (eff > best_eff) {
+            best_eff = eff;
+            NG = cand;
+        }
+    }
     wg.NG = NG;
     {
         const int nthreads = wg.MT * wg.NG * 64;
@@ -932,8 +944,11 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
     float* partb = part + (size_t)wg.S * wg.c.nchunks * wg.c.CO_PAD * wg.NCOL;
     const int ntw = (wg.NTILES + wg.NG - 1) / wg.NG;
     if (ntw <= 1) rc = launch_wgrad_t<1>(wg, x, dy, part, partb, s);
-    else if (ntw <= 3) rc = launch_wgrad_t<3>(wg, x, dy, part, partb, s);
-    else if (ntw <= 5) rc = launch_wgrad_t<5>(wg, x, dy, part, partb, s);
+    else if (ntw == 2) rc = launch_wgrad_t<2>(wg, x, dy, part, partb, s);
+    else if (ntw == 3) rc = launch_wgrad_t<3>(wg, x, dy, part, partb, s);
+    else if (ntw == 4) rc = launch_wgrad_t<4>(wg, x, dy, part, partb, s);
+    else if (ntw == 5) rc = launch_wgrad_t<5>(wg, x, dy, part, partb, s);
+    else if (ntw == 6) rc = launch_wgrad_t<6>(wg, x, dy, part, partb, s);
     else if (ntw <= 9) rc = launch_wgrad_t<9>(wg, x, dy, part, partb, s);
     else return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad: %d column tiles per wave", ntw);
     if (rc) return rc;

@@ -163,11 +163,12 @@ __global__ void prelu_pool_fwd_kernel(const float* __restrict__ z, const float* 
 // row / column).  Through the PReLU: dz = a g and dslope += g z with z = u / a where bit 2 of
 // idx is set (slope exactly 0 loses that term: z is not recoverable from u = 0).
 template <bool VEC>
-__global__ void prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slope,
-                                      const unsigned char* __restrict__ idx,
-                                      const float* __restrict__ du, float* __restrict__ dz,
-                                      float* __restrict__ dslope, int H, int W, int Hp, int Wp,
-                                      float invWp) {
+__global__ void __launch_bounds__(kT)
+prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slope,
+                      const unsigned char* __restrict__ idx, const float* __restrict__ du,
+                      float* __restrict__ dz, float* __restrict__ dslope, int H, int W, int Hp, int Wp,
+                      float invWp) {
+    constexpr int UN = 4;  // pooled pixels per thread per round: 12 loads in flight, then stores
     const float a = slope ? slope[0] : 1.f;
     const float inva = (slope && a != 0.f) ? 1.f / a : 0.f;
     const size_t plane = blockIdx.y;
@@ -175,33 +176,47 @@ __global__ void prelu_pool_bwd_kernel(const float* __restrict__ u, const float* 
     const size_t pbase = plane * (size_t)Hp * Wp;
     const int total = Hp * Wp;
     float ds = 0.f, u0 = 0.f, u1 = 0.f;
-    for (int i = blockIdx.x * kT + threadIdx.x; i < total; i += gridDim.x * kT) {
-        int py, px;
-        divmod_small(i, Wp, invWp, py, px);
-        const int code = idx[pbase + i];
-        float g = du[pbase + i];
-        if (code & 4) {
-            ds += g * u[pbase + i] * inva;
-            g *= a;
+    for (int base = blockIdx.x * kT * UN; base < total; base += gridDim.x * kT * UN) {
+        int code[UN];
+        float g[UN], uu[UN];
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int i = base + r * kT + threadIdx.x;
+            const bool ok = i < total;
+            code[r] = ok ? idx[pbase + i] : 0;
+            g[r] = ok ? du[pbase + i] : 0.f;
+            uu[r] = (ok && slope) ? u[pbase + i] : 0.f;
         }
-        const int pos = code & 3;
-        float* r0 = dzp + (size_t)(2 * py) * W + 2 * px;
-        const float g0 = pos == 0 ? g : 0.f, g1 = pos == 1 ? g : 0.f;
-        const float g2 = pos == 2 ? g : 0.f, g3 = pos == 3 ? g : 0.f;
-        if (VEC) {
-            *reinterpret_cast<float2*>(r0) = make_float2(g0, g1);
-            *reinterpret_cast<float2*>(r0 + W) = make_float2(g2, g3);
-        } else {
-            r0[0] = g0; r0[1] = g1; r0[W] = g2; r0[W + 1] = g3;
-        }
-        if ((W & 1) && px == Wp - 1) {  // odd width: last column belongs to no window
-            dzp[(size_t)(2 * py) * W + W - 1] = 0.f;
-            dzp[(size_t)(2 * py + 1) * W + W - 1] = 0.f;
-        }
-        if ((H & 1) && py == Hp - 1) {  // odd height: last row
-            dzp[(size_t)(H - 1) * W + 2 * px] = 0.f;
-            dzp[(size_t)(H - 1) * W + 2 * px + 1] = 0.f;
-            if ((W & 1) && px == Wp - 1) dzp[(size_t)(H - 1) * W + W - 1] = 0.f;
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int i = base + r * kT + threadIdx.x;
+            if (i >= total) continue;
+            int py, px;
+            divmod_small(i, Wp, invWp, py, px);
+            float gg = g[r];
+            if (code[r] & 4) {
+                ds += gg * uu[r] * inva;
+                gg *= a;
+            }
+            const int pos = code[r] & 3;
+            float* r0 = dzp + (size_t)(2 * py) * W + 2 * px;
+            const float g0 = pos == 0 ? gg : 0.f, g1 = pos == 1 ? gg : 0.f;
+            const float g2 = pos == 2 ? gg : 0.f, g3 = pos == 3 ? gg : 0.f;
+            if (VEC) {
+                *reinterpret_cast<float2*>(r0) = make_float2(g0, g1);
+                *reinterpret_cast<float2*>(r0 + W) = make_float2(g2, g3);
+            } else {
+                r0[0] = g0; r0[1] = g1; r0[W] = g2; r0[W + 1] = g3;
+            }
+            if ((W & 1) && px == Wp - 1) {  // odd width: last column belongs to no window
+                dzp[(size_t)(2 * py) * W + W - 1] = 0.f;
+                dzp[(size_t)(2 * py + 1) * W + W - 1] = 0.f;
+            }
+            if ((H & 1) && py == Hp - 1) {  // odd height: last row
+                dzp[(size_t)(H - 1) * W + 2 * px] = 0.f;
+                dzp[(size_t)(H - 1) * W + 2 * px + 1] = 0.f;
+                if ((W & 1) && px == Wp - 1) dzp[(size_t)(H - 1) * W + W - 1] = 0.f;
+            }
         }
     }
     if (slope) {
@@ -219,7 +234,15 @@ __device__ __forceinline__ void plane_loop(size_t plane_base, int HW, int bx, in
     int head = (int)((4 - (plane_base & 3)) & 3);
     if (head > HW) head = HW;
     const int nvec = (HW - head) >> 2;
-    for (int v = bx * kT + threadIdx.x; v < nvec; v += nbx * kT) f4(head + 4 * v);
+    // four independent float4 visits per trip: with __restrict__ operands the compiler hoists
+    // the four loads above the first store (one memory latency per trip instead of four)
+    for (int v0 = bx * kT * 4 + threadIdx.x; v0 < nvec; v0 += nbx * kT * 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = v0 + r * kT;
+            if (v < nvec) f4(head + 4 * v);
+        }
+    }
     if (bx == 0) {
         if ((int)threadIdx.x < head) f1((int)threadIdx.x);
         const int t = head + 4 * nvec + (int)threadIdx.x;
@@ -594,7 +617,7 @@ extern "C" int afd_prelu_pool_backward(const float* u, const float* slope, const
     if (!u || !idx || !du || !dz || (slope && !dslope)) return afd::fail(AFD_ERR_ARG, "pool bwd: null pointer");
     const int Hp = H / 2, Wp = W / 2;
     if ((long)Hp * Wp >= (1L << 23)) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: plane too large");
-    const unsigned gx = grid1d((size_t)Hp * Wp, 64);
+    const unsigned gx = grid1d(((size_t)Hp * Wp + 3) / 4, 16);
     const bool vec = (W % 2 == 0) && (((size_t)H * W) % 2 == 0) && (((uintptr_t)dz & 7) == 0);
     for (int p0 = 0; p0 < NC; p0 += 65535) {
         const int np = NC - p0 < 65535 ? NC - p0 : 65535;
