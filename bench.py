@@ -244,6 +244,19 @@ def main() -> None:
             roofline = {"kernel": dom, "bound": "mfma", "achieved": ach,
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None}
+        # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process):
+        # read back from the committed counter summary when it covers this workload
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if pmc.get("workload") == a.workload and pmc.get("batch") == a.batch:
+                kk = pmc["kernels"].get({"conv_igemm": "conv_igemm_kernel", "conv_wgrad": "conv_wgrad_kernel",
+                                          "wpt": "wpt2_deep_kernel", "stft": "stft_mfma_kernel"}[dom], {})
+                if kk:
+                    roofline["traffic"] = kk.get("fetch_size_bytes_per_launch", 0.0) + kk.get("write_size_bytes_per_launch", 0.0)
+                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (raw FETCH_SIZE + WRITE_SIZE per launch)"
+        except (OSError, ValueError, KeyError):
+            pass
         roofline["launches_per_step"] = k["launches"]
         roofline["avg_launch_ms"] = k["avg_ms"]
         roofline["share_of_step"] = k["total_ms"] / step_ms
