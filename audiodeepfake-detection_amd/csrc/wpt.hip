@@ -327,6 +327,9 @@ extern "C" int afd_wpt_out_len(int N, int L, int level) {
 }
 
 namespace afd {
+int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L, int level,
+                       unsigned flags, float power, float eps, float mean, float std, float* out,
+                       hipStream_t stream);
 size_t wpt2_workspace_bytes(int B, int N, int L, int level);
 int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
                  int level, unsigned flags, float power, float eps, float mean, float std, float* out,
@@ -352,6 +355,12 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
     if ((flags & AFD_WPT_NORM) && std == 0.f) return afd::fail(AFD_ERR_ARG, "wpt: std == 0");
     if ((long)B << (level >= 3 ? 2 : level - 1) > 0x7fffffffL)
         return afd::fail(AFD_ERR_ARG, "wpt: batch too large");
+    if (!getenv("AFD_WPT_NO_HAAR")) {
+        // Haar, level 14, 22 050-sample frames: dedicated add/subtract network (wpt_haar.hip)
+        const int rch = afd::wpt_haar14_forward(x, B, N, dec_lo, L, level, flags, power, eps, mean, std,
+                                                out, static_cast<hipStream_t>(stream));
+        if (rch != 1) return rch;
+    }
     // Deep transforms (level >= 11) run on the second-generation kernels (wpt2.hip: register
     // window + packed FMAs, dense compile-time deep levels): measured 389 vs 627 us on coif4
     // level 14, B = 128; up to level 10 the single-launch kernel below is faster (94 vs 117 us
