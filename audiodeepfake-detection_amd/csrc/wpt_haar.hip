@@ -3,14 +3,23 @@
 //
 // With 2 taps the transform is an add/subtract network (no products: the 1/sqrt(2) per level is
 // applied once at the end as 2^-7, exactly), so the generic filter-bank kernels are pure
-// overhead here.  This kernel does one frame per workgroup, one level-2 quarter at a time:
-//   levels 1-2   straight from global memory: element i of the quarter is a +/- combination of
-//                x[4i .. 4i+3] (one float4 load; the frame is re-read per quarter from L2);
-//   levels 3-8   in LDS, node-major slots, lanes over positions, float2 reads;
-//   levels 9-14  in registers: one thread per level-9 node (44 samples), compile-time
-//                recursion down to the 32 leaf nodes of 2 samples;
-//   store        leaves are transposed through LDS and written as coalesced float4 rows of the
-//                [B][C][T=2][P=16384] output, log-power / sign / normalise applied on the way.
+// overhead here.  A 512-thread workgroup owns one level-1 half of a frame (its low-pass or its
+// high-pass node, 8192 of the 16384 packets); two workgroups run per CU, and the two halves of
+// a frame are given to workgroups on the same XCD so the frame leaves HBM once.  The half
+// lives in one 44 KB LDS image that every level overwrites in place:
+//   levels 1-2   straight from global memory: element i of the two level-2 nodes is a +/-
+//                combination of x[4i .. 4i+3];
+//   levels 3-8   three radix-4 passes in LDS (two levels per pass): each work item reads four
+//                consecutive samples of a node into registers, barrier, writes element i of
+//                the four grandchildren into the parent's own slot (quartered);
+//   levels 9-14  in registers: thread = level-10 node (512 per half, 22 samples each),
+//                compile-time recursion down to its 16 leaf nodes of 2 samples;
+//   store        a thread owns 16 consecutive packets of both time rows (one 64-byte segment
+//                per row): 4 x 4 float4 transpose inside lane quads, log-power / sign /
+//                normalise in registers, float4 stores into [B][C][T=2][P=16384].
+// The next frame's samples are loaded, a third at a time, while the LDS passes run.
+// Nodes sit in frequency (Gray) order: child 2F of parent F is the low-pass child when F is
+// even and the high-pass child when F is odd.
 // Reflect rule for odd node lengths: xe[n] = x[n-2] (the last pair is (x[n-1], x[n-2])).
 // Algorithmic bytes per frame: 4 * (22050 + 32768) = 219 272.
 #include "afd_common.h"
@@ -18,13 +27,16 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 512;
 constexpr int kN = 22050;
 // node lengths of the Haar tree for N = 22050
 constexpr int kLen[15] = {22050, 11025, 5513, 2757, 1379, 690, 345, 173, 87, 44, 22, 11, 6, 3, 2};
-// LDS slot (even capacity >= length) per node at levels 2..8 inside one quarter
-constexpr int kCap[9] = {0, 0, 5632, 2816, 1408, 704, 352, 176, 88};
-constexpr int kBufFloats = 5632;  // one level of a quarter (64 * 88 = 5632 at level 8 too)
+// LDS slot per node at levels 2, 4, 6, 8 (quartered every two levels).  A workgroup holds one
+// level-1 half of a frame: 2 * 5632 floats = 44 KB
+constexpr int kCap2 = 5632;
+constexpr int kLdsFloats = 2 * kCap2;
+constexpr int kItems = 6;   // work items per thread in an LDS pass
+constexpr int kLoadItems = 11;  // ... and in the frame load (both halves read the whole frame)
 
 struct HaarParams {
     const float* x;
@@ -41,164 +53,269 @@ __device__ __forceinline__ float haar_epilogue(float v, const HaarParams& p) {
     return v;
 }
 
-// registers -> leaves: node of LEN samples with frequency index F (local to the quarter);
-// children of an even-F node are (a, d), of an odd-F node (d, a)
-template <int LEN>
+// registers -> leaves.  `s` is +1 when the node's frequency index is even (first child =
+// sum), -1 when odd (first child = difference); below the root it is a literal, so the
+// products fold into adds / subtracts.  POS = leaf offset of the subtree inside the thread.
+template <int LEN, int POS>
 struct Sub {
-    static __device__ __forceinline__ void run(const float (&v)[LEN], int F, float* leaves) {
+    static __device__ __forceinline__ void run(const float (&v)[LEN], float s, float (&out)[2][16]) {
         constexpr int NOUT = (LEN + 1) / 2;
-        float a[NOUT], d[NOUT];
+        float first[NOUT], second[NOUT];
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) {
             const float x0 = v[2 * i];
             const float x1 = (2 * i + 1 < LEN) ? v[2 * i + 1] : v[2 * i - 1 < 0 ? 0 : 2 * i - 1];
-            a[i] = x0 + x1;
-            d[i] = x0 - x1;
+            first[i] = fmaf(s, x1, x0);
+            second[i] = fmaf(-s, x1, x0);
         }
-        const int par = F & 1;
-        Sub<NOUT>::run(a, 2 * F + par, leaves);
-        Sub<NOUT>::run(d, 2 * F + 1 - par, leaves);
+        Sub<NOUT, 2 * POS>::run(first, 1.f, out);
+        Sub<NOUT, 2 * POS + 1>::run(second, -1.f, out);
     }
 };
 
-template <>
-struct Sub<2> {
-    static __device__ __forceinline__ void run(const float (&v)[2], int F, float* leaves) {
-        // leaves[t * 4096 + packet]
-        leaves[F] = v[0];
-        leaves[4096 + F] = v[1];
+template <int POS>
+struct Sub<2, POS> {
+    static __device__ __forceinline__ void run(const float (&v)[2], float, float (&out)[2][16]) {
+        out[0][POS] = v[0];
+        out[1][POS] = v[1];
     }
 };
 
-__global__ void __launch_bounds__(kThreads) wpt_haar14_kernel(const HaarParams p) {
-    // 54 KB: two workgroups per CU.  Level 8 ends in bufA (six swaps), so the leaf transpose
-    // buffer can share storage with bufB.
-    __shared__ __attribute__((aligned(16))) float bufA[kBufFloats];
-    __shared__ __attribute__((aligned(16))) float bufB[2 * 4096];
-    float* leaves = bufB;
+// v = four float4 per lane; on return float4 k of lane q (inside its quad) is what float4 q of
+// lane k was.  Two exchange stages (lane ^ 1, lane ^ 2) over DPP quad permutes.
+template <int S>
+__device__ __forceinline__ void quad_exchange(float& keep0, float& keep1, bool hi) {
+    // lanes with the bit clear hand over register j1 and take the partner's j0; the others
+    // hand over j0 and take j1
+    const float send = hi ? keep0 : keep1;
+    constexpr int ctrl = (S == 1) ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+    const float recv = __builtin_bit_cast(
+        float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), ctrl, 0xF, 0xF, true));
+    if (hi) keep0 = recv; else keep1 = recv;
+}
+
+__device__ __forceinline__ void quad_transpose(float (&v)[16], int lane) {
+    const bool h1 = lane & 1, h2 = lane & 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        quad_exchange<1>(v[0 + c], v[4 + c], h1);
+        quad_exchange<1>(v[8 + c], v[12 + c], h1);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        quad_exchange<2>(v[0 + c], v[8 + c], h2);
+        quad_exchange<2>(v[4 + c], v[12 + c], h2);
+    }
+}
+
+// The four samples feeding element i of a node's grandchildren are x[4i .. 4i+3], except for
+// the last element of an odd-length node, where the reflect rule (twice: at the node and at
+// its children) gives, for n = 4k + 1, (x[n-1], x[n-2], x[n-3], x[n-2]) and, for n = 4k + 3,
+// (x[n-3], x[n-2], x[n-1], x[n-2]).  Selects instead of branches: every LDS read of a pass is
+// issued before the first is used.  `before` = x[4i-2], x[4i-1] (only read when n = 4k + 1).
+template <int n>
+__device__ __forceinline__ float4 fix_tail(const float4 v, const float2 before, bool last) {
+    if (n % 4 == 1) return last ? make_float4(v.x, before.y, before.x, before.y) : v;
+    static_assert(n % 4 == 1 || n % 4 == 3, "node length");
+    return last ? make_float4(v.x, v.y, v.z, v.y) : v;
+}
+
+// element i of the grandchildren 4F .. 4F+3 of a node with frequency parity `odd`
+__device__ __forceinline__ float4 butterfly4(const float4 x, bool odd) {
+    const float s = odd ? -1.f : 1.f;
+    const float a0 = fmaf(s, x.y, x.x), a1 = fmaf(s, x.w, x.z);    // first child (even index)
+    const float d0 = fmaf(-s, x.y, x.x), d1 = fmaf(-s, x.w, x.z);  // second child (odd index)
+    return make_float4(a0 + a1, a0 - a1, d0 - d1, d0 + d1);
+}
+
+// one radix-4 pass: levels LEV -> LEV + 2 for the 2^(LEV-1) nodes of the half, in place
+template <int LEV>
+__device__ __forceinline__ void lds_pass(float* buf, int tid) {
+    constexpr int M = 1 << (LEV - 1);
+    constexpr int n_gc = kLen[LEV + 2];
+    constexpr int capIn = kCap2 >> (LEV - 2), capOut = capIn / 4;
+    constexpr int total = M * n_gc;
+    static_assert(total <= kItems * kThreads && kLen[2] <= kLoadItems * kThreads,
+                  "pass does not fit the register staging");
+    static_assert(n_gc <= capOut && 4 * n_gc <= capIn, "slot capacity");
+    constexpr int n_in = kLen[LEV];
+    float4 v[kItems];
+    float2 e[kItems];
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        int w = r * kThreads + tid;
+        w = w < total ? w : total - 1;
+        const int q = w / n_gc, i = w - q * n_gc;
+        v[r] = *reinterpret_cast<const float4*>(buf + q * capIn + 4 * i);
+        if (n_in % 4 == 1) e[r] = *reinterpret_cast<const float2*>(buf + q * capIn + (i ? 4 * i - 2 : 0));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kItems; ++r) {
+        const int w = r * kThreads + tid;
+        if (w < total) {
+            const int q = w / n_gc, i = w - q * n_gc;
+            const float4 g = butterfly4(fix_tail<n_in>(v[r], e[r], i == n_gc - 1), q & 1);
+            float* o = buf + q * capIn + i;
+            o[0] = g.x;
+            o[capOut] = g.y;
+            o[2 * capOut] = g.z;
+            o[3 * capOut] = g.w;
+        }
+    }
+    __syncthreads();
+}
+
+// Items [R0, R1) of the frame load: x[4i .. 4i+3] for the level-2 element i; the last element
+// (i = 5512) pairs the level-1 samples (11024, 11023), i.e. x[22048], x[22049], x[22046],
+// x[22047].  No branches: every load is issued before the first use.
+template <int R0, int R1>
+__device__ __forceinline__ void load_items(const float* xb, int tid, float2 (&lo)[kLoadItems],
+                                           float2 (&hi)[kLoadItems]) {
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        int i = r * kThreads + tid;
+        i = i < kLen[2] ? i : 0;
+        const int at = (i == kLen[2] - 1) ? kN - 4 : 4 * i;
+        // frames start 8-byte aligned (22050 * 4 bytes per frame): float2 loads
+        lo[r] = *reinterpret_cast<const float2*>(xb + at);
+        hi[r] = *reinterpret_cast<const float2*>(xb + at + 2);
+    }
+}
+
+// ... and their element i of the level-2 nodes 2h, 2h + 1 (h = level-1 half: 0 low-pass,
+// 1 high-pass)
+template <int R0, int R1>
+__device__ __forceinline__ void level2_items(const float2 (&lo)[kLoadItems], const float2 (&hi)[kLoadItems],
+                                             int tid, int h, float2 (&g)[kLoadItems]) {
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        const bool tail = r * kThreads + tid == kLen[2] - 1;
+        const float4 v = tail ? make_float4(hi[r].x, hi[r].y, lo[r].x, lo[r].y)
+                              : make_float4(lo[r].x, lo[r].y, hi[r].x, hi[r].y);
+        const float4 f = butterfly4(v, false);
+        g[r] = h ? make_float2(f.z, f.w) : make_float2(f.x, f.y);
+    }
+}
+
+__device__ __forceinline__ void write_level2(float* buf, int tid, const float2 (&g)[kLoadItems]) {
+#pragma unroll
+    for (int r = 0; r < kLoadItems; ++r) {
+        const int i = r * kThreads + tid;
+        if (i < kLen[2]) {
+            buf[i] = g[r].x;
+            buf[kCap2 + i] = g[r].y;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) wpt_haar14_kernel(const HaarParams p) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    const float* xb = p.x + (size_t)b * kN;
     const bool sign_ch = p.flags & AFD_WPT_SIGN;
     const size_t P = 16384;
-    float* outb = p.out + (size_t)b * (sign_ch ? 2 : 1) * 2 * P;
+    const size_t frame_out = (size_t)(sign_ch ? 2 : 1) * 2 * P;
 
-    for (int quarter = 0; quarter < 4; ++quarter) {
-        // frequency index `quarter` at level 2 -> filters: Gray code, MSB = level 1, 1 = detail
-        const int g = quarter ^ (quarter >> 1);
-        const float s1 = (g & 2) ? -1.f : 1.f;  // level-1 filter sign
-        const float s2 = (g & 1) ? -1.f : 1.f;  // level-2 filter sign
-        // ---- levels 1-2 from global: element i <- x[4i..4i+3]; last element by reflect ----
-        // 8 float4-equivalents in flight per thread before the first LDS store (a load -> store
-        // chain would pay one L2 latency per element)
-        for (int base = 0; base < kLen[2]; base += kThreads * 8) {
-            float2 lo[8], hi[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = base + r * kThreads + tid;
-                if (i < kLen[2] - 1) {
-                    // frames start 8-byte aligned (22050 * 4 bytes per frame): two float2 loads
-                    lo[r] = *reinterpret_cast<const float2*>(xb + 4 * i);
-                    hi[r] = *reinterpret_cast<const float2*>(xb + 4 * i + 2);
-                } else {
-                    // level-1 node has 11025 samples (odd): pair (l1[11024], l1[11023])
-                    lo[r] = *reinterpret_cast<const float2*>(xb + 22048);
-                    hi[r] = *reinterpret_cast<const float2*>(xb + 22046);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int i = base + r * kThreads + tid;
-                if (i < kLen[2]) bufA[i] = (lo[r].x + s1 * lo[r].y) + s2 * (hi[r].x + s1 * hi[r].y);
-            }
-        }
-        __syncthreads();
-        // ---- levels 3-8 in LDS: M parents of n_in samples in slots of capIn ----
-        float* src = bufA;
-        float* dst = bufB;
-        int Fb = quarter;
-#pragma unroll 1
-        for (int lev = 3; lev <= 8; ++lev) {
-            const int M = 1 << (lev - 3);
-            const int n_in = kLen[lev - 1], n_out = kLen[lev];
-            const int capIn = kCap[lev - 1], capOut = kCap[lev];
-            const int total = M * n_out;
-            const float inv_nout = 1.0f / (float)n_out;
-            for (int w = tid; w < total; w += kThreads) {
-                int q = (int)((float)w * inv_nout);  // w / n_out through the reciprocal + fix-up
-                int i = w - q * n_out;
-                if (i < 0) { i += n_out; --q; } else if (i >= n_out) { i -= n_out; ++q; }
-                const float* nd = src + q * capIn;
-                float x0, x1;
-                if (2 * i + 1 < n_in) {
-                    const float2 v = *reinterpret_cast<const float2*>(nd + 2 * i);
-                    x0 = v.x;
-                    x1 = v.y;
-                } else {
-                    x0 = nd[2 * i];
-                    x1 = nd[2 * i - 1];
-                }
-                const int par = (Fb + q) & 1;
-                dst[(2 * q + par) * capOut + i] = x0 + x1;
-                dst[(2 * q + 1 - par) * capOut + i] = x0 - x1;
-            }
-            __syncthreads();
-            float* t = src;
-            src = dst;
-            dst = t;
-            Fb *= 2;
-        }
-        // src: 64 level-8 nodes (87 samples, slot 88), frequency order; Fb = quarter * 64
-        // ---- levels 9-14 in registers: thread = level-10 node (256 per quarter).  The two
-        // threads of a level-9 node both form its 44 samples from the level-8 parent (cheaper
-        // than leaving half the workgroup idle), then take one level-10 child each.
+    // Workgroups w and w + 8 sit on the same XCD (round-robin dispatch): they take the two
+    // halves of the same frames, so the second read of a frame is an L2 hit.
+    const int w = blockIdx.x;
+    const int half = (w >> 3) & 1;
+    const int fstride = gridDim.x >> 1;
+    int b = ((w >> 4) << 3) | (w & 7);
+    if (b >= p.B) return;
+    {
+        float2 lo[kLoadItems], hi[kLoadItems], g[kLoadItems];
+        load_items<0, kLoadItems>(p.x + (size_t)b * kN, tid, lo, hi);
+        level2_items<0, kLoadItems>(lo, hi, tid, half, g);
+        write_level2(buf, tid, g);
+    }
+    __syncthreads();
+    for (; b < p.B; b += fstride) {
+        // opaque copy of the thread index: keeps the per-item index arithmetic of the passes
+        // inside the loop (hoisted out, it would pin ~100 registers across the whole frame)
+        int lt = tid;
+        asm volatile("" : "+v"(lt));
+        // next frame's samples: a third of them in flight during each LDS pass (all at once
+        // would hold 44 registers across a pass)
+        const int nb = b + fstride;
+        const float* xn = p.x + (size_t)(nb < p.B ? nb : b) * kN;
+        float2 lo[kLoadItems], hi[kLoadItems], nxt[kLoadItems];
+        load_items<0, 4>(xn, lt, lo, hi);
+        lds_pass<2>(buf, lt);
+        level2_items<0, 4>(lo, hi, lt, half, nxt);
+        load_items<4, 8>(xn, lt, lo, hi);
+        lds_pass<4>(buf, lt);
+        level2_items<4, 8>(lo, hi, lt, half, nxt);
+        load_items<8, kLoadItems>(xn, lt, lo, hi);
+        lds_pass<6>(buf, lt);
+        level2_items<8, kLoadItems>(lo, hi, lt, half, nxt);
+        // ---- levels 9-10: thread = level-10 node `tid`; its level-8 grandparent is shared by
+        // four threads, each forms the level-9 node it needs (44 samples) ----
+        float v10[22];
         {
-            const int q8 = tid >> 2;
-            const int c9 = (tid >> 1) & 1;
-            const int c10 = tid & 1;
-            const int F8 = Fb + q8;
-            const float sg9 = ((c9 ^ (F8 & 1)) != 0) ? -1.f : 1.f;
-            const float* nd = src + q8 * kCap[8];
-            float v9[44];
+            const int q8 = lt >> 2;
+            const int F9 = lt >> 1;
+            const float sg9 = ((F9 ^ q8) & 1) ? -1.f : 1.f;
+            const float sg10 = ((lt ^ F9) & 1) ? -1.f : 1.f;
+            const float* nd = buf + q8 * 88;
+            // two halves, so that at most 11 float4 reads are in flight beside `nxt`
 #pragma unroll
-            for (int i = 0; i < 43; ++i) {
-                const float2 xv = *reinterpret_cast<const float2*>(nd + 2 * i);
-                v9[i] = xv.x + sg9 * xv.y;
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const int i = 11 * h + k;
+                    // 87 samples: level-9 element 43 is the reflected pair (86, 85)
+                    const float4 xv = fix_tail<87>(*reinterpret_cast<const float4*>(nd + 4 * i),
+                                                   make_float2(0.f, 0.f), i == 21);
+                    v10[i] = fmaf(sg10, fmaf(sg9, xv.w, xv.z), fmaf(sg9, xv.y, xv.x));
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            v9[43] = nd[86] + sg9 * nd[85];  // 87 samples: the last pair reflects
-            const int F9 = 2 * q8 + c9;  // local to the quarter; parity = global parity
-            const float sg10 = ((c10 ^ (F9 & 1)) != 0) ? -1.f : 1.f;
-            float v10[22];
-#pragma unroll
-            for (int i = 0; i < 22; ++i) v10[i] = v9[2 * i] + sg10 * v9[2 * i + 1];
-            Sub<22>::run(v10, 2 * F9 + c10, leaves);
         }
         __syncthreads();
-        // ---- coalesced store of the quarter: rows t = 0, 1, packets [quarter*4096, +4096) ----
-        for (int e = tid; e < 2 * 1024; e += kThreads) {
-            const int t = e >> 10;
-            const int c4 = e & 1023;
-            const float4 v = *reinterpret_cast<const float4*>(leaves + t * 4096 + 4 * c4);
-            float4 r;
-            r.x = haar_epilogue(v.x, p);
-            r.y = haar_epilogue(v.y, p);
-            r.z = haar_epilogue(v.z, p);
-            r.w = haar_epilogue(v.w, p);
-            float* o = outb + (size_t)t * P + quarter * 4096 + 4 * c4;
-            *reinterpret_cast<float4*>(o) = r;
-            if (sign_ch) {
-                float4 sgn;
-                sgn.x = v.x < 0.f ? -1.f : 1.f;
-                sgn.y = v.y < 0.f ? -1.f : 1.f;
-                sgn.z = v.z < 0.f ? -1.f : 1.f;
-                sgn.w = v.w < 0.f ? -1.f : 1.f;
-                if (p.flags & AFD_WPT_NORM) {
-                    sgn.x = (sgn.x - p.mean) * p.inv_std;
-                    sgn.y = (sgn.y - p.mean) * p.inv_std;
-                    sgn.z = (sgn.z - p.mean) * p.inv_std;
-                    sgn.w = (sgn.w - p.mean) * p.inv_std;
+        // the LDS image is free again: level 2 of the next frame goes in now
+        if (nb < p.B) write_level2(buf, lt, nxt);
+        // ---- levels 11-14 in registers, then the thread's 2 x 16 outputs ----
+        float out[2][16];
+        Sub<22, 0>::run(v10, (lt & 1) ? -1.f : 1.f, out);
+        // A thread's 16 packets of one time row are one 64-byte segment.  Transpose 4 x 4
+        // float4 inside each lane quad, so that a store instruction has the quad write one
+        // whole segment (thread 4m+k's row) instead of four quarter segments.
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            quad_transpose(out[t], lt);
+        }
+        float* ob = p.out + (size_t)b * frame_out + 8192 * half + 16 * (lt & ~3) + 4 * (lt & 3);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float4 r;
+                r.x = haar_epilogue(out[t][4 * k], p);
+                r.y = haar_epilogue(out[t][4 * k + 1], p);
+                r.z = haar_epilogue(out[t][4 * k + 2], p);
+                r.w = haar_epilogue(out[t][4 * k + 3], p);
+                *reinterpret_cast<float4*>(ob + (size_t)t * P + 16 * k) = r;
+            }
+        }
+        if (sign_ch) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float4 sgn;
+                    sgn.x = out[t][4 * k] < 0.f ? -1.f : 1.f;
+                    sgn.y = out[t][4 * k + 1] < 0.f ? -1.f : 1.f;
+                    sgn.z = out[t][4 * k + 2] < 0.f ? -1.f : 1.f;
+                    sgn.w = out[t][4 * k + 3] < 0.f ? -1.f : 1.f;
+                    if (p.flags & AFD_WPT_NORM) {
+                        sgn.x = (sgn.x - p.mean) * p.inv_std;
+                        sgn.y = (sgn.y - p.mean) * p.inv_std;
+                        sgn.z = (sgn.z - p.mean) * p.inv_std;
+                        sgn.w = (sgn.w - p.mean) * p.inv_std;
+                    }
+                    *reinterpret_cast<float4*>(ob + (size_t)(2 + t) * P + 16 * k) = sgn;
                 }
-                *reinterpret_cast<float4*>(o + 2 * P) = sgn;
             }
         }
         __syncthreads();
@@ -216,6 +333,17 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     if (L != 2 || level != 14 || N != kN || power != 2.0f) return 1;
     const float s = 0.70710678118654752f;
     if (fabsf(dec_lo[0] - s) > 1e-6f || fabsf(dec_lo[1] - s) > 1e-6f) return 1;
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt_haar14_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFloats * 4);
+        int dev = 0;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        int cus = 0;
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt haar: %s", hipGetErrorString(e));
+        n_cu = cus > 0 ? cus : 256;
+    }
     HaarParams p{};
     p.x = x;
     p.out = out;
@@ -226,7 +354,12 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     p.inv_std = (float)(1.0 / (double)(std == 0.f ? 1.f : std));
     p.scale = 1.0f / 128.0f;  // (1/sqrt 2)^14
     afd::ScopedTiming timing(AFD_K_WPT, 4.0 * B * ((double)N + ((flags & AFD_WPT_SIGN) ? 2.0 : 1.0) * 32768.0), stream);
-    hipLaunchKernelGGL(wpt_haar14_kernel, dim3(B), dim3(kThreads), 0, stream, p);
+    // two workgroups (frame halves) per CU, 16 per XCD pair up on a frame; the grid is a
+    // multiple of 16 so that every workgroup has its partner
+    int pairs = B < n_cu ? B : n_cu;
+    pairs = (pairs + 7) / 8 * 8;
+    const int grid = 2 * pairs;
+    hipLaunchKernelGGL(wpt_haar14_kernel, dim3(grid), dim3(kThreads), (size_t)kLdsFloats * 4, stream, p);
     return afd::check_launch("wpt_haar14_kernel");
 }
 
