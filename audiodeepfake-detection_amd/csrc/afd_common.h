@@ -40,6 +40,17 @@ struct ScopedTiming {
     }
 };
 
+// dilconv.hip: direct small-channel convolutions of the dilated stack (C = Cin = Cout <= 4)
+bool dilconv_applicable(int Cin, int Cout, int K, int dil);
+size_t dilconv_workspace_bytes(int C, int K);
+int dilconv_forward(const float* x, const float* w, const float* bias, float* y, int N, int C, int H,
+                    int W, int K, int pad, int dil, hipStream_t s);
+int dilconv_backward_data(const float* dy, const float* w, float* dx, int N, int C, int H, int W,
+                          int K, int pad, int dil, hipStream_t s);
+int dilconv_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int N, int C,
+                            int H, int W, int K, int pad, int dil, void* ws, size_t ws_bytes,
+                            hipStream_t s);
+
 constexpr int kWave = 64;
 constexpr int kLdsBytes = 160 * 1024;  // per-CU LDS on gfx950
 

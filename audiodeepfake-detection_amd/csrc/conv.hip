@@ -871,6 +871,10 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(wgrad_ws_floats(wg) * 4);
         if (b > need) need = b;
     }
+    if (afd::dilconv_applicable(Cin, Cout, K, dil)) {
+        const size_t b = align_up(afd::dilconv_workspace_bytes(Cin, K));
+        if (b > need) need = b;
+    }
     return need;
 }
 
@@ -890,6 +894,8 @@ extern "C" int afd_conv2d_forward(const float* x, const float* w, const float* b
                                   void* ws, size_t ws_bytes, afd_stream_t stream) {
     int rc = check_conv_args(x, w, y, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
+    if (afd::dilconv_applicable(Cin, Cout, K, dil))
+        return afd::dilconv_forward(x, w, bias, y, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     ConvGeom g;
@@ -912,6 +918,8 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
     int rc = check_conv_args(dy, w, dx, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
     if (Cin > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "conv dgrad: Cin %d > 128", Cin);
+    if (afd::dilconv_applicable(Cin, Cout, K, dil))
+        return afd::dilconv_backward_data(dy, w, dx, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     const int padd = dil * (K - 1) - pad;
@@ -935,6 +943,9 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
                                           int dil, void* ws, size_t ws_bytes, afd_stream_t stream) {
     int rc = check_conv_args(x, dy, dw, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
+    if (afd::dilconv_applicable(Cin, Cout, K, dil))
+        return afd::dilconv_backward_weight(x, dy, dw, dbias, N, Cin, H, W, K, pad, dil, ws, ws_bytes,
+                                            static_cast<hipStream_t>(stream));
     WgradGeom wg;
     rc = plan_wgrad(wg, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;

@@ -43,6 +43,7 @@ int afd_version(void);
 #define AFD_K_CONV_IGEMM 1 /* forward and backward-data launches of the implicit-GEMM kernel */
 #define AFD_K_CONV_WGRAD 2
 #define AFD_K_STFT 3
+#define AFD_K_CONV_DIRECT 4 /* small-channel direct convolutions (dilated stack at time_dim <= 4) */
 int afd_timing_enable(int on);
 int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work);
 int afd_timing_reset(void);

@@ -40,6 +40,13 @@ CONV_CASES = [
     (1, 64, 6, 2050, 96, 3, 1, 1),
     (1, 3, 64, 1100, 3, 7, 2, 4),
     (1, 3, 64, 1030, 3, 5, 2, 2),
+    # few-channel dilated stack (time_dim = 3 at level 14): direct VALU kernels, dilconv.hip
+    (2, 3, 64, 300, 3, 3, 1, 1),
+    (1, 3, 60, 2044, 3, 7, 2, 4),
+    (2, 4, 61, 259, 4, 7, 2, 4),
+    (2, 1, 40, 70, 1, 5, 2, 2),
+    (3, 2, 33, 513, 2, 7, 2, 4),
+    (2, 4, 30, 64, 4, 3, 1, 1),
     # LCNN shapes (models.py:85-110)
     (2, 1, 101, 256, 64, 5, 2, 1),
     (2, 48, 25, 64, 128, 3, 1, 1),
