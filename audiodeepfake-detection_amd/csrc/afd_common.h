@@ -51,6 +51,17 @@ int dilconv_backward_weight(const float* x, const float* dy, float* dw, float* d
                             int H, int W, int K, int pad, int dil, void* ws, size_t ws_bytes,
                             hipStream_t s);
 
+// conv1x1.hip: 1x1 convolutions as GEMMs over flattened pixels
+bool conv1x1_applicable(int Cin, int Cout, int K, int pad, int dil);
+bool conv1x1_wgrad_applicable(int Cin, int Cout);
+size_t conv1x1_workspace_bytes(int Cin, int Cout);
+int conv1x1_forward(const float* x, const float* w, const float* bias, float* y, int N, int Cin,
+                    int Cout, long HW, hipStream_t s);
+int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout,
+                          long HW, hipStream_t s);
+int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin,
+                            int Cout, long HW, void* ws, size_t ws_bytes, hipStream_t s);
+
 constexpr int kWave = 64;
 constexpr int kLdsBytes = 160 * 1024;  // per-CU LDS on gfx950
 

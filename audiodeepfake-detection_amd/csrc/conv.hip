@@ -875,6 +875,10 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(afd::dilconv_workspace_bytes(Cin, K));
         if (b > need) need = b;
     }
+    if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil) && afd::conv1x1_wgrad_applicable(Cin, Cout)) {
+        const size_t b = align_up(afd::conv1x1_workspace_bytes(Cin, Cout));
+        if (b > need) need = b;
+    }
     return need;
 }
 
@@ -896,6 +900,8 @@ extern "C" int afd_conv2d_forward(const float* x, const float* w, const float* b
     if (rc) return rc;
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_forward(x, w, bias, y, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
+    if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
+        return afd::conv1x1_forward(x, w, bias, y, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     ConvGeom g;
@@ -920,6 +926,8 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
     if (Cin > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "conv dgrad: Cin %d > 128", Cin);
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_backward_data(dy, w, dx, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
+    if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
+        return afd::conv1x1_backward_data(dy, w, dx, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     const int padd = dil * (K - 1) - pad;
@@ -945,6 +953,9 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
     if (rc) return rc;
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_backward_weight(x, dy, dw, dbias, N, Cin, H, W, K, pad, dil, ws, ws_bytes,
+                                            static_cast<hipStream_t>(stream));
+    if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil) && afd::conv1x1_wgrad_applicable(Cin, Cout))
+        return afd::conv1x1_backward_weight(x, dy, dw, dbias, N, Cin, Cout, (long)H * W, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
     WgradGeom wg;
     rc = plan_wgrad(wg, N, Cin, H, W, Cout, K, pad, dil);

@@ -47,6 +47,12 @@ CONV_CASES = [
     (2, 1, 40, 70, 1, 5, 2, 2),
     (3, 2, 33, 513, 2, 7, 2, 4),
     (2, 4, 30, 64, 4, 3, 1, 1),
+    # 1x1 layers: streaming GEMM kernels, conv1x1.hip (ragged pixel tiles, padded channels)
+    (2, 32, 13, 300, 64, 1, 0, 1),
+    (2, 48, 7, 65, 96, 1, 0, 1),
+    (2, 128, 5, 33, 128, 1, 0, 1),
+    (3, 20, 9, 50, 40, 1, 0, 1),
+    (1, 64, 13, 1031, 64, 1, 0, 1),
     # LCNN shapes (models.py:85-110)
     (2, 1, 101, 256, 64, 5, 2, 1),
     (2, 48, 25, 64, 128, 3, 1, 1),
