@@ -847,6 +847,347 @@ int launch_wgrad_t(const WgradGeom& wg, const float* x, const float* dz, float* 
     return afd::check_launch("conv_wgrad_kernel");
 }
 
+// ---------------------------------------------------------------------------------------
+// backward-weight, second generation: producer / consumer waves and a double-buffered LDS
+// image.  Waves 0-3 (one per SIMD) only issue MFMAs: the (channel tile, column tile) pairs of
+// the chunk are dealt to them, TPW per wave.  Waves 4-7 only move data: while tile t is in
+// the MFMAs they stage tile t+1 (dz rows, input patch with zero halo, pixel offsets) into the
+// other buffer and keep the bias sums.  One barrier per tile; the loaders' address arithmetic
+// and memory latency run in the issue slots the 64-cycle MFMAs leave free.
+// ---------------------------------------------------------------------------------------
+constexpr int kW2Threads = 512;
+constexpr int kW2Loaders = 256;
+constexpr int kW2MaxTpw = 7;
+constexpr int kW2MaxDz = 8;      // dz groups of 4 pixels per loader thread (CO_PAD * 16 / 256)
+constexpr int kW2MaxPatch = 14;  // patch groups of 4 columns per loader thread
+
+struct Wgrad2Geom {
+    WgradGeom w;   // c, MT, NTILES, NCOL, S, PIXP, totalTiles as in the first generation
+    int PAIRS;     // MT * NTILES
+    int TPW;       // pairs per MFMA wave
+    int bufFloats; // one LDS buffer: dz [CO_PAD][PIXP] | patch | pixoff [PIX + 8]
+    int nDz;       // dz rows staged per loader thread = CO_PAD / 4
+    int nPatch;    // patch elements staged per loader thread
+};
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// loader side (RECT tiles: 64 consecutive pixels of one output row): tile -> LDS buffer.
+// Work items are groups of four consecutive floats (one dwordx4 load; rows start at any
+// 4-byte address); a group that crosses the image border falls back to four predicated
+// loads.  Every global load of the tile is issued before the first LDS store: the loaders
+// have one MFMA loop (a few microseconds) per tile, two HBM round trips do not fit in it.
+// bsl [CO_PAD][16] (LDS, one cell per group) accumulates dz for the bias gradient.
+__device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float* __restrict__ x,
+                                              const float* __restrict__ dz, long tile, int chunk,
+                                              int ltid, float* buf, float* bsl) {
+    // opaque thread index: keeps the per-item (channel, row, column) arithmetic inside the
+    // tile loop (hoisted out of it, it would pin several registers per staged item)
+    asm volatile("" : "+v"(ltid));
+    const WgradGeom& wg = w2.w;
+    const ConvGeom& g = wg.c;
+    const int tpi = g.tilesX * g.tilesY;
+    const size_t iplane = (size_t)g.H * g.W;
+    const size_t oplane = (size_t)g.Hout * g.Wout;
+    const int n = (int)(tile / tpi);
+    const int t = (int)(tile - (long)n * tpi);
+    int oy0, ox0, p0;
+    tile_origin(g, t, oy0, ox0, p0);
+    const int dzFloats = g.CO_PAD * wg.PIXP;
+    int* pixoff = reinterpret_cast<int*>(buf + dzFloats + g.patchFloats);
+    if (ltid < g.PIX + 8) pixoff[ltid] = (ltid < g.PIX && ox0 + ltid < g.Wout) ? ltid : 0;
+
+    const float* dzn = dz + (size_t)n * g.Cout * oplane + (size_t)oy0 * g.Wout + ox0;
+    const float* xn = x + ((size_t)n * g.Cin + (size_t)chunk * g.CI_T) * iplane;
+    const int iy0 = oy0 - g.pad, ix0 = ox0 - g.pad;
+    const int cin_left = g.Cin - chunk * g.CI_T;
+    const int G = g.PC >> 2;  // groups per patch row (PC is a multiple of 4 here)
+    const int pitems = g.CI_T * g.PR * G;
+    const float invG = 1.0f / (float)G;
+    const float invPR = 1.0f / (float)g.PR;
+    float* patch = buf + dzFloats;
+
+    f32x4u dv[kW2MaxDz], pv[kW2MaxPatch];
+#pragma unroll
+    for (int u = 0; u < kW2MaxDz; ++u) {
+        f32x4u v = {0.f, 0.f, 0.f, 0.f};
+        if (u < w2.nDz) {
+            const int item = ltid + u * kW2Loaders;
+            const int co = item >> 4, px = (item & 15) << 2;
+            if (co < g.Cout) {
+                const float* src = dzn + (size_t)co * oplane + px;
+                if (ox0 + px + 3 < g.Wout) {
+                    v = *reinterpret_cast<const f32x4u*>(src);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ox0 + px + j < g.Wout) v[j] = src[j];
+                }
+            }
+        }
+        dv[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < kW2MaxPatch; ++u) {
+        f32x4u v = {0.f, 0.f, 0.f, 0.f};
+        if (u < w2.nPatch) {
+            const int item = ltid + u * kW2Loaders;
+            int row, g4, ci_l, pr;
+            divmod_small(item, G, invG, row, g4);
+            divmod_small(row, g.PR, invPR, ci_l, pr);
+            const int iy = iy0 + pr, ix = ix0 + 4 * g4;
+            if (item < pitems && ci_l < cin_left && iy >= 0 && iy < g.H) {
+                const float* src = xn + (size_t)ci_l * iplane + (size_t)iy * g.W + ix;
+                if (ix >= 0 && ix + 3 < g.W) {
+                    v = *reinterpret_cast<const f32x4u*>(src);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ix + j >= 0 && ix + j < g.W) v[j] = src[j];
+                }
+            }
+        }
+        pv[u] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < kW2MaxDz; ++u) {
+        if (u < w2.nDz) {
+            const int item = ltid + u * kW2Loaders;
+            const int co = item >> 4, px = (item & 15) << 2;
+            float* d = buf + co * wg.PIXP + px;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = dv[u][j];
+            if (bsl) bsl[item] += (dv[u][0] + dv[u][1]) + (dv[u][2] + dv[u][3]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < kW2MaxPatch; ++u) {
+        const int item = ltid + u * kW2Loaders;
+        if (u < w2.nPatch && item < pitems) *reinterpret_cast<float4*>(patch + 4 * item) = make_float4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+    }
+}
+
+template <int TPW>
+__global__ void __launch_bounds__(kW2Threads)
+conv_wgrad2_kernel(const Wgrad2Geom w2, const float* __restrict__ x, const float* __restrict__ dz,
+                   float* __restrict__ part, float* __restrict__ partb) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const WgradGeom& wg = w2.w;
+    const ConvGeom& g = wg.c;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const bool loader = wave >= 4;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+    const int chunk = blockIdx.y;
+    const int split = blockIdx.x;
+    const int KK = g.K * g.K;
+    const int dzFloats = g.CO_PAD * wg.PIXP;
+
+    int aoff[TPW], joff[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int p = (wave & 3) * TPW + q;
+        const int pp = p < w2.PAIRS ? p : 0;
+        const int m = pp / wg.NTILES, nt = pp - m * wg.NTILES;
+        aoff[q] = (m * 32 + l31) * wg.PIXP;
+        const int c = nt * 32 + l31;
+        int o = 0;
+        if (c < g.CI_T * KK) {
+            const int ci_l = c / KK;
+            const int r = c - ci_l * KK;
+            const int ky = r / g.K;
+            const int kx = r - ky * g.K;
+            o = ci_l * g.PR * g.PC + ky * g.dil * g.PC + kx * g.dil;
+        }
+        joff[q] = dzFloats + o;  // the patch follows the dz rows inside a buffer
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    float* bsl = chunk == 0 ? smem + 2 * w2.bufFloats : nullptr;
+    if (bsl)
+        for (int i = tid; i < g.CO_PAD * 16; i += kW2Threads) bsl[i] = 0.f;
+    __syncthreads();
+
+    long tile = split;
+    int cur = 0;
+    if (loader && tile < wg.totalTiles) w2_stage_tile(w2, x, dz, tile, chunk, tid - 256, smem, bsl);
+    __syncthreads();
+    for (; tile < wg.totalTiles; tile += wg.S) {
+        if (loader) {
+            const long tnext = tile + wg.S;
+            if (tnext < wg.totalTiles)
+                w2_stage_tile(w2, x, dz, tnext, chunk, tid - 256, smem + (cur ^ 1) * w2.bufFloats, bsl);
+        } else {
+            const float* buf = smem + cur * w2.bufFloats;
+            const int* pixoff = reinterpret_cast<const int*>(buf + dzFloats + g.patchFloats);
+            const int ksteps = g.PIX >> 1;  // 32
+            // Two-deep software pipeline with ping-pong fragment registers (see the first
+            // generation); pixoff is padded and rows have slack, so the tail prefetch reads
+            // in-bounds garbage.
+            float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
+            {
+                const int po0 = pixoff[half];
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    a0[q] = buf[aoff[q] + half];
+                    b0[q] = buf[joff[q] + po0];
+                }
+            }
+            int pon = pixoff[2 + half];
+            for (int ks = 0; ks < ksteps; ks += 2) {
+                const int k1 = 2 * ks + 2 + half;
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    a1[q] = buf[aoff[q] + k1];
+                    b1[q] = buf[joff[q] + pon];
+                }
+                const int ponn = pixoff[k1 + 2];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < TPW; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int k2 = k1 + 2;
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    a0[q] = buf[aoff[q] + k2];
+                    b0[q] = buf[joff[q] + ponn];
+                }
+                pon = pixoff[k2 + 2];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < TPW; ++q)
+                    acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[q], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (!loader) {
+        float* slab = part + ((size_t)split * gridDim.y + chunk) * g.CO_PAD * wg.NCOL;
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            const int p = wave * TPW + q;
+            if (p >= w2.PAIRS) continue;
+            const int m = p / wg.NTILES, nt = p - m * wg.NTILES;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                slab[(size_t)co * wg.NCOL + nt * 32 + l31] = acc[q][r];
+            }
+        }
+    } else if (chunk == 0) {
+        // bias gradient: row (wave - 4) + 4u, summed over the 64 pixel lanes
+        // bias gradient: 16 group cells per row, summed in a fixed order
+        const int co = tid - 256;
+        if (co < g.CO_PAD) {
+            float v = 0.f;
+            for (int j = 0; j < 16; ++j) v += bsl[co * 16 + j];
+            partb[(size_t)split * g.CO_PAD + co] = v;
+        }
+    }
+}
+
+int plan_wgrad2(Wgrad2Geom& w2, int N, int Cin, int H, int W, int Cout, int K, int pad, int dil) {
+    WgradGeom& wg = w2.w;
+    ConvGeom& g = wg.c;
+    const int Hout = H + 2 * pad - dil * (K - 1);
+    const int Wout = W + 2 * pad - dil * (K - 1);
+    const int pix = 64;
+    g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.K = K; g.pad = pad; g.dil = dil;
+    g.Hout = Hout; g.Wout = Wout; g.PIX = pix;
+    g.CO_PAD = ((Cout + 31) / 32) * 32;
+    if (g.CO_PAD > 128) return AFD_ERR_UNSUPPORTED;
+    const int KK = K * K;
+    wg.PIXP = pix + 1;
+    wg.MT = g.CO_PAD / 32;
+    wg.NG = 0;
+    wg.fast_stage = 0;
+    w2.nDz = g.CO_PAD / 16;  // groups of 4 pixels per loader thread
+    int best_ct = 0;
+    double best_eff = 0.0;
+    // RECT tiles only (one output row, 64 consecutive pixels): the vectorised loader relies on
+    // it; narrow images stay on the first-generation kernel
+    if (Wout < 4 * pix) return AFD_ERR_UNSUPPORTED;
+    set_tiling(g, pix, true);
+    g.PC = (g.PC + 3) & ~3;  // whole groups of four columns per patch row
+    for (int ct = 1; ct <= Cin && ct <= 128; ++ct) {
+        const int ntiles = (ct * KK + 31) / 32;
+        const int pairs = wg.MT * ntiles;
+        const int tpw = (pairs + 3) / 4;
+        if (tpw > kW2MaxTpw) break;
+        const long patch = (long)ct * g.PR * g.PC;
+        const long buf = (long)g.CO_PAD * wg.PIXP + patch + pix + 8;
+        if ((2 * buf + (long)g.CO_PAD * 16) * 4 > 156 * 1024) break;
+        if ((patch / 4 + kW2Loaders - 1) / kW2Loaders > kW2MaxPatch) break;
+        const int nchunks = (Cin + ct - 1) / ct;
+        // useful MFMA slots / issued slots, over all chunks (padded channels and columns)
+        const double eff = ((double)Cin * KK / 32.0 * wg.MT) / ((double)nchunks * 4 * tpw);
+        if (eff > best_eff + 1e-9 || (eff > best_eff - 1e-9 && ct > best_ct)) {
+            best_eff = eff;
+            best_ct = ct;
+        }
+    }
+    if (best_ct == 0 || best_eff < 0.6) return AFD_ERR_UNSUPPORTED;
+    const int ct = best_ct;
+    g.CI_T = ct;
+    g.nchunks = (Cin + ct - 1) / ct;
+    g.CKP = 0;
+    g.patchFloats = ((ct * g.PR * g.PC + 3) / 4) * 4;
+    wg.NTILES = (ct * KK + 31) / 32;
+    wg.NCOL = wg.NTILES * 32;
+    w2.PAIRS = wg.MT * wg.NTILES;
+    w2.TPW = (w2.PAIRS + 3) / 4;
+    w2.bufFloats = g.CO_PAD * wg.PIXP + g.patchFloats + pix + 8;
+    w2.nPatch = (g.patchFloats / 4 + kW2Loaders - 1) / kW2Loaders;
+    wg.totalTiles = (long)N * g.tilesX * g.tilesY;
+    long S = 1024 / g.nchunks;
+    if (S < 1) S = 1;
+    if (S > wg.totalTiles) S = wg.totalTiles;
+    wg.S = (int)S;
+    return AFD_OK;
+}
+
+template <int TPW>
+int launch_wgrad2_t(const Wgrad2Geom& w2, const float* x, const float* dz, float* part, float* partb,
+                    hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<TPW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const ConvGeom& g = w2.w.c;
+    afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * g.N * g.Cout * (double)g.Hout * g.Wout * g.Cin * g.K * g.K, s);
+    hipLaunchKernelGGL(conv_wgrad2_kernel<TPW>, dim3(w2.w.S, g.nchunks), dim3(kW2Threads),
+                       ((size_t)2 * w2.bufFloats + (size_t)g.CO_PAD * 16) * 4, s, w2, x, dz, part, partb);
+    return afd::check_launch("conv_wgrad2_kernel");
+}
+
+int launch_wgrad2(const Wgrad2Geom& w2, const float* x, const float* dz, float* part, float* partb,
+                  hipStream_t s) {
+    switch (w2.TPW) {
+        case 1: return launch_wgrad2_t<1>(w2, x, dz, part, partb, s);
+        case 2: return launch_wgrad2_t<2>(w2, x, dz, part, partb, s);
+        case 3: return launch_wgrad2_t<3>(w2, x, dz, part, partb, s);
+        case 4: return launch_wgrad2_t<4>(w2, x, dz, part, partb, s);
+        case 5: return launch_wgrad2_t<5>(w2, x, dz, part, partb, s);
+        case 6: return launch_wgrad2_t<6>(w2, x, dz, part, partb, s);
+        case 7: return launch_wgrad2_t<7>(w2, x, dz, part, partb, s);
+    }
+    return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad: %d pairs per wave", w2.TPW);
+}
+
+bool use_wgrad2() { return getenv("AFD_WGRAD_V1") == nullptr; }
+
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -869,6 +1210,11 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
     WgradGeom wg;
     if (plan_wgrad(wg, N, Cin, H, W, Cout, K, pad, dil) == AFD_OK) {
         const size_t b = align_up(wgrad_ws_floats(wg) * 4);
+        if (b > need) need = b;
+    }
+    Wgrad2Geom w2;
+    if (plan_wgrad2(w2, N, Cin, H, W, Cout, K, pad, dil) == AFD_OK) {
+        const size_t b = align_up(wgrad_ws_floats(w2.w) * 4);
         if (b > need) need = b;
     }
     if (afd::dilconv_applicable(Cin, Cout, K, dil)) {
@@ -957,11 +1303,25 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil) && afd::conv1x1_wgrad_applicable(Cin, Cout))
         return afd::conv1x1_backward_weight(x, dy, dw, dbias, N, Cin, Cout, (long)H * W, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Wgrad2Geom w2;
+    if (use_wgrad2() && plan_wgrad2(w2, N, Cin, H, W, Cout, K, pad, dil) == AFD_OK) {
+        const WgradGeom& g2 = w2.w;
+        if (!ws || ws_bytes < wgrad_ws_floats(g2) * 4) return afd::fail(AFD_ERR_WORKSPACE, "conv wgrad: workspace too small");
+        float* part2 = static_cast<float*>(ws);
+        float* partb2 = part2 + (size_t)g2.S * g2.c.nchunks * g2.c.CO_PAD * g2.NCOL;
+        rc = launch_wgrad2(w2, x, dy, part2, partb2, s);
+        if (rc) return rc;
+        const int total2 = Cout * Cin * K * K;
+        const int nblk2 = (total2 + 31) / 32 + (dbias ? (Cout + 31) / 32 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk2), dim3(256), 0, s, part2, partb2, dw, dbias,
+                           Cin, Cout, K * K, g2.c.CI_T, g2.c.nchunks, g2.c.CO_PAD, g2.NCOL, g2.S);
+        return afd::check_launch("wgrad_reduce_kernel");
+    }
     WgradGeom wg;
     rc = plan_wgrad(wg, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
     if (!ws || ws_bytes < wgrad_ws_floats(wg) * 4) return afd::fail(AFD_ERR_WORKSPACE, "conv wgrad: workspace too small");
-    hipStream_t s = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
     float* partb = part + (size_t)wg.S * wg.c.nchunks * wg.c.CO_PAD * wg.NCOL;
     const int ntw = (wg.NTILES + wg.NG - 1) / wg.NG;
