@@ -868,6 +868,7 @@ struct Wgrad2Geom {
     int bufFloats; // one LDS buffer: dz [CO_PAD][PIXP] | patch | pixoff [PIX + 8]
     int nDz;       // dz rows staged per loader thread = CO_PAD / 4
     int nPatch;    // patch elements staged per loader thread
+    int dbg;       // development switches (AFD_W2_DBG): 1 no loader work, 2 no MFMA loop
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -880,7 +881,9 @@ typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 // bsl [CO_PAD][16] (LDS, one cell per group) accumulates dz for the bias gradient.
 __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float* __restrict__ x,
                                               const float* __restrict__ dz, long tile, int chunk,
-                                              int ltid, float* buf, float* bsl) {
+                                              int ltid, const unsigned (&dzo)[kW2MaxDz],
+                                              const unsigned (&xo)[kW2MaxPatch], float* buf,
+                                              float* bsl) {
     // opaque thread index: keeps the per-item (channel, row, column) arithmetic inside the
     // tile loop (hoisted out of it, it would pin several registers per staged item)
     asm volatile("" : "+v"(ltid));
@@ -894,8 +897,6 @@ __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float*
     int oy0, ox0, p0;
     tile_origin(g, t, oy0, ox0, p0);
     const int dzFloats = g.CO_PAD * wg.PIXP;
-    int* pixoff = reinterpret_cast<int*>(buf + dzFloats + g.patchFloats);
-    if (ltid < g.PIX + 8) pixoff[ltid] = (ltid < g.PIX && ox0 + ltid < g.Wout) ? ltid : 0;
 
     const float* dzn = dz + (size_t)n * g.Cout * oplane + (size_t)oy0 * g.Wout + ox0;
     const float* xn = x + ((size_t)n * g.Cin + (size_t)chunk * g.CI_T) * iplane;
@@ -908,6 +909,23 @@ __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float*
     float* patch = buf + dzFloats;
 
     f32x4u dv[kW2MaxDz], pv[kW2MaxPatch];
+    // Interior tile (the common case; the test is scalar): every item is one unpredicated
+    // dwordx4 load at a wave-uniform base plus this lane's constant offset -- two vector adds
+    // per load and nothing else.  The f32 MFMA runs on the vector ALU (MI355X_MICROARCH.md,
+    // "Matrix cores"): every VALU instruction of a loader wave is a cycle the MFMA wave of the
+    // same SIMD does not get, so the per-item index arithmetic below would not hide behind
+    // the matrix work, it would add to it.
+    const bool interior = ox0 + g.PIX <= g.Wout && ix0 >= 0 && ix0 + g.PC <= g.W && iy0 >= 0 &&
+                          iy0 + g.PR <= g.H && cin_left >= g.CI_T && !(w2.dbg & 16);
+    if (interior) {
+        const float* xb = xn + (size_t)iy0 * g.W + ix0;
+#pragma unroll
+        for (int u = 0; u < kW2MaxDz; ++u)
+            if (u < w2.nDz) dv[u] = *reinterpret_cast<const f32x4u*>(dzn + dzo[u]);
+#pragma unroll
+        for (int u = 0; u < kW2MaxPatch; ++u)
+            if (u < w2.nPatch) pv[u] = *reinterpret_cast<const f32x4u*>(xb + xo[u]);
+    } else {
 #pragma unroll
     for (int u = 0; u < kW2MaxDz; ++u) {
         f32x4u v = {0.f, 0.f, 0.f, 0.f};
@@ -926,6 +944,7 @@ __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float*
             }
         }
         dv[u] = v;
+        __builtin_amdgcn_sched_barrier(0);  // border tiles are rare: one item at a time, few live registers
     }
 #pragma unroll
     for (int u = 0; u < kW2MaxPatch; ++u) {
@@ -948,6 +967,8 @@ __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float*
             }
         }
         pv[u] = v;
+        __builtin_amdgcn_sched_barrier(0);
+    }
     }
 #pragma unroll
     for (int u = 0; u < kW2MaxDz; ++u) {
@@ -955,9 +976,10 @@ __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float*
             const int item = ltid + u * kW2Loaders;
             const int co = item >> 4, px = (item & 15) << 2;
             float* d = buf + co * wg.PIXP + px;
+            const bool live = co < g.Cout;  // padded channel rows stay zero (the interior path loads anything there)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = dv[u][j];
-            if (bsl) bsl[item] += (dv[u][0] + dv[u][1]) + (dv[u][2] + dv[u][3]);
+            for (int j = 0; j < 4; ++j) d[j] = live ? dv[u][j] : 0.f;
+            if (bsl && live) bsl[item] += (dv[u][0] + dv[u][1]) + (dv[u][2] + dv[u][3]);
         }
     }
 #pragma unroll
@@ -985,10 +1007,62 @@ conv_wgrad2_kernel(const Wgrad2Geom w2, const float* __restrict__ x, const float
     const int KK = g.K * g.K;
     const int dzFloats = g.CO_PAD * wg.PIXP;
 
+    float* bsl = chunk == 0 ? smem + 2 * w2.bufFloats : nullptr;
+    if (bsl)
+        for (int i = tid; i < g.CO_PAD * 16; i += kW2Threads) bsl[i] = 0.f;
+    __syncthreads();
+
+    // The two roles run separate tile loops with matching barrier counts (s_barrier counts
+    // waves, not program locations): neither role carries the other's registers.
+    const long ntiles = wg.totalTiles;
+    if (loader) {
+        const int ltid = tid - 256;
+        // this lane's element offsets inside an interior tile (constant over the tile loop)
+        unsigned dzo[kW2MaxDz], xo[kW2MaxPatch];
+        {
+            const int G = g.PC >> 2;
+            const int pitems = g.CI_T * g.PR * G;
+#pragma unroll
+            for (int u = 0; u < kW2MaxDz; ++u) {
+                const int item = ltid + u * kW2Loaders;
+                const int co = item >> 4, px = (item & 15) << 2;
+                dzo[u] = co < g.Cout ? (unsigned)co * (unsigned)(g.Hout * g.Wout) + px : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kW2MaxPatch; ++u) {
+                const int item = ltid + u * kW2Loaders;
+                const int row = item / G, g4 = item - row * G;
+                const int ci_l = row / g.PR, pr = row - ci_l * g.PR;
+                xo[u] = item < pitems ? (unsigned)ci_l * (unsigned)(g.H * g.W) + (unsigned)(pr * g.W + 4 * g4) : 0u;
+            }
+        }
+        long tile = split;
+        int cur = 0;
+        if (tile < ntiles) w2_stage_tile(w2, x, dz, tile, chunk, ltid, dzo, xo, smem, bsl);
+        __syncthreads();
+        for (; tile < ntiles; tile += wg.S) {
+            const long tnext = tile + wg.S;
+            if (tnext < ntiles && !(w2.dbg & 1))
+                w2_stage_tile(w2, x, dz, tnext, chunk, ltid, dzo, xo, smem + (cur ^ 1) * w2.bufFloats, bsl);
+            __syncthreads();
+            cur ^= 1;
+        }
+        if (chunk == 0) {
+            // bias gradient: 16 group cells per row, summed in a fixed order
+            const int co = ltid;
+            if (co < g.CO_PAD) {
+                float v = 0.f;
+                for (int j = 0; j < 16; ++j) v += bsl[co * 16 + j];
+                partb[(size_t)split * g.CO_PAD + co] = v;
+            }
+        }
+        return;
+    }
+
     int aoff[TPW], joff[TPW];
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
-        const int p = (wave & 3) * TPW + q;
+        const int p = wave * TPW + q;
         const int pp = p < w2.PAIRS ? p : 0;
         const int m = pp / wg.NTILES, nt = pp - m * wg.NTILES;
         aoff[q] = (m * 32 + l31) * wg.PIXP;
@@ -1008,61 +1082,61 @@ conv_wgrad2_kernel(const Wgrad2Geom w2, const float* __restrict__ x, const float
     for (int q = 0; q < TPW; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
-    float* bsl = chunk == 0 ? smem + 2 * w2.bufFloats : nullptr;
-    if (bsl)
-        for (int i = tid; i < g.CO_PAD * 16; i += kW2Threads) bsl[i] = 0.f;
-    __syncthreads();
-
-    long tile = split;
     int cur = 0;
-    if (loader && tile < wg.totalTiles) w2_stage_tile(w2, x, dz, tile, chunk, tid - 256, smem, bsl);
-    __syncthreads();
-    for (; tile < wg.totalTiles; tile += wg.S) {
-        if (loader) {
-            const long tnext = tile + wg.S;
-            if (tnext < wg.totalTiles)
-                w2_stage_tile(w2, x, dz, tnext, chunk, tid - 256, smem + (cur ^ 1) * w2.bufFloats, bsl);
-        } else {
+    __syncthreads();  // the first tile is staged
+    for (long tile = split; tile < ntiles; tile += wg.S) {
+        if (!(w2.dbg & 2)) {
             const float* buf = smem + cur * w2.bufFloats;
-            const int* pixoff = reinterpret_cast<const int*>(buf + dzFloats + g.patchFloats);
-            const int ksteps = g.PIX >> 1;  // 32
-            // Two-deep software pipeline with ping-pong fragment registers (see the first
-            // generation); pixoff is padded and rows have slack, so the tail prefetch reads
-            // in-bounds garbage.
-            float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
-            {
-                const int po0 = pixoff[half];
+            // RECT tile: pixel k of the tile sits k columns into the patch row, so every
+            // fragment address is a per-lane base plus a compile-time offset (pixels past
+            // the image edge read in-bounds patch columns against dz = 0).  Ping-pong
+            // fragment registers; the reads of step s+1 are spread between the MFMAs of
+            // step s (one MFMA, two LDS reads, ...) so that the matrix pipe neither waits
+            // for a block of reads to issue nor for their latency at the step boundary.
+            const float* ap[TPW];
+            const float* bp[TPW];
 #pragma unroll
-                for (int q = 0; q < TPW; ++q) {
-                    a0[q] = buf[aoff[q] + half];
-                    b0[q] = buf[joff[q] + po0];
-                }
+            for (int q = 0; q < TPW; ++q) {
+                ap[q] = buf + aoff[q] + half;
+                bp[q] = buf + joff[q] + half;
             }
-            int pon = pixoff[2 + half];
-            for (int ks = 0; ks < ksteps; ks += 2) {
-                const int k1 = 2 * ks + 2 + half;
+            float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                a0[q] = ap[q][0];
+                b0[q] = bp[q][0];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 32; ks += 2) {
 #pragma unroll
                 for (int q = 0; q < TPW; ++q) {
-                    a1[q] = buf[aoff[q] + k1];
-                    b1[q] = buf[joff[q] + pon];
+                    a1[q] = ap[q][2 * ks + 2];
+                    b1[q] = bp[q][2 * ks + 2];
                 }
-                const int ponn = pixoff[k1 + 2];
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < TPW; ++q)
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[q], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const int k2 = k1 + 2;
 #pragma unroll
                 for (int q = 0; q < TPW; ++q) {
-                    a0[q] = buf[aoff[q] + k2];
-                    b0[q] = buf[joff[q] + ponn];
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 }
-                pon = pixoff[k2 + 2];
                 __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 32) {
+#pragma unroll
+                    for (int q = 0; q < TPW; ++q) {
+                        a0[q] = ap[q][2 * ks + 4];
+                        b0[q] = bp[q][2 * ks + 4];
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < TPW; ++q)
                     acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -1070,27 +1144,16 @@ conv_wgrad2_kernel(const Wgrad2Geom w2, const float* __restrict__ x, const float
         cur ^= 1;
     }
 
-    if (!loader) {
-        float* slab = part + ((size_t)split * gridDim.y + chunk) * g.CO_PAD * wg.NCOL;
+    float* slab = part + ((size_t)split * gridDim.y + chunk) * g.CO_PAD * wg.NCOL;
 #pragma unroll
-        for (int q = 0; q < TPW; ++q) {
-            const int p = wave * TPW + q;
-            if (p >= w2.PAIRS) continue;
-            const int m = p / wg.NTILES, nt = p - m * wg.NTILES;
+    for (int q = 0; q < TPW; ++q) {
+        const int p = wave * TPW + q;
+        if (p >= w2.PAIRS) continue;
+        const int m = p / wg.NTILES, nt = p - m * wg.NTILES;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                slab[(size_t)co * wg.NCOL + nt * 32 + l31] = acc[q][r];
-            }
-        }
-    } else if (chunk == 0) {
-        // bias gradient: row (wave - 4) + 4u, summed over the 64 pixel lanes
-        // bias gradient: 16 group cells per row, summed in a fixed order
-        const int co = tid - 256;
-        if (co < g.CO_PAD) {
-            float v = 0.f;
-            for (int j = 0; j < 16; ++j) v += bsl[co * 16 + j];
-            partb[(size_t)split * g.CO_PAD + co] = v;
+        for (int r = 0; r < 16; ++r) {
+            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[(size_t)co * wg.NCOL + nt * 32 + l31] = acc[q][r];
         }
     }
 }
@@ -1152,6 +1215,9 @@ int plan_wgrad2(Wgrad2Geom& w2, int N, int Cin, int H, int W, int Cout, int K, i
     if (S < 1) S = 1;
     if (S > wg.totalTiles) S = wg.totalTiles;
     wg.S = (int)S;
+    if ((size_t)g.CO_PAD * Hout * Wout >= 0x7fffffffULL || (size_t)ct * H * W >= 0x7fffffffULL)
+        return AFD_ERR_UNSUPPORTED;  // 32-bit element offsets inside a tile
+    { const char* e = getenv("AFD_W2_DBG"); w2.dbg = e ? atoi(e) : 0; }
     return AFD_OK;
 }
 
