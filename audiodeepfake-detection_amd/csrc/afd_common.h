@@ -62,6 +62,12 @@ int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int
 int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin,
                             int Cout, long HW, void* ws, size_t ws_bytes, hipStream_t s);
 
+// conv3x3.hip: 3x3 / dilation 1 / pad 1 on wide images, vector-ALU-free inner loop
+bool conv3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
+size_t conv3x3_workspace_bytes(int Cin, int Cout);
+int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
+                int W, int Cout, int dgrad, void* ws, size_t ws_bytes, hipStream_t s);
+
 constexpr int kWave = 64;
 constexpr int kLdsBytes = 160 * 1024;  // per-CU LDS on gfx950
 

@@ -1287,6 +1287,14 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(afd::dilconv_workspace_bytes(Cin, K));
         if (b > need) need = b;
     }
+    if (afd::conv3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
+        const size_t b = align_up(afd::conv3x3_workspace_bytes(Cin, Cout));
+        if (b > need) need = b;
+    }
+    if (afd::conv3x3_applicable(Cout, Hout, Wout, Cin, K, dil * (K - 1) - pad, dil)) {
+        const size_t b = align_up(afd::conv3x3_workspace_bytes(Cout, Cin));
+        if (b > need) need = b;
+    }
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil) && afd::conv1x1_wgrad_applicable(Cin, Cout)) {
         const size_t b = align_up(afd::conv1x1_workspace_bytes(Cin, Cout));
         if (b > need) need = b;
@@ -1314,6 +1322,8 @@ extern "C" int afd_conv2d_forward(const float* x, const float* w, const float* b
         return afd::dilconv_forward(x, w, bias, y, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
         return afd::conv1x1_forward(x, w, bias, y, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
+    if (afd::conv3x3_applicable(Cin, H, W, Cout, K, pad, dil))
+        return afd::conv3x3_run(x, w, bias, y, N, Cin, H, W, Cout, 0, ws, ws_bytes, static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     ConvGeom g;
@@ -1340,6 +1350,8 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
         return afd::dilconv_backward_data(dy, w, dx, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
         return afd::conv1x1_backward_data(dy, w, dx, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
+    if (afd::conv3x3_applicable(Cout, H, W, Cin, K, dil * (K - 1) - pad, dil))
+        return afd::conv3x3_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, ws, ws_bytes, static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     const int padd = dil * (K - 1) - pad;

@@ -1,0 +1,301 @@
+// 3x3 (dilation 1) forward / backward-data on wide images: implicit GEMM with a vector-ALU-free
+// inner loop.
+//
+// The f32 MFMA runs at the vector-ALU rate (MI355X_MICROARCH.md, "Matrix cores"), so address
+// arithmetic between MFMAs is not hidden behind them, it competes with them: the
+// general kernel (conv.hip, conv_igemm_kernel) spends ~8 VALU instructions per MFMA on its
+// k -> (channel, ky, kx) table and fragment addresses and tops out near 50 % of the MFMA peak.
+// This kernel fixes the tile geometry at compile time -- one output row, PIX pixels, channel
+// chunks of 8, patch [8][3][PIX + 4] -- and orders K as (channel pair, ky, kx, channel parity):
+// the two halves of a wave (k parity of v_mfma_f32_32x32x2_f32) then differ by ONE channel
+// plane, a per-lane constant, and every A / B fragment of a chunk is a ds_read at
+// lane base + compile-time immediate.  The chunk loop is unrolled (36 k-steps) with the reads
+// of step s+1 placed between the MFMAs of step s.
+// Staging: interior tiles load at a wave-uniform base + a per-thread constant offset (dwordx4,
+// no index arithmetic); border tiles take a predicated per-element path.
+// Used for the level-14 DCNN blocks 3-6 (models.py:262-270) in both directions; everything
+// else stays on conv_igemm_kernel.  Same two-level fp32 accumulation as there.
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kCT = 8;        // channels per chunk
+constexpr int kPairs = kCT / 2;
+constexpr int kKsteps = kPairs * 9;  // 36 k-steps of two channels
+constexpr int kPR = 3;        // patch rows
+
+struct G3 {
+    int N, Cin, H, W, Cout;  // of THIS convolution (backward-data: roles already swapped)
+    int pad;                 // 1 (forward) or 1 (backward-data of pad 1): out = in + 2 pad - 2
+    int Hout, Wout;
+    int nchunks, tilesX;
+};
+
+// weights w[Cout][Cin][3][3] -> wp[chunk][kstep = (pair, ky, kx)][parity][CO_PAD]
+// dgrad: the output channels are the forward's input channels, taps flipped
+__global__ void repack3_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout,
+                               int CO_PAD, int nchunks, int dgrad) {
+    const int total = nchunks * kKsteps * 2 * CO_PAD;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int co = i % CO_PAD;
+        const int par = (i / CO_PAD) & 1;
+        const int ks = (i / (2 * CO_PAD)) % kKsteps;
+        const int chunk = i / (2 * CO_PAD * kKsteps);
+        const int pair = ks / 9, r = ks - pair * 9;
+        const int ci = chunk * kCT + 2 * pair + par;
+        float v = 0.f;
+        if (ci < Cin && co < Cout)
+            v = dgrad ? w[((size_t)ci * Cout + co) * 9 + (8 - r)] : w[((size_t)co * Cin + ci) * 9 + r];
+        wp[i] = v;
+    }
+}
+
+// MW x NW 32x32 tiles per wave, WNB waves along the pixel axis; PIX = NW * WNB * 32
+template <int MW, int NW, int WMB, int WNB>
+__global__ void __launch_bounds__(WMB * WNB * 64)
+conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict__ wp,
+               const float* __restrict__ bias, float* __restrict__ y) {
+    constexpr int NT = WMB * WNB * 64;
+    constexpr int CO_PAD = MW * WMB * 32;
+    constexpr int PIX = NW * WNB * 32;
+    constexpr int PC = PIX + 4;  // 2 halo columns + 2 of padding: whole groups of four per row
+    constexpr int G4 = PC / 4;
+    constexpr int WFLOATS = kKsteps * 2 * CO_PAD;
+    constexpr int PFLOATS = kCT * kPR * PC;
+    constexpr int WV = (WFLOATS / 4 + NT - 1) / NT;     // weight float4 per thread
+    constexpr int PV = (kCT * kPR * G4 + NT - 1) / NT;  // patch groups per thread
+    __shared__ __attribute__((aligned(16))) float wl[WFLOATS];
+    __shared__ __attribute__((aligned(16))) float patch[PFLOATS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wmb = wave % WMB, wnb = wave / WMB;
+    const int tpi = g.tilesX * g.Hout;
+    const int n = blockIdx.x / tpi;
+    const int t = blockIdx.x - n * tpi;
+    const int oy = t / g.tilesX;
+    const int ox0 = (t - oy * g.tilesX) * PIX;
+    const int iy0 = oy - g.pad, ix0 = ox0 - g.pad;
+    const size_t iplane = (size_t)g.H * g.W;
+
+    // per-thread staging offsets (elements), constant over the chunks
+    unsigned xo[PV];
+#pragma unroll
+    for (int u = 0; u < PV; ++u) {
+        const int item = tid + u * NT;
+        const int row = item / G4, g4 = item - row * G4;
+        const int ci_l = row / kPR, pr = row - ci_l * kPR;
+        xo[u] = item < kCT * kPR * G4 ? (unsigned)ci_l * (unsigned)(g.H * g.W) + (unsigned)(pr * g.W + 4 * g4) : 0u;
+    }
+    const bool interior = iy0 >= 0 && iy0 + kPR <= g.H && ix0 >= 0 && ix0 + PC <= g.W;
+
+    // fragment bases (floats): A = wl + parity row + channel column, B = patch + parity plane + pixel
+    const float* abase = wl + half * CO_PAD + wmb * MW * 32 + l31;
+    const float* bbase = patch + half * kPR * PC + wnb * NW * 32 + l31;
+
+    f32x16 acc[MW][NW];
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+
+    const float* xn = x + (size_t)n * g.Cin * iplane;
+    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
+        // ---- stage: every load of the chunk in flight before the first LDS store ----
+        f32x4u wv[WV], pv[PV];
+        {
+            const f32x4u* src = reinterpret_cast<const f32x4u*>(wp + (size_t)chunk * WFLOATS);
+#pragma unroll
+            for (int u = 0; u < WV; ++u) {
+                const int i = tid + u * NT;
+                if (i < WFLOATS / 4) wv[u] = src[i];
+            }
+            const float* xc = xn + (size_t)chunk * kCT * iplane;
+            if (interior) {
+                const float* xb = xc + (size_t)iy0 * g.W + ix0;
+#pragma unroll
+                for (int u = 0; u < PV; ++u) pv[u] = *reinterpret_cast<const f32x4u*>(xb + xo[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < PV; ++u) {
+                    const int item = tid + u * NT;
+                    const int row = item / G4, g4 = item - row * G4;
+                    const int ci_l = row / kPR, pr = row - ci_l * kPR;
+                    const int iy = iy0 + pr, ix = ix0 + 4 * g4;
+                    f32x4u v = {0.f, 0.f, 0.f, 0.f};
+                    if (item < kCT * kPR * G4 && iy >= 0 && iy < g.H) {
+                        const float* src4 = xc + (size_t)ci_l * iplane + (size_t)iy * g.W + ix;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ix + j >= 0 && ix + j < g.W) v[j] = src4[j];
+                    }
+                    pv[u] = v;
+                }
+            }
+        }
+        __syncthreads();  // the previous chunk's fragments have been read
+        {
+            float4* wd = reinterpret_cast<float4*>(wl);
+#pragma unroll
+            for (int u = 0; u < WV; ++u) {
+                const int i = tid + u * NT;
+                if (i < WFLOATS / 4) wd[i] = make_float4(wv[u][0], wv[u][1], wv[u][2], wv[u][3]);
+            }
+            float4* pd = reinterpret_cast<float4*>(patch);
+#pragma unroll
+            for (int u = 0; u < PV; ++u) {
+                const int item = tid + u * NT;
+                if (item < kCT * kPR * G4) pd[item] = make_float4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+            }
+        }
+        __syncthreads();
+        // ---- 36 k-steps, fragment addresses = lane base + immediate ----
+        f32x16 part[MW][NW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[m][i][r] = 0.f;
+        float a0[MW], b0[NW], a1[MW], b1[NW];
+#pragma unroll
+        for (int m = 0; m < MW; ++m) a0[m] = abase[m * 32];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) b0[i] = bbase[i * 32];
+#pragma unroll
+        for (int ks = 0; ks < kKsteps; ks += 2) {
+            {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int k1 = ks + 1;
+                const int pair = k1 / 9, r = k1 - pair * 9, ky = r / 3, kx = r - ky * 3;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) a1[m] = abase[k1 * 2 * CO_PAD + m * 32];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) b1[i] = bbase[(2 * pair * kPR + ky) * PC + kx + i * 32];
+            }
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[i], part[m][i], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MW * NW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < kKsteps) {
+                const int k2 = ks + 2;
+                const int pair = k2 / 9, r = k2 - pair * 9, ky = r / 3, kx = r - ky * 3;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) a0[m] = abase[k2 * 2 * CO_PAD + m * 32];
+#pragma unroll
+                for (int i = 0; i < NW; ++i) b0[i] = bbase[(2 * pair * kPR + ky) * PC + kx + i * 32];
+            }
+#pragma unroll
+            for (int m = 0; m < MW; ++m)
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[i], part[m][i], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < MW * NW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // two-level accumulation: one fp32 chain per channel chunk, then one add
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int i = 0; i < NW; ++i) acc[m][i] += part[m][i];
+    }
+
+    // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const size_t oplane = (size_t)g.Hout * g.Wout;
+    float* yn = y + (size_t)n * g.Cout * oplane + (size_t)oy * g.Wout;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const int ox = ox0 + (wnb * NW + i) * 32 + l31;
+        if (ox >= g.Wout) continue;
+#pragma unroll
+        for (int m = 0; m < MW; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (wmb * MW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (co < g.Cout) yn[(size_t)co * oplane + ox] = acc[m][i][r] + (bias ? bias[co] : 0.f);
+            }
+        }
+    }
+}
+
+template <int MW, int NW, int WMB, int WNB>
+int launch3(G3 g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
+    constexpr int PIX = NW * WNB * 32;
+    g.tilesX = (g.Wout + PIX - 1) / PIX;
+    const long blocks = (long)g.N * g.Hout * g.tilesX;
+    if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: grid too large");
+    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB>), dim3((unsigned)blocks), dim3(WMB * WNB * 64), 0,
+                       s, g, x, wp, bias, y);
+    return afd::check_launch("conv3x3_kernel");
+}
+
+int run3(const G3& g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
+    switch ((g.Cout + 31) / 32) {
+        case 1: return launch3<1, 2, 1, 4>(g, x, wp, bias, y, s);  // 32 ch x 256 px
+        case 2: return launch3<1, 2, 2, 2>(g, x, wp, bias, y, s);  // 64 ch x 128 px
+        case 3: return launch3<3, 1, 1, 4>(g, x, wp, bias, y, s);  // 96 ch x 128 px
+        case 4: return launch3<2, 2, 2, 2>(g, x, wp, bias, y, s);  // 128 ch x 128 px
+    }
+    return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: Cout %d > 128", g.Cout);
+}
+
+}  // namespace
+
+namespace afd {
+
+// (Cin, Cout, ...) of the convolution that is actually computed (for backward-data: swapped)
+bool conv3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
+    if (getenv("AFD_NO_CONV3X3")) return false;
+    if (K != 3 || dil != 1 || pad != 1) return false;
+    if (Cin % kCT != 0 || Cout > 128 || Cin < kCT) return false;
+    if (W < 1024) return false;  // wide (level-14 style) images only: one-row tiles of 128-256 pixels
+    return (size_t)kCT * H * W < 0x7fffffffULL;
+}
+
+size_t conv3x3_workspace_bytes(int Cin, int Cout) {
+    const size_t co_pad = (size_t)(Cout + 31) / 32 * 32;
+    return (size_t)(Cin / kCT) * kKsteps * 2 * co_pad * sizeof(float);
+}
+
+// dgrad = 0: y = conv(x, w) + bias, w [Cout][Cin][3][3].
+// dgrad = 1: x is dy [N][Cin=forward Cout][H][W], y is dx [N][Cout=forward Cin][H][W],
+//            w is the forward weight [Cin][Cout][3][3].
+int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
+                int W, int Cout, int dgrad, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < conv3x3_workspace_bytes(Cin, Cout))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv3x3: workspace too small");
+    G3 g{};
+    g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout; g.pad = 1;
+    g.Hout = H; g.Wout = W;
+    g.nchunks = Cin / kCT;
+    float* wp = static_cast<float*>(ws);
+    const int co_pad = (Cout + 31) / 32 * 32;
+    const int total = g.nchunks * kKsteps * 2 * co_pad;
+    hipLaunchKernelGGL(repack3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, wp, Cin, Cout, co_pad,
+                       g.nchunks, dgrad);
+    int rc = afd::check_launch("repack3_kernel");
+    if (rc) return rc;
+    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)H * W * Cin * 9, s);
+    return run3(g, x, wp, bias, y, s);
+}
+
+}  // namespace afd

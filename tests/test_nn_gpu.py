@@ -53,6 +53,13 @@ CONV_CASES = [
     (2, 128, 5, 33, 128, 1, 0, 1),
     (3, 20, 9, 50, 40, 1, 0, 1),
     (1, 64, 13, 1031, 64, 1, 0, 1),
+    # 3x3 on wide images: compile-time-geometry kernel, conv3x3.hip (all four wave tilings,
+    # both directions; border tiles, ragged right edge, padded output channels)
+    (2, 32, 6, 1100, 64, 3, 1, 1),
+    (1, 128, 5, 1300, 32, 3, 1, 1),
+    (1, 96, 4, 1025, 128, 3, 1, 1),
+    (1, 8, 3, 1024, 40, 3, 1, 1),
+    (1, 64, 13, 1157, 96, 3, 1, 1),
     # LCNN shapes (models.py:85-110)
     (2, 1, 101, 256, 64, 5, 2, 1),
     (2, 48, 25, 64, 128, 3, 1, 1),
