@@ -1283,6 +1283,12 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(wgrad_ws_floats(w2.w) * 4);
         if (b > need) need = b;
     }
+    if (afd::wgrad3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
+        int S3, nch3, ct3, cop3, ncol3;
+        afd::wgrad3x3_geometry(N, Cin, H, W, Cout, &S3, &nch3, &ct3, &cop3, &ncol3);
+        const size_t b = align_up(((size_t)S3 * nch3 * cop3 * ncol3 + (size_t)S3 * cop3) * 4);
+        if (b > need) need = b;
+    }
     if (afd::dilconv_applicable(Cin, Cout, K, dil)) {
         const size_t b = align_up(afd::dilconv_workspace_bytes(Cin, K));
         if (b > need) need = b;
@@ -1382,6 +1388,21 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
         return afd::conv1x1_backward_weight(x, dy, dw, dbias, N, Cin, Cout, (long)H * W, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (afd::wgrad3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
+        int S3, nch3, ct3, cop3, ncol3;
+        afd::wgrad3x3_geometry(N, Cin, H, W, Cout, &S3, &nch3, &ct3, &cop3, &ncol3);
+        const size_t slabs = (size_t)S3 * nch3 * cop3 * ncol3;
+        if (!ws || ws_bytes < (slabs + (size_t)S3 * cop3) * 4) return afd::fail(AFD_ERR_WORKSPACE, "conv wgrad: workspace too small");
+        float* part3 = static_cast<float*>(ws);
+        float* partb3 = part3 + slabs;
+        rc = afd::wgrad3x3_launch(x, dy, part3, partb3, N, Cin, H, W, Cout, s);
+        if (rc) return rc;
+        const int total3 = Cout * Cin * K * K;
+        const int nblk3 = (total3 + 31) / 32 + (dbias ? (Cout + 31) / 32 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk3), dim3(256), 0, s, part3, partb3, dw, dbias,
+                           Cin, Cout, K * K, ct3, nch3, cop3, ncol3, S3);
+        return afd::check_launch("wgrad_reduce_kernel");
+    }
     Wgrad2Geom w2;
     if (use_wgrad2() && plan_wgrad2(w2, N, Cin, H, W, Cout, K, pad, dil) == AFD_OK) {
         const WgradGeom& g2 = w2.w;

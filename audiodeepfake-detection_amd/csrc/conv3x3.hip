@@ -258,7 +258,280 @@ int run3(const G3& g, const float* x, const float* wp, const float* bias, float*
     return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: Cout %d > 128", g.Cout);
 }
 
+// ---------------------------------------------------------------------------------------
+// backward-weight for the same layers: dw[co][ci][ky][kx] = sum_p dz[co][p] x[ci][p + tap].
+// GEMM with M = output channels, N = (ci, ky, kx) columns of a chunk of CT channels,
+// K = pixels in tiles of 64 (one output row).  The (channel tile, column tile) pairs of a
+// chunk are dealt to four waves, TPW each, and stay in accumulators over the whole tile list
+// of the workgroup; per tile: loads -> barrier -> LDS stores -> barrier -> 32 k-steps whose
+// fragment reads are lane base + immediate.  dz rows have pitch 65 and the patch rows pitch 68
+// (whole float4 groups; the 32 columns of a B read land on >= 24 banks).
+// One partial slab per (split, chunk), summed by conv.hip's wgrad_reduce_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int kWPix = 64;
+constexpr int kWPitch = 65;
+constexpr int kWPC = kWPix + 4;
+
+struct GW {
+    int N, Cin, H, W, Cout;  // forward geometry; dz is [N][Cout][H][W]
+    int tilesX, S, nchunks;
+    int ntiles;
+};
+
+template <int MT, int CT, int TPW>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dz,
+                float* __restrict__ part, float* __restrict__ partb) {
+    constexpr int CO_PAD = MT * 32;
+    constexpr int NTILES = CT * 9 / 32;
+    static_assert(CT * 9 % 32 == 0, "whole column tiles");
+    constexpr int PAIRS = MT * NTILES;
+    static_assert(4 * TPW >= PAIRS, "pairs per wave");
+    constexpr int NCOL = NTILES * 32;
+    constexpr int DZF = CO_PAD * kWPitch;
+    constexpr int PF = CT * kPR * kWPC;
+    constexpr int G4 = kWPC / 4;
+    constexpr int DV = CO_PAD * 16 / 256;             // dz groups (4 pixels) per thread
+    constexpr int PV = (CT * kPR * G4 + 255) / 256;   // patch groups per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // dz | patch | bias cells
+    float* patch = smem + DZF;
+    float* bsl = smem + DZF + PF;  // [CO_PAD][16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int chunk = blockIdx.y, split = blockIdx.x;
+    const size_t plane = (size_t)g.H * g.W;
+
+    for (int i = tid; i < CO_PAD * 16; i += 256) bsl[i] = 0.f;
+
+    // staging offsets (elements) inside an interior tile
+    unsigned dzo[DV], xo[PV];
+#pragma unroll
+    for (int u = 0; u < DV; ++u) {
+        const int item = tid + u * 256;
+        const int co = item >> 4, px = (item & 15) << 2;
+        dzo[u] = co < g.Cout ? (unsigned)co * (unsigned)(g.H * g.W) + px : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < PV; ++u) {
+        const int item = tid + u * 256;
+        const int row = item / G4, g4 = item - row * G4;
+        const int ci_l = row / kPR, pr = row - ci_l * kPR;
+        xo[u] = item < CT * kPR * G4 ? (unsigned)ci_l * (unsigned)(g.H * g.W) + (unsigned)(pr * g.W + 4 * g4) : 0u;
+    }
+    // fragment bases
+    const float* ap[TPW];
+    const float* bp[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int p = wave * TPW + q;
+        const int pp = p < PAIRS ? p : 0;
+        const int m = pp / NTILES, nt = pp - m * NTILES;
+        const int c = nt * 32 + l31;
+        const int ci_l = c / 9, r = c - ci_l * 9, ky = r / 3, kx = r - ky * 3;
+        ap[q] = smem + (m * 32 + l31) * kWPitch + half;
+        bp[q] = patch + (ci_l * kPR + ky) * kWPC + kx + half;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int tpi = g.tilesX * g.H;
+    for (int tile = split; tile < g.ntiles; tile += g.S) {
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int oy = t / g.tilesX;
+        const int ox0 = (t - oy * g.tilesX) * kWPix;
+        const int iy0 = oy - 1, ix0 = ox0 - 1;
+        const float* dzn = dz + (size_t)n * g.Cout * plane + (size_t)oy * g.W + ox0;
+        const float* xc = x + ((size_t)n * g.Cin + (size_t)chunk * CT) * plane;
+        {
+            f32x4u dv[DV], pv[PV];
+            const bool interior = ox0 + kWPix <= g.W && ix0 >= 0 && ix0 + kWPC <= g.W && iy0 >= 0 &&
+                                  iy0 + kPR <= g.H;
+            if (interior) {
+                const float* xb = xc + (size_t)iy0 * g.W + ix0;
+#pragma unroll
+                for (int u = 0; u < DV; ++u) dv[u] = *reinterpret_cast<const f32x4u*>(dzn + dzo[u]);
+#pragma unroll
+                for (int u = 0; u < PV; ++u) pv[u] = *reinterpret_cast<const f32x4u*>(xb + xo[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < DV; ++u) {
+                    const int item = tid + u * 256;
+                    const int co = item >> 4, px = (item & 15) << 2;
+                    f32x4u v = {0.f, 0.f, 0.f, 0.f};
+                    if (co < g.Cout) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ox0 + px + j < g.W) v[j] = dzn[(size_t)co * plane + px + j];
+                    }
+                    dv[u] = v;
+                }
+#pragma unroll
+                for (int u = 0; u < PV; ++u) {
+                    const int item = tid + u * 256;
+                    const int row = item / G4, g4 = item - row * G4;
+                    const int ci_l = row / kPR, pr = row - ci_l * kPR;
+                    const int iy = iy0 + pr, ix = ix0 + 4 * g4;
+                    f32x4u v = {0.f, 0.f, 0.f, 0.f};
+                    if (item < CT * kPR * G4 && iy >= 0 && iy < g.H) {
+                        const float* src = xc + (size_t)ci_l * plane + (size_t)iy * g.W + ix;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (ix + j >= 0 && ix + j < g.W) v[j] = src[j];
+                    }
+                    pv[u] = v;
+                }
+            }
+            __syncthreads();  // the previous tile's fragments have been read (first pass: bias cells are zero)
+#pragma unroll
+            for (int u = 0; u < DV; ++u) {
+                const int item = tid + u * 256;
+                const int co = item >> 4, px = (item & 15) << 2;
+                float* d = smem + co * kWPitch + px;
+                const bool live = co < g.Cout;  // padded channel rows stay zero
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = live ? dv[u][j] : 0.f;
+                if (chunk == 0 && live) bsl[item] += (dv[u][0] + dv[u][1]) + (dv[u][2] + dv[u][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < PV; ++u) {
+                const int item = tid + u * 256;
+                if (item < CT * kPR * G4)
+                    *reinterpret_cast<float4*>(patch + 4 * item) = make_float4(pv[u][0], pv[u][1], pv[u][2], pv[u][3]);
+            }
+            __syncthreads();
+        }
+        float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            a0[q] = ap[q][0];
+            b0[q] = bp[q][0];
+        }
+#pragma unroll
+        for (int ks = 0; ks < kWPix / 2; ks += 2) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                a1[q] = ap[q][2 * ks + 2];
+                b1[q] = bp[q][2 * ks + 2];
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < kWPix / 2) {
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    a0[q] = ap[q][2 * ks + 4];
+                    b0[q] = bp[q][2 * ks + 4];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float* slab = part + ((size_t)split * g.nchunks + chunk) * CO_PAD * NCOL;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int p = wave * TPW + q;
+        if (p >= PAIRS) continue;
+        const int m = p / NTILES, nt = p - m * NTILES;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[(size_t)co * NCOL + nt * 32 + l31] = acc[q][r];
+        }
+    }
+    __syncthreads();  // the last tile's bias cells are written
+    if (chunk == 0 && tid < CO_PAD) {
+        float v = 0.f;
+        for (int j = 0; j < 16; ++j) v += bsl[tid * 16 + j];  // fixed order
+        partb[(size_t)split * CO_PAD + tid] = v;
+    }
+}
+
+template <int MT, int CT, int TPW>
+int launchw(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
+    constexpr size_t lds = (size_t)(MT * 32 * kWPitch + CT * kPR * kWPC + MT * 32 * 16) * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<MT, CT, TPW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad3x3: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad3x3_kernel<MT, CT, TPW>), dim3(g.S, g.nchunks), dim3(256), lds, s, g, x, dz,
+                       part, partb);
+    return afd::check_launch("wgrad3x3_kernel");
+}
+
+// channels per chunk (64 with 32 output channels measured slower: 58 vs 68 TF/s on 128 -> 32)
+int wgrad_ct(int, int) { return 32; }
+
 }  // namespace
+
+namespace afd {
+
+bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
+    if (getenv("AFD_NO_WGRAD3X3")) return false;
+    if (K != 3 || dil != 1 || pad != 1 || W < 1024 || Cout > 128) return false;
+    const int mt = (Cout + 31) / 32;
+    if (Cin % wgrad_ct(mt, Cin) != 0) return false;
+    return (size_t)128 * H * W < 0x7fffffffULL;
+}
+
+// slab geometry for conv.hip's reduction: S splits x nchunks slabs of [CO_PAD][NCOL]
+void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int* S, int* nchunks, int* CI_T,
+                       int* CO_PAD, int* NCOL) {
+    const int mt = (Cout + 31) / 32;
+    const int ct = wgrad_ct(mt, Cin);
+    *CI_T = ct;
+    *nchunks = Cin / ct;
+    *CO_PAD = mt * 32;
+    *NCOL = ct * 9;
+    const long tiles = (long)N * H * ((W + kWPix - 1) / kWPix);
+    long s = 1024 / *nchunks;
+    if (s < 1) s = 1;
+    if (s > tiles) s = tiles;
+    *S = (int)s;
+}
+
+int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, int N, int Cin, int H,
+                    int W, int Cout, hipStream_t s) {
+    GW g{};
+    g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout;
+    g.tilesX = (W + kWPix - 1) / kWPix;
+    int ct, co_pad, ncol;
+    wgrad3x3_geometry(N, Cin, H, W, Cout, &g.S, &g.nchunks, &ct, &co_pad, &ncol);
+    const long tiles = (long)N * H * g.tilesX;
+    if (tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad3x3: too many tiles");
+    g.ntiles = (int)tiles;
+    afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)H * W * Cin * 9, s);
+    const int mt = co_pad / 32;
+    if (mt == 1) return launchw<1, 32, 3>(g, x, dz, part, partb, s);              //  9 pairs
+    if (mt == 2) return launchw<2, 32, 5>(g, x, dz, part, partb, s);              // 18 pairs
+    if (mt == 3) return launchw<3, 32, 7>(g, x, dz, part, partb, s);              // 27 pairs
+    return launchw<4, 32, 9>(g, x, dz, part, partb, s);                           // 36 pairs
+}
+
+}  // namespace afd
 
 namespace afd {
 
