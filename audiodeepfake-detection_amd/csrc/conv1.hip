@@ -106,18 +106,28 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
         if (px >= Wp) continue;
         float p[4][4];
         load_patch(x + (size_t)n * H * W, H, W, py, px, pad, p);
-        size_t o = (((size_t)n * Cout + cg * kCG) * Hp + py) * Wp + px;
+        const size_t o0 = (((size_t)n * Cout + cg * kCG) * Hp + py) * Wp + px;
+        // all 3 * kCG loads of the pixel in flight before the first use (a load -> FMA chain
+        // per channel pays one HBM latency per channel)
+        int code[kCG];
+        float gv[kCG], uv[kCG];
 #pragma unroll
-        for (int c = 0; c < kCG; ++c, o += plane) {
-            if (cg * kCG + c >= Cout) break;
-            const int code = idx[o];
-            float g = du[o];
-            if (code & 4) {
-                accs[c] += g * u[o] * inva;
+        for (int c = 0; c < kCG; ++c) {
+            const bool ok = cg * kCG + c < Cout;
+            const size_t o = o0 + (size_t)c * plane;
+            code[c] = ok ? idx[o] : 0;
+            gv[c] = ok ? du[o] : 0.f;
+            uv[c] = ok ? u[o] : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < kCG; ++c) {
+            float g = gv[c];
+            if (code[c] & 4) {
+                accs[c] += g * uv[c] * inva;
                 g *= a;
             }
             accb[c] += g;
-            const int pos = code & 3;
+            const int pos = code[c] & 3;
             const float g0 = pos == 0 ? g : 0.f, g1 = pos == 1 ? g : 0.f;
             const float g2 = pos == 2 ? g : 0.f, g3 = pos == 3 ? g : 0.f;
 #pragma unroll

@@ -251,11 +251,21 @@ def main() -> None:
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
                 pmc = json.load(fh)
             if pmc.get("workload") == a.workload and pmc.get("batch") == a.batch:
-                kk = pmc["kernels"].get({"conv_igemm": "conv_igemm_kernel", "conv_wgrad": "conv_wgrad_kernel",
-                                          "wpt": "wpt2_deep_kernel", "stft": "stft_mfma_kernel"}[dom], {})
-                if kk:
-                    roofline["traffic"] = kk.get("fetch_size_bytes_per_launch", 0.0) + kk.get("write_size_bytes_per_launch", 0.0)
-                    roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (raw FETCH_SIZE + WRITE_SIZE per launch)"
+                # the class's launches are spread over these kernels: launch-weighted mean
+                names = {"conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
+                         "conv_wgrad": ("wgrad3x3_kernel", "conv1x1_wgrad_kernel", "conv_wgrad2_kernel",
+                                        "conv_wgrad_kernel"),
+                         "wpt": ("wpt2_deep_kernel", "wpt2_top_kernel"), "stft": ("stft_mfma_kernel",)}[dom]
+                tot = cnt = 0.0
+                for nm in names:
+                    kk = pmc["kernels"].get(nm)
+                    if kk:
+                        tot += (kk.get("fetch_bytes_per_launch", 0.0) + kk.get("write_bytes_per_launch", 0.0)) * kk["launches_in_trace"]
+                        cnt += kk["launches_in_trace"]
+                if cnt:
+                    roofline["traffic"] = tot / cnt
+                    roofline["traffic_source"] = ("profiles/r01_pmc_traffic.json (FETCH_SIZE x2 for dwordx4 readers "
+                                                  "+ WRITE_SIZE, launch-weighted over the class's kernels)")
         except (OSError, ValueError, KeyError):
             pass
         roofline["launches_per_step"] = k["launches"]

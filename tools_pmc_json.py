@@ -1,0 +1,33 @@
+"""Turns the two rocprofv3 --pmc passes of tools_pmc_bench.sh into profiles/r01_pmc_traffic.json.
+
+FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE
+counts 64 B per 128-B request of wide (16 B/lane) coalesced reads, so it is doubled for the kernels
+whose staging loads are dwordx4; other widths are uncalibrated and recorded raw.
+"""
+import collections, csv, glob, json, re, sys
+
+WIDE = ("conv3x3_kernel", "wgrad3x3_kernel", "conv1x1_kernel", "wpt_haar14_kernel", "conv_wgrad2_kernel",
+        "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel", "bn_bwd_apply_kernel",
+        "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
+out = {"note": __doc__.strip(), "workload": "coif4-l14", "batch": 128, "kernels": {}}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = sorted(glob.glob(f"gpurun_out/pmc_{counter}/*/*counter_collection.csv"))[-1]
+    agg = collections.defaultdict(float); n = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        m = re.search(r"(\w+_kernel)", r["Kernel_Name"]); k = m.group(1) if m else "other"
+        agg[k] += float(r["Counter_Value"]) * 1024.0; n[k] += 1
+    for k in agg:
+        e = out["kernels"].setdefault(k, {})
+        raw = agg[k] / n[k]
+        if counter == "FETCH_SIZE":
+            e["fetch_raw_bytes_per_launch"] = raw
+            e["fetch_bytes_per_launch"] = raw * (2.0 if k in WIDE else 1.0)
+            e["fetch_corrected_x2"] = k in WIDE
+        else:
+            e["write_bytes_per_launch"] = raw
+        e["launches_in_trace"] = n[k]
+json.dump(out, open("profiles/r01_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+for k, e in sorted(out["kernels"].items(), key=lambda kv: -(kv[1].get("fetch_bytes_per_launch", 0) + kv[1].get("write_bytes_per_launch", 0)) * kv[1]["launches_in_trace"])[:12]:
+    print(f"{k:28s} launches {e['launches_in_trace']:3d}  fetch {e.get('fetch_bytes_per_launch', 0)/1e9:7.3f} GB  write {e.get('write_bytes_per_launch', 0)/1e9:7.3f} GB per launch")
