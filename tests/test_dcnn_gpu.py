@@ -115,3 +115,45 @@ def test_level14_coif4_shape_runs():
     loss.backward()
     for k, p in net.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
+def test_full_width_level14_step_matches_cpu_restatement():
+    """BASELINE configs[1] geometry at full width (16384 packets x 24 time steps), 2 frames.
+
+    Exercises the wide-image kernels (conv3x3 / wgrad3x3 / conv1x1 / dilconv / fused conv1)
+    inside the real model: features -> DCNN -> loss -> backward against oracle/torch_ref.DCNNRef
+    on the CPU (fp32).  Bars as in test_train_step_matches_reference: logits 1e-4, loss 1e-5,
+    gradients bounded by pool / PReLU near-tie flips (relative L2 over all parameters <= 3e-3).
+    """
+    from oracle import torch_ref
+    from audiofakedetect.wavelet_math import Packets
+
+    torch.manual_seed(11)
+    x = (0.1 * torch.randn(2, 1, 22050)).clamp_(-1, 1)
+    feats, _ = Packets("coif4", max_lev=14, log_scale=True)(x.cuda())  # view [B, 1, 16384, 24]
+    feats = (feats - feats.mean()) / feats.std()
+    assert tuple(feats.shape) == (2, 1, 16384, 24)
+    args = _args(feats.shape, flattend_size=40 * (16384 // 8 - 24), dropout_cnn=0.0, dropout_lstm=0.0)
+    net = DCNN(args)
+    ref = torch_ref.DCNNRef(args.input_dim, dropout_cnn=0.0, dropout_lstm=0.0,
+                            flattend_size=args.flattend_size)
+    ref.load_state_dict(net.state_dict())
+    net.cuda().train()
+    ref.train()
+    labels = torch.tensor([0, 1])
+    out = net(feats)
+    loss = ops.CrossEntropyLoss()(out, labels.cuda())
+    loss.backward()
+    out_ref = ref(feats.cpu())
+    loss_ref = torch.nn.functional.cross_entropy(out_ref, labels)
+    loss_ref.backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    assert torch.equal(out.argmax(-1).cpu(), out_ref.argmax(-1))
+    num = den = 0.0
+    refp = dict(ref.named_parameters())
+    for k, p in net.named_parameters():
+        d = (p.grad.cpu() - refp[k].grad)
+        num += d.pow(2).sum().item()
+        den += refp[k].grad.pow(2).sum().item()
+    assert (num / den) ** 0.5 <= 3e-3, (num / den) ** 0.5
