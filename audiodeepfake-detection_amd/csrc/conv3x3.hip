@@ -55,8 +55,8 @@ __global__ void repack3_kernel(const float* __restrict__ w, float* __restrict__ 
 }
 
 // MW x NW 32x32 tiles per wave, WNB waves along the pixel axis; PIX = NW * WNB * 32
-template <int MW, int NW, int WMB, int WNB>
-__global__ void __launch_bounds__(WMB * WNB * 64)
+template <int MW, int NW, int WMB, int WNB, bool PF>
+__global__ void __launch_bounds__(WMB * WNB * 64) __attribute__((amdgpu_waves_per_eu(2)))
 conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ y) {
     constexpr int NT = WMB * WNB * 64;
@@ -107,39 +107,42 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
             for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
 
     const float* xn = x + (size_t)n * g.Cin * iplane;
-    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
-        // ---- stage: every load of the chunk in flight before the first LDS store ----
-        f32x4u wv[WV], pv[PV];
-        {
-            const f32x4u* src = reinterpret_cast<const f32x4u*>(wp + (size_t)chunk * WFLOATS);
+    // staging registers: the loads of chunk c+1 are issued before the k-loop of chunk c and
+    // written to LDS after it (interior tiles: no address arithmetic, nothing for the MFMAs to
+    // wait on)
+    f32x4u wv[WV], pv[PV];
+    auto load_chunk = [&](int chunk) {
+        const f32x4u* src = reinterpret_cast<const f32x4u*>(wp + (size_t)chunk * WFLOATS);
 #pragma unroll
-            for (int u = 0; u < WV; ++u) {
-                const int i = tid + u * NT;
-                if (i < WFLOATS / 4) wv[u] = src[i];
-            }
-            const float* xc = xn + (size_t)chunk * kCT * iplane;
-            if (interior) {
-                const float* xb = xc + (size_t)iy0 * g.W + ix0;
+        for (int u = 0; u < WV; ++u) {
+            const int i = tid + u * NT;
+            if (i < WFLOATS / 4) wv[u] = src[i];
+        }
+        const float* xc = xn + (size_t)chunk * kCT * iplane;
+        if (interior) {
+            const float* xb = xc + (size_t)iy0 * g.W + ix0;
 #pragma unroll
-                for (int u = 0; u < PV; ++u) pv[u] = *reinterpret_cast<const f32x4u*>(xb + xo[u]);
-            } else {
+            for (int u = 0; u < PV; ++u) pv[u] = *reinterpret_cast<const f32x4u*>(xb + xo[u]);
+        } else {
 #pragma unroll
-                for (int u = 0; u < PV; ++u) {
-                    const int item = tid + u * NT;
-                    const int row = item / G4, g4 = item - row * G4;
-                    const int ci_l = row / kPR, pr = row - ci_l * kPR;
-                    const int iy = iy0 + pr, ix = ix0 + 4 * g4;
-                    f32x4u v = {0.f, 0.f, 0.f, 0.f};
-                    if (item < kCT * kPR * G4 && iy >= 0 && iy < g.H) {
-                        const float* src4 = xc + (size_t)ci_l * iplane + (size_t)iy * g.W + ix;
+            for (int u = 0; u < PV; ++u) {
+                const int item = tid + u * NT;
+                const int row = item / G4, g4 = item - row * G4;
+                const int ci_l = row / kPR, pr = row - ci_l * kPR;
+                const int iy = iy0 + pr, ix = ix0 + 4 * g4;
+                f32x4u v = {0.f, 0.f, 0.f, 0.f};
+                if (item < kCT * kPR * G4 && iy >= 0 && iy < g.H) {
+                    const float* src4 = xc + (size_t)ci_l * iplane + (size_t)iy * g.W + ix;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (ix + j >= 0 && ix + j < g.W) v[j] = src4[j];
-                    }
-                    pv[u] = v;
+                    for (int j = 0; j < 4; ++j)
+                        if (ix + j >= 0 && ix + j < g.W) v[j] = src4[j];
                 }
+                pv[u] = v;
             }
         }
+    };
+    load_chunk(0);
+    for (int chunk = 0; chunk < g.nchunks; ++chunk) {
         __syncthreads();  // the previous chunk's fragments have been read
         {
             float4* wd = reinterpret_cast<float4*>(wl);
@@ -156,6 +159,7 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
             }
         }
         __syncthreads();
+        if (PF && chunk + 1 < g.nchunks) load_chunk(chunk + 1);
         // ---- 36 k-steps, fragment addresses = lane base + immediate ----
         f32x16 part[MW][NW];
 #pragma unroll
@@ -217,6 +221,7 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
         for (int m = 0; m < MW; ++m)
 #pragma unroll
             for (int i = 0; i < NW; ++i) acc[m][i] += part[m][i];
+        if (!PF && chunk + 1 < g.nchunks) load_chunk(chunk + 1);
     }
 
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -237,23 +242,24 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
     }
 }
 
-template <int MW, int NW, int WMB, int WNB>
+template <int MW, int NW, int WMB, int WNB, bool PF>
 int launch3(G3 g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
     constexpr int PIX = NW * WNB * 32;
     g.tilesX = (g.Wout + PIX - 1) / PIX;
     const long blocks = (long)g.N * g.Hout * g.tilesX;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: grid too large");
-    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB>), dim3((unsigned)blocks), dim3(WMB * WNB * 64), 0,
+    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, PF>), dim3((unsigned)blocks), dim3(WMB * WNB * 64), 0,
                        s, g, x, wp, bias, y);
     return afd::check_launch("conv3x3_kernel");
 }
 
 int run3(const G3& g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
+    const bool pf = getenv("AFD_C33_NOPF") == nullptr;
     switch ((g.Cout + 31) / 32) {
-        case 1: return launch3<1, 2, 1, 4>(g, x, wp, bias, y, s);  // 32 ch x 256 px
-        case 2: return launch3<1, 2, 2, 2>(g, x, wp, bias, y, s);  // 64 ch x 128 px
-        case 3: return launch3<3, 1, 1, 4>(g, x, wp, bias, y, s);  // 96 ch x 128 px
-        case 4: return launch3<2, 2, 2, 2>(g, x, wp, bias, y, s);  // 128 ch x 128 px
+        case 1: return pf ? launch3<1, 2, 1, 4, true>(g, x, wp, bias, y, s) : launch3<1, 2, 1, 4, false>(g, x, wp, bias, y, s);  // 32 ch x 256 px
+        case 2: return pf ? launch3<1, 2, 2, 2, true>(g, x, wp, bias, y, s) : launch3<1, 2, 2, 2, false>(g, x, wp, bias, y, s);  // 64 ch x 128 px
+        case 3: return pf ? launch3<3, 1, 1, 4, true>(g, x, wp, bias, y, s) : launch3<3, 1, 1, 4, false>(g, x, wp, bias, y, s);  // 96 ch x 128 px
+        case 4: return pf ? launch3<2, 2, 2, 2, true>(g, x, wp, bias, y, s) : launch3<2, 2, 2, 2, false>(g, x, wp, bias, y, s);  // 128 ch x 128 px
     }
     return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: Cout %d > 128", g.Cout);
 }
