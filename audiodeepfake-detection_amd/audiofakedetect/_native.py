@@ -48,6 +48,7 @@ _SIGNATURES = {
     "afd_conv1_pool_workspace_bytes": (c_sz, [c_i] * 5),
     "afd_conv1_pool_forward": (c_i, [c_p] * 6 + [c_i] * 5 + [c_p]),
     "afd_conv1_pool_backward": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p]),
+    "afd_moments_accumulate": (c_i, [c_p, c_sz, c_p, c_p]),
     "afd_normalize_forward": (c_i, [c_p, c_p, c_sz, c_f, c_f, c_p]),
     "afd_transpose_last2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_prelu_dropout_forward": (c_i, [c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),

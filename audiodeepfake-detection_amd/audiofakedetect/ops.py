@@ -46,6 +46,31 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+class ScalarMoments:
+    """Scalar mean / std of everything it is shown, accumulated on the GPU in double precision.
+
+    One fused reduction per batch (``afd_moments_accumulate``) in place of the reference's
+    ``WelfordEstimator.update`` chain of elementwise passes (data_loader.py:27-71); ``finalize``
+    returns the same population statistics, ``sqrt(M2 / count)``.
+    """
+
+    def __init__(self, device) -> None:
+        self.acc = torch.zeros(3, dtype=torch.float64, device=device)
+
+    def update(self, t: torch.Tensor) -> None:
+        _native.require_gpu()
+        src = t if t.is_contiguous() else t.contiguous()
+        src = src.to(torch.float32)
+        _native.check(_lib().afd_moments_accumulate(_native.ptr(src), src.numel(), _native.ptr(self.acc),
+                                                    _native.stream_ptr()), "afd_moments_accumulate")
+
+    def finalize(self):
+        n, s, q = (float(v) for v in self.acc.cpu())
+        mean = s / n
+        var = max(q / n - mean * mean, 0.0)
+        return (torch.tensor([mean], dtype=torch.float32), torch.tensor([var ** 0.5], dtype=torch.float32))
+
+
 def normalize_forward(t: torch.Tensor, mean: float, std: float) -> torch.Tensor:
     """(t - mean) / std, out of place, in the memory order of `t`."""
     _native.require_gpu()

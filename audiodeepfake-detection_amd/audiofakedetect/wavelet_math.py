@@ -283,12 +283,21 @@ def calc_normalization(args: DotDict, pbar: bool, transforms: torch.nn.Sequentia
     )
     loader = torch.utils.data.DataLoader(dataset, batch_size=4000, shuffle=False,
                                          num_workers=0)
-    welford = WelfordEstimator()
+    from .ops import ScalarMoments
+
+    # single-channel features: the reference's per-channel Welford over [B, T, P, C=1] is a
+    # scalar mean / std; two-channel (loss-less) features keep the per-channel estimator
+    welford = None
     welford_dict = None
     with torch.no_grad():
         for batch in loader:
             feats, welford_dict = transforms(batch["audio"].cuda(non_blocking=True))
-            welford.update(feats.permute(0, 3, 2, 1))
+            if welford is None:
+                welford = ScalarMoments(feats.device) if feats.shape[1] == 1 else WelfordEstimator()
+            if isinstance(welford, ScalarMoments):
+                welford.update(feats)
+            else:
+                welford.update(feats.permute(0, 3, 2, 1))
         mean, std = welford.finalize()
     os.makedirs(os.path.dirname(norm_dir), exist_ok=True)
     with open(f"{norm_dir}_mean_std.pkl", "wb") as f:

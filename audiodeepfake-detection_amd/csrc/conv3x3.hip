@@ -56,7 +56,7 @@ __global__ void repack3_kernel(const float* __restrict__ w, float* __restrict__ 
 
 // MW x NW 32x32 tiles per wave, WNB waves along the pixel axis; PIX = NW * WNB * 32
 template <int MW, int NW, int WMB, int WNB, bool PF>
-__global__ void __launch_bounds__(WMB * WNB * 64) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(WMB * WNB * 64) __attribute__((amdgpu_waves_per_eu(MW * NW <= 3 ? 3 : 2)))
 conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ y) {
     constexpr int NT = WMB * WNB * 64;

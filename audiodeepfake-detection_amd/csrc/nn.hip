@@ -557,6 +557,61 @@ inline unsigned grid1d(size_t n, int cap = 4096) {
 
 #define AFD_STREAM static_cast<hipStream_t>(stream)
 
+// grid-stride double-precision sum / sum of squares; one double atomic pair per workgroup
+__global__ void __launch_bounds__(256)
+moments_kernel(const float* __restrict__ x, size_t n, double* __restrict__ acc) {
+    __shared__ double red[2][4];
+    double s = 0.0, q = 0.0;
+    const size_t n4 = n >> 2;
+    // head to a 16-byte boundary is not needed: feature tensors come from the allocator
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    const bool aligned = (reinterpret_cast<size_t>(x) & 15) == 0;
+    if (aligned) {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 v = x4[i];
+            const float a = v.x + v.y, b = v.z + v.w;
+            const float qa = fmaf(v.x, v.x, v.y * v.y), qb = fmaf(v.z, v.z, v.w * v.w);
+            s += (double)a + (double)b;
+            q += (double)qa + (double)qb;
+        }
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            s += x[i];
+            q += (double)x[i] * x[i];
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+            s += x[i];
+            q += (double)x[i] * x[i];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        q += __shfl_down(q, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wave] = s;
+        red[1][wave] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(acc + 1, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]));
+        atomicAdd(acc + 2, (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        if (blockIdx.x == 0) atomicAdd(acc, (double)n);
+    }
+}
+
+extern "C" int afd_moments_accumulate(const float* x, size_t n, double* acc, afd_stream_t stream) {
+    if (!x || !acc) return afd::fail(AFD_ERR_ARG, "moments: null pointer");
+    if (n == 0) return AFD_OK;
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(moments_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, acc);
+    return afd::check_launch("moments_kernel");
+}
+
 extern "C" int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,
                                      afd_stream_t stream) {
     if (!x || !y || std == 0.f) return afd::fail(AFD_ERR_ARG, "normalize: bad argument");

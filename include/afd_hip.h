@@ -135,6 +135,12 @@ int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx,
  * HBM-bound layers.  `slope` is the device address of the single shared PReLU parameter
  * (nn.PReLU(), models.py:258); where it is "may be NULL" the PReLU is skipped.
  * ---------------------------------------------------------------------------------- */
+/* Scalar moments of the transformed training set: replaces the per-batch WelfordEstimator
+ * update of calc_normalization (wavelet_math.py:387-452, data_loader.py:27-71).
+ * acc[0] += n, acc[1] += sum x, acc[2] += sum x^2, accumulated in double precision
+ * (acc is device memory, zeroed by the caller before the first batch). */
+int afd_moments_accumulate(const float* x, size_t n, double* acc, afd_stream_t stream);
+
 /* torchvision Normalize with scalar statistics (wavelet_math.py:380-382): y = (x-mean)/std */
 int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,
                           afd_stream_t stream);

@@ -266,3 +266,25 @@ def test_fused_conv1_prelu_pool(shape, cout, pad, slope):
     _close(wg.grad, wr.grad, 2e-5, "conv1 fused dw")
     _close(bg.grad, br.grad, 2e-5, "conv1 fused db")
     _close(ag.grad, ar.grad, 1e-4, "conv1 fused dslope")
+
+
+def test_scalar_moments_match_welford_and_torch():
+    # calc_normalization's statistics (wavelet_math.py:387-452): fused double-precision
+    # reduction vs the reference's Welford update chain and vs torch in float64
+    from audiofakedetect.data_loader import WelfordEstimator
+
+    g = torch.Generator().manual_seed(5)
+    batches = [(-12.0 + 5.0 * torch.randn(3, 1, 257, 41, generator=g)) for _ in range(4)]
+    mom = ops.ScalarMoments(torch.device("cuda"))
+    wel = WelfordEstimator()
+    for b in batches:
+        mom.update(b.cuda())
+        mom.update(b.cuda()[..., 1:])  # non-contiguous view, odd element count
+        wel.update(b.permute(0, 3, 2, 1))
+        wel.update(b[..., 1:].permute(0, 3, 2, 1))
+    mean, std = mom.finalize()
+    allv = torch.cat([torch.cat([b.reshape(-1), b[..., 1:].reshape(-1)]) for b in batches]).double()
+    assert abs(mean.item() - allv.mean().item()) <= 1e-6 * abs(allv.mean().item())
+    assert abs(std.item() - allv.std(unbiased=False).item()) <= 1e-6 * allv.std().item()
+    wm, ws = wel.finalize()
+    assert abs(mean.item() - wm.item()) <= 1e-4 and abs(std.item() - ws.item()) <= 1e-4
