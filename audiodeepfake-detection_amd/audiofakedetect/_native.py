@@ -45,6 +45,8 @@ _SIGNATURES = {
     "afd_conv2d_forward": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     "afd_conv2d_backward_data": (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     "afd_conv2d_backward_weight": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
+    "afd_conv2d_forward_cropped": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
+    "afd_conv2d_backward_weight_cropped": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
     "afd_conv1_pool_workspace_bytes": (c_sz, [c_i] * 5),
     "afd_conv1_pool_forward": (c_i, [c_p] * 6 + [c_i] * 5 + [c_p]),
     "afd_conv1_pool_backward": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p]),

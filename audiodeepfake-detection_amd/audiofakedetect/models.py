@@ -75,7 +75,7 @@ class DCNN(nn.Module):
                 if bn_i is not None:
                     h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
                 continue
-            z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
+            z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled)
             if pooled:
                 h = ops.prelu_maxpool2x2(z, slope)
                 if bn_i is not None:

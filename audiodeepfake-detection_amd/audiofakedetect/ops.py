@@ -118,7 +118,7 @@ def transpose_contiguous(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, pad, dil):
+    def forward(ctx, x, w, b, pad, dil, pooled):
         lib = _lib()
         x = _f32c(x)
         w = _f32c(w)
@@ -126,16 +126,21 @@ class _Conv2d(torch.autograd.Function):
         cout, _, k, _ = w.shape
         ho = h + 2 * pad - dil * (k - 1)
         wo = wd + 2 * pad - dil * (k - 1)
+        # a 2x2/2 max-pool follows: the odd last row / column of y is never read and its
+        # gradient is zero (nn.MaxPool2d floor mode)
+        crop = (2 * (ho // 2), 2 * (wo // 2)) if pooled else (ho, wo)
         if ho < 1 or wo < 1:
             raise ValueError(f"conv2d: empty output for input {tuple(x.shape)}, k={k}, pad={pad}, dil={dil}")
         y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
         nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
         ws = _ws(nbytes, x.device)
-        _native.check(lib.afd_conv2d_forward(
+        _native.check(lib.afd_conv2d_forward_cropped(
             _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(y), n, cin, h, wd, cout, k,
-            pad, dil, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_forward")
+            pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+            "afd_conv2d_forward")
         ctx.save_for_backward(x, w)
         ctx.geom = (n, cin, h, wd, cout, k, pad, dil)
+        ctx.crop = crop
         ctx.has_bias = b is not None
         return y
 
@@ -156,15 +161,17 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            _native.check(lib.afd_conv2d_backward_weight(
+            _native.check(lib.afd_conv2d_backward_weight_cropped(
                 _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
-                cout, k, pad, dil, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
-                "afd_conv2d_backward_weight")
-        return dx, dw, db, None, None
+                cout, k, pad, dil, ctx.crop[0], ctx.crop[1], _native.ptr(ws), ws.numel(),
+                _native.stream_ptr()), "afd_conv2d_backward_weight")
+        return dx, dw, db, None, None, None
 
 
-def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1):
-    return _Conv2d.apply(x, w, b, int(padding), int(dilation))
+def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1, pooled: bool = False):
+    """``pooled=True``: the result only feeds ``prelu_maxpool2x2`` (whose backward zeroes the
+    gradient of an odd last row / column), so those need not be computed."""
+    return _Conv2d.apply(x, w, b, int(padding), int(dilation), bool(pooled))
 
 
 # --------------------------------------------------------------------------------------

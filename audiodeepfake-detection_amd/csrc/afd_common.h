@@ -66,13 +66,14 @@ int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* d
 bool conv3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 size_t conv3x3_workspace_bytes(int Cin, int Cout);
 int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H,
-                int W, int Cout, int dgrad, void* ws, size_t ws_bytes, hipStream_t s);
+                int W, int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes,
+                hipStream_t s);
 
 bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
-void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int* S, int* nchunks, int* CI_T,
-                       int* CO_PAD, int* NCOL);
+void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int dz_cols, int* S,
+                       int* nchunks, int* CI_T, int* CO_PAD, int* NCOL);
 int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, int N, int Cin, int H,
-                    int W, int Cout, hipStream_t s);
+                    int W, int Cout, int dz_rows, int dz_cols, hipStream_t s);
 
 constexpr int kWave = 64;
 constexpr int kLdsBytes = 160 * 1024;  // per-CU LDS on gfx950

@@ -1285,7 +1285,7 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
     }
     if (afd::wgrad3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
         int S3, nch3, ct3, cop3, ncol3;
-        afd::wgrad3x3_geometry(N, Cin, H, W, Cout, &S3, &nch3, &ct3, &cop3, &ncol3);
+        afd::wgrad3x3_geometry(N, Cin, H, W, Cout, Hout, Wout, &S3, &nch3, &ct3, &cop3, &ncol3);
         const size_t b = align_up(((size_t)S3 * nch3 * cop3 * ncol3 + (size_t)S3 * cop3) * 4);
         if (b > need) need = b;
     }
@@ -1322,14 +1322,25 @@ static int check_conv_args(const void* a, const void* b, const void* c, int N, i
 extern "C" int afd_conv2d_forward(const float* x, const float* w, const float* bias, float* y,
                                   int N, int Cin, int H, int W, int Cout, int K, int pad, int dil,
                                   void* ws, size_t ws_bytes, afd_stream_t stream) {
+    return afd_conv2d_forward_cropped(x, w, bias, y, N, Cin, H, W, Cout, K, pad, dil, 0x7fffffff,
+                                      0x7fffffff, ws, ws_bytes, stream);
+}
+
+// only the 3x3 wide-image kernel makes use of the crop; the other paths compute all of y
+extern "C" int afd_conv2d_forward_cropped(const float* x, const float* w, const float* bias, float* y,
+                                          int N, int Cin, int H, int W, int Cout, int K, int pad,
+                                          int dil, int out_rows, int out_cols, void* ws,
+                                          size_t ws_bytes, afd_stream_t stream) {
     int rc = check_conv_args(x, w, y, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
+    if (out_rows < 1 || out_cols < 1) return afd::fail(AFD_ERR_ARG, "conv fwd: empty crop");
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_forward(x, w, bias, y, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
         return afd::conv1x1_forward(x, w, bias, y, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
     if (afd::conv3x3_applicable(Cin, H, W, Cout, K, pad, dil))
-        return afd::conv3x3_run(x, w, bias, y, N, Cin, H, W, Cout, 0, ws, ws_bytes, static_cast<hipStream_t>(stream));
+        return afd::conv3x3_run(x, w, bias, y, N, Cin, H, W, Cout, 0, out_rows, out_cols, ws, ws_bytes,
+                                static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     ConvGeom g;
@@ -1357,7 +1368,8 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
         return afd::conv1x1_backward_data(dy, w, dx, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
     if (afd::conv3x3_applicable(Cout, H, W, Cin, K, dil * (K - 1) - pad, dil))
-        return afd::conv3x3_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, ws, ws_bytes, static_cast<hipStream_t>(stream));
+        return afd::conv3x3_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes,
+                                static_cast<hipStream_t>(stream));
     const int Hout = H + 2 * pad - dil * (K - 1);
     const int Wout = W + 2 * pad - dil * (K - 1);
     const int padd = dil * (K - 1) - pad;
@@ -1379,8 +1391,18 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
 extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw, float* dbias,
                                           int N, int Cin, int H, int W, int Cout, int K, int pad,
                                           int dil, void* ws, size_t ws_bytes, afd_stream_t stream) {
+    return afd_conv2d_backward_weight_cropped(x, dy, dw, dbias, N, Cin, H, W, Cout, K, pad, dil,
+                                              0x7fffffff, 0x7fffffff, ws, ws_bytes, stream);
+}
+
+extern "C" int afd_conv2d_backward_weight_cropped(const float* x, const float* dy, float* dw,
+                                                  float* dbias, int N, int Cin, int H, int W,
+                                                  int Cout, int K, int pad, int dil, int dy_rows,
+                                                  int dy_cols, void* ws, size_t ws_bytes,
+                                                  afd_stream_t stream) {
     int rc = check_conv_args(x, dy, dw, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
+    if (dy_rows < 1 || dy_cols < 1) return afd::fail(AFD_ERR_ARG, "conv wgrad: empty crop");
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_backward_weight(x, dy, dw, dbias, N, Cin, H, W, K, pad, dil, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
@@ -1390,12 +1412,12 @@ extern "C" int afd_conv2d_backward_weight(const float* x, const float* dy, float
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (afd::wgrad3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
         int S3, nch3, ct3, cop3, ncol3;
-        afd::wgrad3x3_geometry(N, Cin, H, W, Cout, &S3, &nch3, &ct3, &cop3, &ncol3);
+        afd::wgrad3x3_geometry(N, Cin, H, W, Cout, dy_rows, dy_cols, &S3, &nch3, &ct3, &cop3, &ncol3);
         const size_t slabs = (size_t)S3 * nch3 * cop3 * ncol3;
         if (!ws || ws_bytes < (slabs + (size_t)S3 * cop3) * 4) return afd::fail(AFD_ERR_WORKSPACE, "conv wgrad: workspace too small");
         float* part3 = static_cast<float*>(ws);
         float* partb3 = part3 + slabs;
-        rc = afd::wgrad3x3_launch(x, dy, part3, partb3, N, Cin, H, W, Cout, s);
+        rc = afd::wgrad3x3_launch(x, dy, part3, partb3, N, Cin, H, W, Cout, dy_rows, dy_cols, s);
         if (rc) return rc;
         const int total3 = Cout * Cin * K * K;
         const int nblk3 = (total3 + 31) / 32 + (dbias ? (Cout + 31) / 32 : 0);

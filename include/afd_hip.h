@@ -116,6 +116,20 @@ int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
                                afd_stream_t stream);
 
+/* The same two calls for a convolution whose result feeds nn.MaxPool2d(2, 2) (models.py:264,
+ * floor mode): the pool never reads an odd last row / column of y, and its backward leaves them
+ * zero in dy.  Only y[.., :out_rows, :out_cols] is computed (the rest of y is left untouched);
+ * dy is taken to be zero outside [:dy_rows, :dy_cols].  Pass the full extents for the plain
+ * behaviour. */
+int afd_conv2d_forward_cropped(const float* x, const float* w, const float* bias, float* y, int N,
+                               int Cin, int H, int W, int Cout, int K, int pad, int dil,
+                               int out_rows, int out_cols, void* ws, size_t ws_bytes,
+                               afd_stream_t stream);
+int afd_conv2d_backward_weight_cropped(const float* x, const float* dy, float* dw, float* dbias,
+                                       int N, int Cin, int H, int W, int Cout, int K, int pad,
+                                       int dil, int dy_rows, int dy_cols, void* ws,
+                                       size_t ws_bytes, afd_stream_t stream);
+
 /* First block for single-channel inputs, fused: Conv2d(1 -> Cout, 3x3, pad) + PReLU +
  * MaxPool2d(2,2) (reference models.py:255-259 with args.input_dim[1] == 1).  Forward writes
  * only the pooled tensor u [N][Cout][Hp][Wp] and the 3-bit code idx (as afd_prelu_pool_*);

@@ -288,3 +288,27 @@ def test_scalar_moments_match_welford_and_torch():
     assert abs(std.item() - allv.std(unbiased=False).item()) <= 1e-6 * allv.std().item()
     wm, ws = wel.finalize()
     assert abs(mean.item() - wm.item()) <= 1e-4 and abs(std.item() - ws.item()) <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 7, 1027, 96), (2, 32, 6, 1100, 64), (1, 16, 5, 1025, 32)])
+def test_conv_feeding_maxpool_skips_the_unused_row_and_column(shape):
+    # conv2d(pooled=True) + prelu_maxpool2x2 against conv -> PReLU -> MaxPool2d(2, 2) in float64:
+    # the odd last row / column of the conv output is neither produced nor differentiated
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    slope = torch.tensor([0.25])
+    xr, wr, br, sr = (t.double().requires_grad_() for t in (x, wt, b, slope))
+    yr = F.max_pool2d(F.prelu(F.conv2d(xr, wr, br, padding=1), sr), 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg, wg, bg, sg = (t.cuda().requires_grad_() for t in (x, wt, b, slope))
+    yg = ops.prelu_maxpool2x2(ops.conv2d(xg, wg, bg, 1, 1, pooled=True), sg)
+    _close(yg, yr.detach(), 2e-5, "conv+pool fwd")
+    yg.backward(dy.cuda())
+    _close(xg.grad, xr.grad, 2e-5, "dgrad")
+    _close(wg.grad, wr.grad, 3e-5, "wgrad")
+    _close(bg.grad, br.grad, 2e-5, "dbias")
+    _close(sg.grad, sr.grad, 1e-4, "dslope")

@@ -9,6 +9,7 @@ SHAPES = {
     "conv1": (32, 1, 24, 16384, 64, 3, 2, 1),
     "conv2": (32, 64, 13, 8193, 64, 1, 0, 1),
     "conv3": (32, 64, 13, 8193, 96, 3, 1, 1),
+    "conv3p": (32, 64, 12, 8192, 96, 3, 1, 1),
     "conv4": (32, 96, 6, 4096, 128, 3, 1, 1),
     "conv5": (32, 128, 6, 4096, 32, 3, 1, 1),
     "conv6": (32, 32, 6, 4096, 64, 3, 1, 1),
