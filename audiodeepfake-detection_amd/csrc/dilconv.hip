@@ -246,7 +246,7 @@ int run_direct(DirGeom g, const float* in, const float* w, const float* bias, fl
     return afd::check_launch("dilconv_direct_kernel");
 }
 
-constexpr int kWgradBlocks = 1024;
+constexpr int kWgradBlocks = 1021;  // prime: a count sharing a factor with the tiles per row walks tile columns in lock step
 
 template <int C, int K, int DIL>
 int run_wgrad(DirGeom g, const float* x, const float* dy, float* dw, float* dbias, float* partial,
