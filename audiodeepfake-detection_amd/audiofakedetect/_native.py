@@ -68,6 +68,7 @@ _SIGNATURES = {
     "afd_mfm_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_gemm_nt": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
     "afd_lstm_cell": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "afd_lstm_cell_backward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "afd_cross_entropy": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     "afd_adam_step": (c_i, [c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_p]),
 }

@@ -4,8 +4,8 @@ Layer objects hold parameters / buffers under the reference's state_dict keys (`
 ``lstm.K.l_blstm.*``, ``fc.*``); ``forward`` drives HIP kernels: conv (MFMA implicit GEMM),
 max-feature-map, max-pool, BatchNorm, dropout+permute, and the two bidirectional LSTM layers as
 input/recurrent projections on ``afd_gemm_nt`` plus the fused cell kernel.  The convolutional
-trunk supports backward; the LSTM backward pass is not built yet (config 5 of BASELINE.json is
-an evaluation workload) and raises if a gradient is requested through it.
+trunk and the LSTM layers support backward (BPTT over the handful of time steps left after the
+four pools, ``afd_lstm_cell_backward`` + the same GEMM kernel).
 """
 
 from __future__ import annotations
@@ -73,7 +73,13 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate: b
 
 
 class _BLSTM(torch.autograd.Function):
-    """Bidirectional single-layer LSTM forward, x [B,T,D] -> [B,T,2H] (nn.LSTM semantics)."""
+    """Bidirectional single-layer LSTM, x [B,T,D] -> [B,T,2H] (nn.LSTM semantics).
+
+    Forward: one input projection GEMM per direction, then per step the recurrent projection
+    accumulated into the step's gate rows (``afd_gemm_nt``) and the fused cell kernel.  For the
+    backward pass the gate pre-activations and the cell states of every step are kept; BPTT runs
+    ``afd_lstm_cell_backward`` per step and the same GEMM kernel for dh, dx, dW.
+    """
 
     @staticmethod
     def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
@@ -82,11 +88,14 @@ class _BLSTM(torch.autograd.Function):
         h = w_hh.shape[1]
         xt = x.permute(1, 0, 2).contiguous().view(steps * bsz, d)  # [T*B, D]
         out = torch.empty((steps, bsz, 2 * h), dtype=torch.float32, device=x.device)
+        keep = any(ctx.needs_input_grad)
+        saved = []
         for direction, (wi, wh, bi, bh) in enumerate(((w_ih, w_hh, b_ih, b_hh),
                                                       (w_ih_r, w_hh_r, b_ih_r, b_hh_r))):
             pre = gemm_nt(xt, ops._f32c(wi), bi + bh).view(steps, bsz, 4 * h)
             hs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
             cs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+            c_all = torch.empty((steps, bsz, h), dtype=torch.float32, device=x.device) if keep else None
             whc = ops._f32c(wh)
             order = range(steps) if direction == 0 else range(steps - 1, -1, -1)
             for t in order:
@@ -96,13 +105,52 @@ class _BLSTM(torch.autograd.Function):
                 _native.check(lib.afd_lstm_cell(_native.ptr(gates), _native.ptr(cs), _native.ptr(hout),
                                                 _native.ptr(hs), bsz, h, 2 * h, _native.stream_ptr()),
                               "afd_lstm_cell")
+                if keep:
+                    c_all[t].copy_(cs)
+            saved += [pre, c_all]
+        if keep:
+            ctx.save_for_backward(xt, out, ops._f32c(w_ih), ops._f32c(w_hh), ops._f32c(w_ih_r),
+                                  ops._f32c(w_hh_r), *saved)
+            ctx.dims = (bsz, steps, d, h)
         return out.permute(1, 0, 2).contiguous()
 
     @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(
-            "LCNN: the LSTM backward pass is not built yet (BASELINE config 5 is an evaluation "
-            "workload); run LCNN under torch.no_grad() / eval")
+    def backward(ctx, dy):
+        lib = _native.load()
+        xt, out, w_ih, w_hh, w_ih_r, w_hh_r, pre_f, c_f, pre_r, c_r = ctx.saved_tensors
+        bsz, steps, d, h = ctx.dims
+        dout = ops._f32c(dy).permute(1, 0, 2).contiguous()  # [T, B, 2H]
+        dx = torch.zeros((steps * bsz, d), dtype=torch.float32, device=dy.device)
+        grads = []
+        for direction, (wi, wh, pre, c_all) in enumerate(((w_ih, w_hh, pre_f, c_f),
+                                                          (w_ih_r, w_hh_r, pre_r, c_r))):
+            wh_t = wh.t().contiguous()  # [H, 4H]: dh_prev = dpre @ W_hh
+            dpre = torch.empty((steps, bsz, 4 * h), dtype=torch.float32, device=dy.device)
+            dc = torch.zeros((bsz, h), dtype=torch.float32, device=dy.device)
+            dh = torch.zeros((bsz, h), dtype=torch.float32, device=dy.device)
+            hprev = torch.zeros((steps, bsz, h), dtype=torch.float32, device=dy.device)
+            order = list(range(steps)) if direction == 0 else list(range(steps - 1, -1, -1))
+            for pos in range(len(order) - 1, -1, -1):  # reverse of the processing order
+                t = order[pos]
+                tprev = order[pos - 1] if pos > 0 else None
+                dh.add_(dout[t, :, direction * h:(direction + 1) * h])
+                _native.check(lib.afd_lstm_cell_backward(
+                    _native.ptr(pre[t]), _native.ptr(c_all[t]),
+                    _native.ptr(c_all[tprev]) if tprev is not None else None, _native.ptr(dh), h,
+                    _native.ptr(dc), _native.ptr(dpre[t]), bsz, h, _native.stream_ptr()),
+                    "afd_lstm_cell_backward")
+                if tprev is not None:
+                    hprev[t].copy_(out[tprev, :, direction * h:(direction + 1) * h])
+                    gemm_nt(dpre[t], wh_t, None, out=dh)  # gradient reaching h_{t_prev}
+            dpre2 = dpre.view(steps * bsz, 4 * h)
+            dpre2_t = dpre2.t().contiguous()  # [4H, T*B]
+            gemm_nt(dpre2, wi.t().contiguous(), None, out=dx, accumulate=True)       # dx += dpre @ W_ih
+            dwi = gemm_nt(dpre2_t, xt.t().contiguous())                              # dpre^T @ x
+            dwh = gemm_nt(dpre2_t, hprev.view(steps * bsz, h).t().contiguous())      # dpre^T @ h_prev
+            db = dpre2.sum(0)
+            grads += [dwi, dwh, db, db.clone()]
+        dx = dx.view(steps, bsz, d).permute(1, 0, 2).contiguous()
+        return (dx, *grads)
 
 
 class BLSTMLayer(nn.Module):

@@ -119,6 +119,35 @@ __global__ void lstm_cell_kernel(const float* __restrict__ gates, float* __restr
     }
 }
 
+// One backward step of the cell.  gates = the saved pre-activation sums of the step, c / cprev
+// the cell state after / before it (cprev may be NULL: zero), dh = gradient reaching h_t
+// (layer output gradient + recurrent part), dc = running cell-state gradient (in: from step
+// t+1, out: for step t-1), dpre = gradient of the pre-activations [B][4H].
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c,
+                                     const float* __restrict__ cprev, const float* __restrict__ dh,
+                                     int lddh, float* __restrict__ dc, float* __restrict__ dpre, int Bn,
+                                     int H) {
+    const int total = Bn * H;
+    for (int idx = blockIdx.x * kT + threadIdx.x; idx < total; idx += gridDim.x * kT) {
+        const int b = idx / H, j = idx - b * H;
+        const float* g = gates + (size_t)b * 4 * H;
+        const float ig = sigmoidf_(g[j]);
+        const float fg = sigmoidf_(g[H + j]);
+        const float gg = tanhf(g[2 * H + j]);
+        const float og = sigmoidf_(g[3 * H + j]);
+        const float tc = tanhf(c[idx]);
+        const float dhv = dh[(size_t)b * lddh + j];
+        const float dcv = fmaf(dhv * og, 1.f - tc * tc, dc[idx]);
+        const float cp = cprev ? cprev[idx] : 0.f;
+        float* d = dpre + (size_t)b * 4 * H;
+        d[j] = dcv * gg * ig * (1.f - ig);
+        d[H + j] = dcv * cp * fg * (1.f - fg);
+        d[2 * H + j] = dcv * ig * (1.f - gg * gg);
+        d[3 * H + j] = dhv * tc * og * (1.f - og);
+        dc[idx] = dcv * fg;
+    }
+}
+
 inline unsigned grid1(size_t n) {
     size_t b = (n + kT - 1) / kT;
     return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -162,4 +191,14 @@ extern "C" int afd_lstm_cell(const float* gates, float* c, float* hout, float* h
     hipLaunchKernelGGL(lstm_cell_kernel, dim3(grid1((size_t)B * H)), dim3(kT), 0, AFD_STREAM, gates, c,
                        hout, hstate, B, H, ldh);
     return afd::check_launch("lstm_cell_kernel");
+}
+
+extern "C" int afd_lstm_cell_backward(const float* gates, const float* c, const float* cprev,
+                                      const float* dh, int lddh, float* dc, float* dpre, int B, int H,
+                                      afd_stream_t stream) {
+    if (!gates || !c || !dh || !dc || !dpre || B < 1 || H < 1 || lddh < H)
+        return afd::fail(AFD_ERR_ARG, "lstm cell bwd: bad argument");
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid1((size_t)B * H)), dim3(kT), 0, AFD_STREAM, gates, c,
+                       cprev, dh, lddh, dc, dpre, B, H);
+    return afd::check_launch("lstm_cell_bwd_kernel");
 }

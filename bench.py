@@ -47,6 +47,7 @@ WORKLOADS = {
     "stft": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + DCNN train step"),
     # BASELINE configs[4]: evaluation (forward + argmax) of the LCNN head on STFT features
     "stft-lcnn-eval": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + LCNN eval forward (fp32)"),
+    "stft-lcnn": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + LCNN train step (fp32)"),
 }
 
 
@@ -73,7 +74,7 @@ def build(workload: str, batch: int, ddp: bool, device):
     # flattened size of the dil_conv output: [time_dim, 64-24=40, P/8-24]
     p8 = args.input_dim[2] // 8
     args.flattend_size = (64 - 24) * (p8 - 24)
-    if workload.endswith("lcnn-eval"):
+    if "lcnn" in workload:
         from audiofakedetect.lcnn import LCNN
 
         model = LCNN(classes=2, in_channels=1, lstm_channels=scales).to(device)

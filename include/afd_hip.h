@@ -224,6 +224,13 @@ int afd_gemm_nt(const float* A, const float* B, const float* bias, float* C, int
                 int lda, int ldb, int ldc, int accumulate, afd_stream_t stream);
 int afd_lstm_cell(const float* gates, float* c, float* hout, float* hstate, int B, int H, int ldh,
                   afd_stream_t stream);
+/* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):
+ * gates = saved pre-activation sums [B][4H] of the step, c / cprev = cell state after / before it
+ * (cprev NULL = zero), dh = gradient reaching h_t (row stride lddh), dc = running cell-state
+ * gradient [B][H] (updated in place for the previous step), dpre = gradient of the
+ * pre-activations [B][4H]. */
+int afd_lstm_cell_backward(const float* gates, const float* c, const float* cprev, const float* dh,
+                           int lddh, float* dc, float* dpre, int B, int H, afd_stream_t stream);
 
 /* CrossEntropyLoss (mean) + its gradient + number of correct argmax predictions
  * (train_classifier.py:970-979); dlogits / correct may be NULL */

@@ -50,8 +50,66 @@ def test_lcnn_eval_logits_match_reference():
     assert torch.equal(y.argmax(-1).cpu(), g["labels"])
 
 
-def test_lcnn_lstm_backward_is_loud():
-    net = LCNN().cuda().train()
-    out = net(torch.randn(2, 1, 256, 101, device="cuda"))
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
+def test_blstm_layer_forward_backward_matches_nn_lstm():
+    # BLSTMLayer (reference models.py:212-237) = bidirectional nn.LSTM over [T, B, D] seen as
+    # [B, T, D]; float64 torch on the CPU is the reference
+    from audiofakedetect.lcnn import BLSTMLayer
+
+    torch.manual_seed(3)
+    bsz, steps, d = 5, 6, 64
+    layer = BLSTMLayer(d, d)
+    ref = torch.nn.LSTM(d, d // 2, bidirectional=True).double()
+    ref.load_state_dict({k: v.double() for k, v in layer.l_blstm.state_dict().items()})
+    x = torch.randn(bsz, steps, d)
+    xr = x.double().requires_grad_()
+    yr = ref(xr.permute(1, 0, 2))[0].permute(1, 0, 2)
+    dy = torch.randn(yr.shape)
+    yr.backward(dy.double())
+    layer.cuda()
+    xg = x.cuda().requires_grad_()
+    yg = layer(xg)
+    yg.backward(dy.cuda())
+    assert (yg.detach().cpu().double() - yr.detach()).abs().max().item() <= 2e-6
+    assert (xg.grad.cpu().double() - xr.grad).abs().max().item() <= 2e-5 * xr.grad.abs().max().item()
+    refg = dict(ref.named_parameters())
+    for k, p in layer.l_blstm.named_parameters():
+        err = (p.grad.cpu().double() - refg[k].grad).abs().max().item()
+        assert err <= 3e-5 * refg[k].grad.abs().max().item(), (k, err)
+
+
+def test_lcnn_train_step_matches_cpu_restatement():
+    # forward + backward of the whole LCNN (dropout off) against oracle/torch_ref.LCNNRef, which
+    # tests/test_oracle_dcnn.py pins on the reference's own LCNN class
+    from oracle import torch_ref
+    from recipes import fill_state_dict
+
+    g = torch.load(os.path.join(GOLD, "dcnn_lcnn_eval.pt"), map_location="cpu")
+    net = LCNN()
+    net.load_state_dict(fill_state_dict(g["shapes"]), strict=True)
+    ref = torch_ref.LCNNRef()
+    ref.load_state_dict(net.state_dict())
+    for m in (net, ref):
+        m.train()
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    net.cuda()
+    x = g["x"]
+    labels = torch.arange(x.shape[0]) % 2
+    out = net(x.cuda())
+    loss = torch.nn.functional.cross_entropy(out, labels.cuda())
+    loss.backward()
+    out_ref = ref(x)
+    loss_ref = torch.nn.functional.cross_entropy(out_ref, labels)
+    loss_ref.backward()
+    assert (out.detach().cpu() - out_ref.detach()).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_ref.item()) <= 1e-5
+    num = den = 0.0
+    refp = dict(ref.named_parameters())
+    for k, p in net.named_parameters():
+        assert p.grad is not None, k
+        d = p.grad.cpu() - refp[k].grad
+        num += d.pow(2).sum().item()
+        den += refp[k].grad.pow(2).sum().item()
+    # max-feature-map / max-pool near ties bound element-wise agreement (see test_dcnn_gpu.py)
+    assert (num / den) ** 0.5 <= 5e-3, (num / den) ** 0.5
