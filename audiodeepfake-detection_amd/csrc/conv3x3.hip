@@ -33,7 +33,7 @@ struct G3 {
     int pad;                 // 1 (forward) or 1 (backward-data of pad 1): out = in + 2 pad - 2
     int Hout, Wout;
     int Hc, Wc;  // computed extent (<= Hout, Wout): rows / columns beyond are not produced
-    int nchunks, tilesX;
+    int nchunks, tilesX, tilesY;
 };
 
 // weights w[Cout][Cin][3][3] -> wp[chunk][kstep = (pair, ky, kx)][parity][CO_PAD]
@@ -55,15 +55,22 @@ __global__ void repack3_kernel(const float* __restrict__ w, float* __restrict__ 
     }
 }
 
-// MW x NW 32x32 tiles per wave, WNB waves along the pixel axis; PIX = NW * WNB * 32
-template <int MW, int NW, int WMB, int WNB, bool PF>
+// MW x NW 32x32 tiles per wave, WNB waves along the pixel axis; PIX = NW * WNB * 32 pixels per
+// workgroup, arranged as TH rows of TW columns: TW = PIX (one row; wide level-14 images) or
+// TW = 32 (PIX / 32 rows; the narrow level-8 / STFT / LCNN images).  The LDS patch pitch depends
+// on the tile shape only, never on the image width, so the fragment offsets stay immediates.
+template <int MW, int NW, int WMB, int WNB, bool PF, int TW>
 __global__ void __launch_bounds__(WMB * WNB * 64) __attribute__((amdgpu_waves_per_eu(MW * NW <= 3 ? 3 : 2)))
 conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ y) {
     constexpr int NT = WMB * WNB * 64;
     constexpr int CO_PAD = MW * WMB * 32;
     constexpr int PIX = NW * WNB * 32;
-    constexpr int PC = PIX + 4;  // 2 halo columns + 2 of padding: whole groups of four per row
+    static_assert(TW == 32 || TW == PIX, "tile width");
+    constexpr int TH = PIX / TW;
+    constexpr int kPR = TH + 2;  // patch rows (shadows the one-row constant of the file)
+    constexpr int PC = TW + 4;   // 2 halo columns + 2 of padding: whole groups of four per row
+    constexpr int STEP = TW == 32 ? PC : 32;  // patch offset between consecutive 32-pixel tiles
     constexpr int G4 = PC / 4;
     constexpr int WFLOATS = kKsteps * 2 * CO_PAD;
     constexpr int PFLOATS = kCT * kPR * PC;
@@ -76,12 +83,13 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
     const int lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wmb = wave % WMB, wnb = wave / WMB;
-    const int tpi = g.tilesX * g.Hc;
+    const int tpi = g.tilesX * g.tilesY;
     const int n = blockIdx.x / tpi;
     const int t = blockIdx.x - n * tpi;
-    const int oy = t / g.tilesX;
-    const int ox0 = (t - oy * g.tilesX) * PIX;
-    const int iy0 = oy - g.pad, ix0 = ox0 - g.pad;
+    const int ty = t / g.tilesX;
+    const int oy0 = ty * TH;
+    const int ox0 = (t - ty * g.tilesX) * TW;
+    const int iy0 = oy0 - g.pad, ix0 = ox0 - g.pad;
     const size_t iplane = (size_t)g.H * g.W;
 
     // per-thread staging offsets (elements), constant over the chunks
@@ -97,7 +105,7 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
 
     // fragment bases (floats): A = wl + parity row + channel column, B = patch + parity plane + pixel
     const float* abase = wl + half * CO_PAD + wmb * MW * 32 + l31;
-    const float* bbase = patch + half * kPR * PC + wnb * NW * 32 + l31;
+    const float* bbase = patch + half * kPR * PC + wnb * NW * STEP + l31;
 
     f32x16 acc[MW][NW];
 #pragma unroll
@@ -134,9 +142,13 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
                 f32x4u v = {0.f, 0.f, 0.f, 0.f};
                 if (item < kCT * kPR * G4 && iy >= 0 && iy < g.H) {
                     const float* src4 = xc + (size_t)ci_l * iplane + (size_t)iy * g.W + ix;
+                    if (ix >= 0 && ix + 3 < g.W) {
+                        v = *reinterpret_cast<const f32x4u*>(src4);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (ix + j >= 0 && ix + j < g.W) v[j] = src4[j];
+                        for (int j = 0; j < 4; ++j)
+                            if (ix + j >= 0 && ix + j < g.W) v[j] = src4[j];
+                    }
                 }
                 pv[u] = v;
             }
@@ -173,7 +185,7 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
 #pragma unroll
         for (int m = 0; m < MW; ++m) a0[m] = abase[m * 32];
 #pragma unroll
-        for (int i = 0; i < NW; ++i) b0[i] = bbase[i * 32];
+        for (int i = 0; i < NW; ++i) b0[i] = bbase[i * STEP];
 #pragma unroll
         for (int ks = 0; ks < kKsteps; ks += 2) {
             {
@@ -184,7 +196,7 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
 #pragma unroll
                 for (int m = 0; m < MW; ++m) a1[m] = abase[k1 * 2 * CO_PAD + m * 32];
 #pragma unroll
-                for (int i = 0; i < NW; ++i) b1[i] = bbase[(2 * pair * kPR + ky) * PC + kx + i * 32];
+                for (int i = 0; i < NW; ++i) b1[i] = bbase[(2 * pair * kPR + ky) * PC + kx + i * STEP];
             }
 #pragma unroll
             for (int m = 0; m < MW; ++m)
@@ -203,7 +215,7 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
 #pragma unroll
                 for (int m = 0; m < MW; ++m) a0[m] = abase[k2 * 2 * CO_PAD + m * 32];
 #pragma unroll
-                for (int i = 0; i < NW; ++i) b0[i] = bbase[(2 * pair * kPR + ky) * PC + kx + i * 32];
+                for (int i = 0; i < NW; ++i) b0[i] = bbase[(2 * pair * kPR + ky) * PC + kx + i * STEP];
             }
 #pragma unroll
             for (int m = 0; m < MW; ++m)
@@ -227,40 +239,50 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
 
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     const size_t oplane = (size_t)g.Hout * g.Wout;
-    float* yn = y + (size_t)n * g.Cout * oplane + (size_t)oy * g.Wout;
+    float* yn = y + (size_t)n * g.Cout * oplane;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-        const int ox = ox0 + (wnb * NW + i) * 32 + l31;
-        if (ox >= g.Wc) continue;
+        const int p = (wnb * NW + i) * 32 + l31;  // pixel inside the tile
+        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        if (oy >= g.Hc || ox >= g.Wc) continue;
+        float* yp = yn + (size_t)oy * g.Wout + ox;
 #pragma unroll
         for (int m = 0; m < MW; ++m) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = (wmb * MW + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < g.Cout) yn[(size_t)co * oplane + ox] = acc[m][i][r] + (bias ? bias[co] : 0.f);
+                if (co < g.Cout) yp[(size_t)co * oplane] = acc[m][i][r] + (bias ? bias[co] : 0.f);
             }
         }
     }
 }
 
-template <int MW, int NW, int WMB, int WNB, bool PF>
+template <int MW, int NW, int WMB, int WNB, int TW>
 int launch3(G3 g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
     constexpr int PIX = NW * WNB * 32;
-    g.tilesX = (g.Wc + PIX - 1) / PIX;
-    const long blocks = (long)g.N * g.Hc * g.tilesX;
+    constexpr int TH = PIX / TW;
+    g.tilesX = (g.Wc + TW - 1) / TW;
+    g.tilesY = (g.Hc + TH - 1) / TH;
+    const long blocks = (long)g.N * g.tilesY * g.tilesX;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: grid too large");
-    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, PF>), dim3((unsigned)blocks), dim3(WMB * WNB * 64), 0,
-                       s, g, x, wp, bias, y);
+    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, true, TW>), dim3((unsigned)blocks),
+                       dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
     return afd::check_launch("conv3x3_kernel");
 }
 
+// one-row tiles for wide images, 32-column tiles otherwise
+template <int MW, int NW, int WMB, int WNB>
+int launch3_shape(const G3& g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
+    if (g.W >= 1024) return launch3<MW, NW, WMB, WNB, NW * WNB * 32>(g, x, wp, bias, y, s);
+    return launch3<MW, NW, WMB, WNB, 32>(g, x, wp, bias, y, s);
+}
+
 int run3(const G3& g, const float* x, const float* wp, const float* bias, float* y, hipStream_t s) {
-    const bool pf = getenv("AFD_C33_NOPF") == nullptr;
     switch ((g.Cout + 31) / 32) {
-        case 1: return pf ? launch3<1, 2, 1, 4, true>(g, x, wp, bias, y, s) : launch3<1, 2, 1, 4, false>(g, x, wp, bias, y, s);  // 32 ch x 256 px
-        case 2: return pf ? launch3<1, 2, 2, 2, true>(g, x, wp, bias, y, s) : launch3<1, 2, 2, 2, false>(g, x, wp, bias, y, s);  // 64 ch x 128 px
-        case 3: return pf ? launch3<3, 1, 1, 4, true>(g, x, wp, bias, y, s) : launch3<3, 1, 1, 4, false>(g, x, wp, bias, y, s);  // 96 ch x 128 px
-        case 4: return pf ? launch3<2, 2, 2, 2, true>(g, x, wp, bias, y, s) : launch3<2, 2, 2, 2, false>(g, x, wp, bias, y, s);  // 128 ch x 128 px
+        case 1: return launch3_shape<1, 2, 1, 4>(g, x, wp, bias, y, s);  // 32 ch x 256 px
+        case 2: return launch3_shape<1, 2, 2, 2>(g, x, wp, bias, y, s);  // 64 ch x 128 px
+        case 3: return launch3_shape<3, 1, 1, 4>(g, x, wp, bias, y, s);  // 96 ch x 128 px
+        case 4: return launch3_shape<2, 2, 2, 2>(g, x, wp, bias, y, s);  // 128 ch x 128 px
     }
     return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: Cout %d > 128", g.Cout);
 }
@@ -268,7 +290,7 @@ int run3(const G3& g, const float* x, const float* wp, const float* bias, float*
 // ---------------------------------------------------------------------------------------
 // backward-weight for the same layers: dw[co][ci][ky][kx] = sum_p dz[co][p] x[ci][p + tap].
 // GEMM with M = output channels, N = (ci, ky, kx) columns of a chunk of CT channels,
-// K = pixels in tiles of 64 (one output row).  The (channel tile, column tile) pairs of a
+// K = pixels in tiles of 64 (one output row of 64, or two rows of 32 on narrow images).  The (channel tile, column tile) pairs of a
 // chunk are dealt to four waves, TPW each, and stay in accumulators over the whole tile list
 // of the workgroup; per tile: loads -> barrier -> LDS stores -> barrier -> 32 k-steps whose
 // fragment reads are lane base + immediate.  dz rows have pitch 65 and the patch rows pitch 68
@@ -277,20 +299,23 @@ int run3(const G3& g, const float* x, const float* wp, const float* bias, float*
 // ---------------------------------------------------------------------------------------
 constexpr int kWPix = 64;
 constexpr int kWPitch = 65;
-constexpr int kWPC = kWPix + 4;
 
 struct GW {
     int N, Cin, H, W, Cout;  // forward geometry; dz is [N][Cout][H][W]
     int Hc, Wc;              // dz is zero outside [:Hc, :Wc]: tiles cover that extent only
-    int tilesX, S, nchunks;
+    int tilesX, tilesY, S, nchunks;
     int ntiles;
 };
 
-template <int MT, int CT, int TPW>
+template <int MT, int CT, int TPW, int TW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dz,
                 float* __restrict__ part, float* __restrict__ partb) {
     constexpr int CO_PAD = MT * 32;
+    static_assert(TW == 64 || TW == 32, "tile width");
+    constexpr int TH = kWPix / TW;
+    constexpr int kPR = TH + 2;   // patch rows (shadows the one-row constant of the file)
+    constexpr int kWPC = TW + 4;  // patch pitch: halo + padding to whole float4 groups
     constexpr int NTILES = CT * 9 / 32;
     static_assert(CT * 9 % 32 == 0, "whole column tiles");
     constexpr int PAIRS = MT * NTILES;
@@ -319,7 +344,7 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
     for (int u = 0; u < DV; ++u) {
         const int item = tid + u * 256;
         const int co = item >> 4, px = (item & 15) << 2;
-        dzo[u] = co < g.Cout ? (unsigned)co * (unsigned)(g.H * g.W) + px : 0u;
+        dzo[u] = co < g.Cout ? (unsigned)co * (unsigned)(g.H * g.W) + (unsigned)((px / TW) * g.W + px % TW) : 0u;
     }
 #pragma unroll
     for (int u = 0; u < PV; ++u) {
@@ -347,19 +372,20 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-    const int tpi = g.tilesX * g.Hc;
+    const int tpi = g.tilesX * g.tilesY;
     for (int tile = split; tile < g.ntiles; tile += g.S) {
         const int n = tile / tpi;
         const int t = tile - n * tpi;
-        const int oy = t / g.tilesX;
-        const int ox0 = (t - oy * g.tilesX) * kWPix;
+        const int ty = t / g.tilesX;
+        const int oy = ty * TH;
+        const int ox0 = (t - ty * g.tilesX) * TW;
         const int iy0 = oy - 1, ix0 = ox0 - 1;
         const float* dzn = dz + (size_t)n * g.Cout * plane + (size_t)oy * g.W + ox0;
         const float* xc = x + ((size_t)n * g.Cin + (size_t)chunk * CT) * plane;
         {
             f32x4u dv[DV], pv[PV];
-            const bool interior = ox0 + kWPix <= g.W && ix0 >= 0 && ix0 + kWPC <= g.W && iy0 >= 0 &&
-                                  iy0 + kPR <= g.H;
+            const bool interior = ox0 + TW <= g.W && oy + TH <= g.H && ix0 >= 0 && ix0 + kWPC <= g.W &&
+                                  iy0 >= 0 && iy0 + kPR <= g.H;
             if (interior) {
                 const float* xb = xc + (size_t)iy0 * g.W + ix0;
 #pragma unroll
@@ -372,10 +398,11 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
                     const int item = tid + u * 256;
                     const int co = item >> 4, px = (item & 15) << 2;
                     f32x4u v = {0.f, 0.f, 0.f, 0.f};
-                    if (co < g.Cout) {
+                    const int r = px / TW, c = px % TW;
+                    if (co < g.Cout && oy + r < g.H) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (ox0 + px + j < g.W) v[j] = dzn[(size_t)co * plane + px + j];
+                            if (ox0 + c + j < g.W) v[j] = dzn[(size_t)co * plane + (size_t)r * g.W + c + j];
                     }
                     dv[u] = v;
                 }
@@ -388,9 +415,13 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
                     f32x4u v = {0.f, 0.f, 0.f, 0.f};
                     if (item < CT * kPR * G4 && iy >= 0 && iy < g.H) {
                         const float* src = xc + (size_t)ci_l * plane + (size_t)iy * g.W + ix;
+                        if (ix >= 0 && ix + 3 < g.W) {
+                            v = *reinterpret_cast<const f32x4u*>(src);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (ix + j >= 0 && ix + j < g.W) v[j] = src[j];
+                            for (int j = 0; j < 4; ++j)
+                                if (ix + j >= 0 && ix + j < g.W) v[j] = src[j];
+                        }
                     }
                     pv[u] = v;
                 }
@@ -414,6 +445,8 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
             }
             __syncthreads();
         }
+        // pixel k of the tile sits (k / TW) patch rows down, k % TW columns in
+        auto boff = [](int k) { return (k / TW) * kWPC + k % TW; };
         float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
@@ -425,7 +458,7 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
                 a1[q] = ap[q][2 * ks + 2];
-                b1[q] = bp[q][2 * ks + 2];
+                b1[q] = bp[q][boff(2 * ks + 2)];
             }
 #pragma unroll
             for (int q = 0; q < TPW; ++q)
@@ -440,7 +473,7 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
 #pragma unroll
                 for (int q = 0; q < TPW; ++q) {
                     a0[q] = ap[q][2 * ks + 4];
-                    b0[q] = bp[q][2 * ks + 4];
+                    b0[q] = bp[q][boff(2 * ks + 4)];
                 }
             }
 #pragma unroll
@@ -475,20 +508,29 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
     }
 }
 
-template <int MT, int CT, int TPW>
-int launchw(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
-    constexpr size_t lds = (size_t)(MT * 32 * kWPitch + CT * kPR * kWPC + MT * 32 * 16) * 4;
+template <int MT, int CT, int TPW, int TW>
+int launchw_t(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
+    constexpr size_t lds = (size_t)(MT * 32 * kWPitch + CT * (kWPix / TW + 2) * (TW + 4) + MT * 32 * 16) * 4;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<MT, CT, TPW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<MT, CT, TPW, TW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad3x3: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad3x3_kernel<MT, CT, TPW>), dim3(g.S, g.nchunks), dim3(256), lds, s, g, x, dz,
+    hipLaunchKernelGGL((wgrad3x3_kernel<MT, CT, TPW, TW>), dim3(g.S, g.nchunks), dim3(256), lds, s, g, x, dz,
                        part, partb);
     return afd::check_launch("wgrad3x3_kernel");
 }
+
+template <int MT, int CT, int TPW>
+int launchw(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
+    if (g.W >= 1024) return launchw_t<MT, CT, TPW, 64>(g, x, dz, part, partb, s);
+    return launchw_t<MT, CT, TPW, 32>(g, x, dz, part, partb, s);
+}
+
+// tile shape for an image width: one row of 64 pixels, or two rows of 32
+int wgrad_tw(int W) { return W >= 1024 ? 64 : 32; }
 
 // channels per chunk (64 with 32 output channels measured slower: 58 vs 68 TF/s on 128 -> 32)
 int wgrad_ct(int, int) { return 32; }
@@ -499,7 +541,7 @@ namespace afd {
 
 bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
     if (getenv("AFD_NO_WGRAD3X3")) return false;
-    if (K != 3 || dil != 1 || pad != 1 || W < 1024 || Cout > 128) return false;
+    if (K != 3 || dil != 1 || pad != 1 || W < 24 || H < 2 || Cout > 128) return false;
     const int mt = (Cout + 31) / 32;
     if (Cin % wgrad_ct(mt, Cin) != 0) return false;
     return (size_t)128 * H * W < 0x7fffffffULL;
@@ -515,14 +557,15 @@ void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int 
     *CO_PAD = mt * 32;
     *NCOL = ct * 9;
     const int hc = dz_rows < H ? dz_rows : H, wc = dz_cols < W ? dz_cols : W;
-    const long tiles = (long)N * hc * ((wc + kWPix - 1) / kWPix);
+    const int tw = wgrad_tw(W), th = kWPix / tw;
+    const long tiles = (long)N * ((hc + th - 1) / th) * ((wc + tw - 1) / tw);
     long s = 1024 / *nchunks;
     if (s < 1) s = 1;
     if (s > tiles) s = tiles;
     // A split count that shares a factor with the tiles per row makes every workgroup walk down
     // one tile column in lock step (measured 80 instead of 109 TF/s at 512 splits x 128 tiles per
     // row): take the next smaller count coprime to it.
-    const long tx = (wc + kWPix - 1) / kWPix;
+    const long tx = (wc + tw - 1) / tw;
     auto gcd = [](long a, long b) { while (b) { const long t = a % b; a = b; b = t; } return a; };
     while (s > 1 && gcd(s, tx) != 1) --s;
     *S = (int)s;
@@ -534,10 +577,12 @@ int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, 
     g.N = N; g.Cin = Cin; g.H = H; g.W = W; g.Cout = Cout;
     g.Hc = dz_rows < H ? dz_rows : H;
     g.Wc = dz_cols < W ? dz_cols : W;
-    g.tilesX = (g.Wc + kWPix - 1) / kWPix;
+    const int tw = wgrad_tw(W), th = kWPix / tw;
+    g.tilesX = (g.Wc + tw - 1) / tw;
+    g.tilesY = (g.Hc + th - 1) / th;
     int ct, co_pad, ncol;
     wgrad3x3_geometry(N, Cin, H, W, Cout, dz_rows, dz_cols, &g.S, &g.nchunks, &ct, &co_pad, &ncol);
-    const long tiles = (long)N * g.Hc * g.tilesX;
+    const long tiles = (long)N * g.tilesY * g.tilesX;
     if (tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad3x3: too many tiles");
     g.ntiles = (int)tiles;
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.Hc * g.Wc * Cin * 9, s);
@@ -557,7 +602,7 @@ bool conv3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil
     if (getenv("AFD_NO_CONV3X3")) return false;
     if (K != 3 || dil != 1 || pad != 1) return false;
     if (Cin % kCT != 0 || Cout > 128 || Cin < kCT) return false;
-    if (W < 1024) return false;  // wide (level-14 style) images only: one-row tiles of 128-256 pixels
+    if (W < 24 || H < 2) return false;  // 32-column tiles would be mostly padding
     return (size_t)kCT * H * W < 0x7fffffffULL;
 }
 

@@ -60,6 +60,12 @@ CONV_CASES = [
     (1, 96, 4, 1025, 128, 3, 1, 1),
     (1, 8, 3, 1024, 40, 3, 1, 1),
     (1, 64, 13, 1157, 96, 3, 1, 1),
+    # the same kernels with 32-column tiles (narrow level-8 / STFT / LCNN images): ragged tile rows
+    # and columns, 4- and 8-row tiles
+    (2, 32, 12, 32, 64, 3, 1, 1),
+    (2, 64, 12, 32, 32, 3, 1, 1),
+    (2, 96, 7, 40, 128, 3, 1, 1),
+    (1, 32, 9, 24, 96, 3, 1, 1),
     # LCNN shapes (models.py:85-110)
     (2, 1, 101, 256, 64, 5, 2, 1),
     (2, 48, 25, 64, 128, 3, 1, 1),
