@@ -59,8 +59,8 @@ __global__ void repack3_kernel(const float* __restrict__ w, float* __restrict__ 
 // workgroup, arranged as TH rows of TW columns: TW = PIX (one row; wide level-14 images) or
 // TW = 32 (PIX / 32 rows; the narrow level-8 / STFT / LCNN images).  The LDS patch pitch depends
 // on the tile shape only, never on the image width, so the fragment offsets stay immediates.
-template <int MW, int NW, int WMB, int WNB, bool PF, int TW>
-__global__ void __launch_bounds__(WMB * WNB * 64) __attribute__((amdgpu_waves_per_eu(MW * NW <= 3 ? 3 : 2)))
+template <int MW, int NW, int WMB, int WNB, bool TWO, int TW>
+__global__ void __launch_bounds__(WMB * WNB * 64) __attribute__((amdgpu_waves_per_eu(TWO ? (MW * NW <= 3 ? 3 : 2) : (MW * NW <= 3 ? 4 : 3))))
 conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict__ wp,
                const float* __restrict__ bias, float* __restrict__ y) {
     constexpr int NT = WMB * WNB * 64;
@@ -172,15 +172,20 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
             }
         }
         __syncthreads();
-        if (PF && chunk + 1 < g.nchunks) load_chunk(chunk + 1);
+        if (chunk + 1 < g.nchunks) load_chunk(chunk + 1);
         // ---- 36 k-steps, fragment addresses = lane base + immediate ----
-        f32x16 part[MW][NW];
+        // TWO: one fp32 chain per channel chunk, added to the running sum afterwards (conv
+        // outputs within ~5e-7 of fp64 instead of ~2e-6, for the price of MW*NW*16 adds and
+        // registers per chunk)
+        f32x16 part[TWO ? MW : 1][TWO ? NW : 1];
+        if (TWO) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int i = 0; i < NW; ++i)
+                for (int i = 0; i < NW; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) part[m][i][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) part[m][i][r] = 0.f;
+        }
         float a0[MW], b0[NW], a1[MW], b1[NW];
 #pragma unroll
         for (int m = 0; m < MW; ++m) a0[m] = abase[m * 32];
@@ -202,7 +207,8 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int i = 0; i < NW; ++i)
-                    part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[i], part[m][i], 0, 0, 0);
+                    if (TWO) part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[i], part[m][i], 0, 0, 0);
+                    else acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[m], b0[i], acc[m][i], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < MW * NW; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -221,7 +227,8 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
             for (int m = 0; m < MW; ++m)
 #pragma unroll
                 for (int i = 0; i < NW; ++i)
-                    part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[i], part[m][i], 0, 0, 0);
+                    if (TWO) part[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[i], part[m][i], 0, 0, 0);
+                    else acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[m], b1[i], acc[m][i], 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < MW * NW; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
@@ -229,12 +236,12 @@ conv3x3_kernel(const G3 g, const float* __restrict__ x, const float* __restrict_
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // two-level accumulation: one fp32 chain per channel chunk, then one add
+        if (TWO) {
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+            for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int i = 0; i < NW; ++i) acc[m][i] += part[m][i];
-        if (!PF && chunk + 1 < g.nchunks) load_chunk(chunk + 1);
+                for (int i = 0; i < NW; ++i) acc[m][i] += part[m][i];
+        }
     }
 
     // D layout: column = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -265,8 +272,12 @@ int launch3(G3 g, const float* x, const float* wp, const float* bias, float* y, 
     g.tilesY = (g.Hc + TH - 1) / TH;
     const long blocks = (long)g.N * g.tilesY * g.tilesX;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: grid too large");
-    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, true, TW>), dim3((unsigned)blocks),
-                       dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
+    if (getenv("AFD_C33_TWO"))
+        hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, true, TW>), dim3((unsigned)blocks),
+                           dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
+    else
+        hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, false, TW>), dim3((unsigned)blocks),
+                           dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
     return afd::check_launch("conv3x3_kernel");
 }
 
