@@ -292,7 +292,7 @@ int run3(const G3& g, const float* x, const float* wp, const float* bias, float*
     switch ((g.Cout + 31) / 32) {
         case 1: return launch3_shape<1, 2, 1, 4>(g, x, wp, bias, y, s);  // 32 ch x 256 px
         case 2: return launch3_shape<1, 2, 2, 2>(g, x, wp, bias, y, s);  // 64 ch x 128 px
-        case 3: return launch3_shape<3, 1, 1, 4>(g, x, wp, bias, y, s);  // 96 ch x 128 px
+        case 3: return launch3_shape<3, 1, 1, 4>(g, x, wp, bias, y, s);  // 96 ch x 128 px (x 256 px: 97 vs 115 TF/s)
         case 4: return launch3_shape<2, 2, 2, 2>(g, x, wp, bias, y, s);  // 128 ch x 128 px
     }
     return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: Cout %d > 128", g.Cout);
