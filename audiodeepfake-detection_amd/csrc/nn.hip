@@ -720,7 +720,10 @@ extern "C" int afd_bn_apply_forward(const float* x, const float* slope, const fl
                                     float* y, int N, int C, int HW, afd_stream_t stream) {
     if (!x || !mean || !invstd || !y) return afd::fail(AFD_ERR_ARG, "bn apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn apply: N*C > 65535");
-    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(grid1d((size_t)HW / 16 + 1, 16), N * C), dim3(kT), 0, AFD_STREAM, x,
+    unsigned bx = (unsigned)(HW / 16384);  // at least 16k elements per workgroup
+    if (bx < 1) bx = 1;
+    if (bx > 16) bx = 16;
+    hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(bx, N * C), dim3(kT), 0, AFD_STREAM, x,
                        slope, mean, invstd, gamma, beta, y, C, HW);
     return afd::check_launch("bn_apply_fwd_kernel");
 }
@@ -745,7 +748,12 @@ extern "C" int afd_bn_backward_apply(const float* x, const float* slope, const f
     if (!x || !dy || !mean || !invstd || !mean_dy || !mean_dy_xhat || !dx || (slope && !dslope))
         return afd::fail(AFD_ERR_ARG, "bn bwd apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn bwd apply: N*C > 65535");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid1d((size_t)HW / 16 + 1, 16), N * C), dim3(kT), 0, AFD_STREAM, x,
+    // at least 16k elements per workgroup (each ends in one float atomic on dslope; short
+    // workgroups also pay the block reduction per few hundred elements)
+    unsigned bx = (unsigned)(HW / 16384);
+    if (bx < 1) bx = 1;
+    if (bx > 16) bx = 16;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx, N * C), dim3(kT), 0, AFD_STREAM, x,
                        slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, C, HW);
     return afd::check_launch("bn_bwd_apply_kernel");
 }
