@@ -4,14 +4,14 @@ FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH
 counts 64 B per 128-B request of wide (16 B/lane) coalesced reads, so it is doubled for the kernels
 whose staging loads are dwordx4; other widths are uncalibrated and recorded raw.
 """
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 WIDE = ("conv3x3_kernel", "wgrad3x3_kernel", "conv1x1_kernel", "wpt_haar14_kernel", "conv_wgrad2_kernel",
         "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel", "bn_bwd_apply_kernel",
         "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
 out = {"note": __doc__.strip(), "workload": "coif4-l14", "batch": 128, "kernels": {}}
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = sorted(glob.glob(f"gpurun_out/pmc_{counter}/*/*counter_collection.csv"))[-1]
+    f = max(glob.glob(f"gpurun_out/pmc_{counter}/*/*counter_collection.csv"), key=os.path.getmtime)
     agg = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
