@@ -8,10 +8,10 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for r in rows:
-    m = re.search(r"(conv_\w+<[^>]*>|\w+_kernel)", r["Kernel_Name"]); k = m.group(1) if m else r["Kernel_Name"][:30]
+    m = re.search(r"(\w+_kernel<[^>]*>|\w+_kernel)", r["Kernel_Name"]); k = m.group(1) if m else r["Kernel_Name"][:30]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
 for k, d in agg.items():
-    if "conv_" not in k: continue
+    if "conv" not in k and "wgrad" not in k: continue
     n = len(disp[k]); print(k, "dispatches", n, "grid", )
     for c, v in sorted(d.items()): print("   %-28s %.4g per dispatch" % (c, v / n))
 PY
