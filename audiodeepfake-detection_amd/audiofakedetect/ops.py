@@ -307,9 +307,29 @@ class _BatchNorm(torch.autograd.Function):
             sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
             _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c,
                                            hw, _native.stream_ptr()), "afd_bn_stats")
-            mean, invstd, cnt = bn_finalize(sums, c, count, eps, sync, running_mean, running_var,
-                                            nbt, momentum)
-            ctx.count = cnt
+            if x.is_cuda:
+                # one kernel for mean / invstd / running statistics / num_batches_tracked
+                dist_on = _dist_on(sync)
+                if dist_on:
+                    sums[2 * c] = count
+                    dist.all_reduce(sums)
+                mean = torch.empty(c, dtype=torch.float32, device=dev)
+                invstd = torch.empty(c, dtype=torch.float32, device=dev)
+                cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
+                mom = momentum
+                if mom is None:  # cumulative moving average (nn.BatchNorm2d(momentum=None))
+                    mom = 1.0 / float(int(nbt) + 1) if nbt is not None else 0.0
+                with torch.no_grad():
+                    _native.check(lib.afd_bn_finalize(
+                        _native.ptr(sums), c, -1.0 if dist_on else count, float(eps), float(mom),
+                        _native.ptr(mean), _native.ptr(invstd), _native.ptr(running_mean),
+                        _native.ptr(running_var), _native.ptr(nbt), _native.ptr(cnt),
+                        _native.stream_ptr()), "afd_bn_finalize")
+                ctx.count = cnt if dist_on else count
+            else:
+                mean, invstd, cnt = bn_finalize(sums, c, count, eps, sync, running_mean, running_var,
+                                                nbt, momentum)
+                ctx.count = cnt
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
@@ -348,8 +368,13 @@ class _BatchNorm(torch.autograd.Function):
         if _dist_on(sync):
             sums = sums.clone()
             dist.all_reduce(sums)
-        mdy = (sums[:c] / ctx.count).float()
-        mdyx = (sums[c:] / ctx.count).float()
+        mdy = torch.empty(c, dtype=torch.float32, device=x.device)
+        mdyx = torch.empty(c, dtype=torch.float32, device=x.device)
+        on_dev = torch.is_tensor(ctx.count)
+        _native.check(lib.afd_bn_backward_means(
+            _native.ptr(sums), c, -1.0 if on_dev else float(ctx.count),
+            _native.ptr(ctx.count) if on_dev else None, _native.ptr(mdy), _native.ptr(mdyx),
+            _native.stream_ptr()), "afd_bn_backward_means")
         dx = torch.empty_like(x)
         dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
         _native.check(lib.afd_bn_backward_apply(

@@ -704,6 +704,58 @@ extern "C" int afd_prelu_pool_backward(const float* u, const float* slope, const
     return afd::check_launch("prelu_pool_bwd_kernel");
 }
 
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, float eps,
+                                   float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ nbt, double* __restrict__ count_out) {
+    const double cnt = count < 0.0 ? sums[2 * C] : count;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        const double m = sums[c] / cnt;
+        double var = sums[C + c] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[c] = (float)m;
+        invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = var * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
+            running_mean[c] = running_mean[c] * (1.f - momentum) + (float)m * momentum;
+            running_var[c] = running_var[c] * (1.f - momentum) + (float)unbiased * momentum;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (nbt) *nbt += 1;
+        if (count_out) *count_out = cnt;
+    }
+}
+
+__global__ void bn_bwd_means_kernel(const double* __restrict__ sums, int C, double count,
+                                    const double* __restrict__ count_dev, float* __restrict__ mdy,
+                                    float* __restrict__ mdyx) {
+    const double cnt = count < 0.0 ? *count_dev : count;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        mdy[c] = (float)(sums[c] / cnt);
+        mdyx[c] = (float)(sums[C + c] / cnt);
+    }
+}
+
+extern "C" int afd_bn_finalize(const double* sums, int C, double count, float eps, float momentum,
+                               float* mean, float* invstd, float* running_mean, float* running_var,
+                               long long* nbt, double* count_out, afd_stream_t stream) {
+    if (!sums || !mean || !invstd || C < 1) return afd::fail(AFD_ERR_ARG, "bn finalize: bad argument");
+    if ((running_mean == nullptr) != (running_var == nullptr)) return afd::fail(AFD_ERR_ARG, "bn finalize: running stats");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, AFD_STREAM, sums, C, count, eps,
+                       momentum, mean, invstd, running_mean, running_var, nbt, count_out);
+    return afd::check_launch("bn_finalize_kernel");
+}
+
+extern "C" int afd_bn_backward_means(const double* sums, int C, double count, const double* count_dev,
+                                     float* mdy, float* mdyx, afd_stream_t stream) {
+    if (!sums || !mdy || !mdyx || C < 1 || (count < 0.0 && !count_dev))
+        return afd::fail(AFD_ERR_ARG, "bn backward means: bad argument");
+    hipLaunchKernelGGL(bn_bwd_means_kernel, dim3((C + 255) / 256), dim3(256), 0, AFD_STREAM, sums, C, count,
+                       count_dev, mdy, mdyx);
+    return afd::check_launch("bn_bwd_means_kernel");
+}
+
 extern "C" int afd_bn_stats(const float* x, const float* slope, double* sums, int N, int C, int HW,
                             afd_stream_t stream) {
     if (!x || !sums || N < 1 || C < 1 || HW < 1) return afd::fail(AFD_ERR_ARG, "bn stats: bad argument");

@@ -197,6 +197,20 @@ int afd_bn_backward_apply(const float* x, const float* slope, const float* dy, c
                           const float* mean_dy_xhat, float* dx, float* dslope /* += */, int N,
                           int C, int HW, afd_stream_t stream);
 
+/* The small per-channel steps between the BatchNorm passes, one launch each instead of a chain of
+ * elementwise torch kernels (nn.BatchNorm2d / SyncBatchNorm semantics, models.py:260-289):
+ * finalize: from the packed sums [sum(C) | sum of squares(C) | count] -> mean, invstd (biased
+ *   variance), running statistics updated in place with `momentum` (unbiased variance),
+ *   *num_batches_tracked += 1.  count = sums[2C] when count < 0 (set by the caller before the
+ *   cross-rank all-reduce), else the host value.  running_* / nbt may be NULL.
+ * backward means: mdy = sums[0:C] / count, mdyx = sums[C:2C] / count (count as above, read from
+ *   count_dev when count < 0). */
+int afd_bn_finalize(const double* sums, int C, double count, float eps, float momentum, float* mean,
+                    float* invstd, float* running_mean, float* running_var, long long* nbt,
+                    double* count_out, afd_stream_t stream);
+int afd_bn_backward_means(const double* sums, int C, double count, const double* count_dev,
+                          float* mdy, float* mdyx, afd_stream_t stream);
+
 /* Dropout(p) + permute(0,2,1,3).contiguous() (models.py:277,307): x [B][C][H][W] ->
  * y [B][H][C][W]; inverse != 0 runs the backward (dy [B][H][C][W] -> dx [B][C][H][W]) */
 int afd_dropout_permute(const float* x, float* y, int B, int C, int H, int W, float p,
