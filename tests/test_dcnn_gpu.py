@@ -69,7 +69,7 @@ def test_train_step_matches_reference():
     # Gradients: fp32 rounding of a conv output can flip a 2x2 max-pool argmax at a near
     # tie or the PReLU branch at a zero crossing; each flip re-routes one gradient element, so
     # element-wise agreement with another fp32 implementation is bounded by those flips, not
-    # by accumulation error (measured with tools_grad_debug.py: with no flip between two
+    # by accumulation error (measured with tools/grad_debug.py: with no flip between two
     # runs every tensor agrees to ~1e-6; one pool flip in block 3 costs 1e-3 L2 upstream of
     # it, and the CPU fp32 reference differs from its own fp64 run by 2e-4 .. 2e-3 for the
     # same reason).  Bars: per tensor relative L2 <= 2e-2 and max <= 1e-1 of its largest

@@ -114,7 +114,7 @@ def test_lcnn_train_step_matches_cpu_restatement():
     # A max-feature-map / max-pool decision at a near tie can fall the other way under another
     # fp32 summation order; one such flip re-routes one gradient element and shows up as ~2e-3
     # relative L2 in every layer upstream of it, while the layers downstream of it agree to ~5e-6
-    # (tools_lcnn_grad_debug.py prints the per-tensor picture; see also test_dcnn_gpu.py).
+    # (tools/lcnn_grad_debug.py prints the per-tensor picture; see also test_dcnn_gpu.py).
     assert (num / den) ** 0.5 <= 2e-2, (num / den) ** 0.5
     # the recurrent / linear tail is downstream of every max decision: near-exact
     for k, p in net.named_parameters():

@@ -1,7 +1,7 @@
-# usage: tools_pmc.sh <conv name> <counters...>
+# usage: tools/pmc.sh <conv name> <counters...>
 name=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rm -rf gpurun_out/pmc && mkdir -p gpurun_out/pmc
-timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc -- python3 tools_conv_bench.py $name > gpurun_out/pmc/out.txt 2>&1
+timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc -- python3 tools/conv_bench.py $name > gpurun_out/pmc/out.txt 2>&1
 f=$(find gpurun_out/pmc -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<PY
 import csv, sys, collections, re

@@ -9,4 +9,4 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 for w in coif4-l8 sym5-l8 stft stft-lcnn-eval; do
   python3 bench.py --workload $w --cpu-frames 0 --steps 10 --warmup 3 > $O/bench_$w.json 2> $O/bench_$w.err && cat $O/bench_$w.json
 done
-python3 tools_frontend_bench.py > $O/frontend.log 2>&1 && cat $O/frontend.log
+python3 tools/frontend_bench.py > $O/frontend.log 2>&1 && cat $O/frontend.log
