@@ -34,29 +34,61 @@ __device__ __forceinline__ float wread(const float* __restrict__ w, int o, int i
 }
 
 // Stage in[ci][iy0 + r*DIL][ix0 .. ix0+PC) for r < R into tile[ci][r][PC], zero outside the
-// image; loads are issued in batches of 8 per thread before the LDS stores.
+// image.  Lanes run along a patch row (coalesced, no per-element index arithmetic: these are
+// vector-ALU kernels, every staging instruction is an FMA slot lost); rows are either all taken
+// by every thread (PC >= NT: the (channel, row) of a load is a compile-time constant), or, for
+// tiles narrower than the workgroup, addressed through a flat element index.  Loads go out in batches of 8 before their LDS stores.
 template <int C, int R, int PC, int DIL, int NT>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ img, int H, int W, int iy0,
                                            int ix0, float* tile, int tid) {
-    constexpr int total = C * R * PC;
-    constexpr int per = (total + NT - 1) / NT;
+    constexpr int ROWSALL = C * R;
     const size_t plane = (size_t)H * W;
+    if constexpr (PC >= NT) {
+        constexpr int CP = (PC + NT - 1) / NT;
 #pragma unroll
-    for (int u0 = 0; u0 < per; u0 += 8) {
-        float v[8];
+        for (int cp = 0; cp < CP; ++cp) {
+            const int col = tid + cp * NT;
+            const int ix = ix0 + col;
+            const bool inx = col < PC && ix >= 0 && ix < W;
+            const float* src = img + ix;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + (u0 + u) * NT;
-            const int row = e / PC, c = e - row * PC;
-            const int ci = row / R, r = row - ci * R;
-            const int iy = iy0 + r * DIL, ix = ix0 + c;
-            const bool ok = (u0 + u < per) && (e < total) && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            v[u] = ok ? img[(size_t)ci * plane + (size_t)iy * W + ix] : 0.f;
+            for (int r0 = 0; r0 < ROWSALL; r0 += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = r0 + u;
+                    const int ci = row / R, r = row - ci * R;  // compile-time
+                    const int iy = iy0 + r * DIL;             // wave-uniform
+                    v[u] = (row < ROWSALL && inx && iy >= 0 && iy < H) ? src[(size_t)ci * plane + (size_t)iy * W] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int row = r0 + u;
+                    if (row < ROWSALL && col < PC) tile[row * PC + col] = v[u];
+                }
+            }
         }
+    } else {
+        // narrow tiles (the backward-weight kernel): flat element index over the whole tile
+        constexpr int total = C * R * PC;
+        constexpr int per = (total + NT - 1) / NT;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = tid + (u0 + u) * NT;
-            if (u0 + u < per && e < total) tile[e] = v[u];
+        for (int u0 = 0; u0 < per; u0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (u0 + u) * NT;
+                const int row = e / PC, c = e - row * PC;
+                const int ci = row / R, r = row - ci * R;
+                const int iy = iy0 + r * DIL, ix = ix0 + c;
+                const bool ok = (u0 + u < per) && (e < total) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                v[u] = ok ? img[(size_t)ci * plane + (size_t)iy * W + ix] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = tid + (u0 + u) * NT;
+                if (u0 + u < per && e < total) tile[e] = v[u];
+            }
         }
     }
 }
