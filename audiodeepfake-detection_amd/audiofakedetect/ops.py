@@ -9,6 +9,7 @@ the cross-rank reductions go through torch / torch.distributed.
 from __future__ import annotations
 
 import itertools
+import os
 from typing import Optional
 
 import torch
@@ -24,14 +25,50 @@ def _lib():
     return _native.load()
 
 
-def _ws(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch buffer per device (conv weight slabs / wgrad partial slabs)."""
-    key = (device.type, device.index)
+def _ws(nbytes: int, device, lane: str = "main") -> torch.Tensor:
+    """Grow-only scratch buffer per device and stream lane (conv weight slabs / wgrad partial slabs)."""
+    key = (device.type, device.index, lane)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+# --------------------------------------------------------------------------------------
+# Weight gradients on a side stream.  A conv's backward-weight kernel (MFMA-bound, little HBM
+# traffic) depends only on the layer's input and its output gradient; the main chain meanwhile
+# runs the BatchNorm / pool backward passes (HBM-bound, no matrix work) and the next backward-data
+# kernel.  When the parameter's gradient lives in a FusedAdam arena the kernel is issued on a
+# second HIP stream and adds its result into the arena view there; an end-of-backward callback
+# joins the streams before anything reads the arena.
+_side_streams: dict = {}
+_side_pending: set = set()
+
+
+def _side_enabled() -> bool:
+    return os.environ.get("AFD_WGRAD_STREAM", "1") != "0"
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    st = _side_streams.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device.index] = st
+    return st
+
+
+def _join_side(device_index: int) -> None:
+    _side_pending.discard(device_index)
+    torch.cuda.current_stream(device_index).wait_stream(_side_streams[device_index])
+
+
+def _queue_join(device) -> None:
+    if device.index in _side_pending:
+        return
+    _side_pending.add(device.index)
+    idx = device.index
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(idx))
 
 
 def next_seed() -> int:
@@ -142,6 +179,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.geom = (n, cin, h, wd, cout, k, pad, dil)
         ctx.crop = crop
         ctx.has_bias = b is not None
+        ctx.bias_ref = b  # the Parameter itself: its .grad may be an optimizer arena view
         return y
 
     @staticmethod
@@ -159,12 +197,35 @@ class _Conv2d(torch.autograd.Function):
                 _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
                 _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty_like(w)
-            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            _native.check(lib.afd_conv2d_backward_weight_cropped(
-                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
-                cout, k, pad, dil, ctx.crop[0], ctx.crop[1], _native.ptr(ws), ws.numel(),
-                _native.stream_ptr()), "afd_conv2d_backward_weight")
+            b = ctx.bias_ref
+            side = (_side_enabled() and x.is_cuda and w.grad is not None
+                    and (not ctx.has_bias or (b is not None and b.grad is not None)))
+            if side:
+                main = torch.cuda.current_stream(x.device)
+                st = _side_stream(x.device)
+                st.wait_stream(main)  # dy (and the zeroed arena) are ready
+                with torch.cuda.stream(st):
+                    dwt = torch.empty_like(w)
+                    dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                    ws2 = _ws(nbytes, x.device, "side")
+                    _native.check(lib.afd_conv2d_backward_weight_cropped(
+                        _native.ptr(x), _native.ptr(dy), _native.ptr(dwt), _native.ptr(dbt), n, cin, h,
+                        wd, cout, k, pad, dil, ctx.crop[0], ctx.crop[1], _native.ptr(ws2), ws2.numel(),
+                        _native.stream_ptr()), "afd_conv2d_backward_weight")
+                    with torch.no_grad():
+                        w.grad.add_(dwt)
+                        if dbt is not None:
+                            b.grad.add_(dbt)
+                x.record_stream(st)
+                dy.record_stream(st)
+                _queue_join(x.device)
+            else:
+                dw = torch.empty_like(w)
+                db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+                _native.check(lib.afd_conv2d_backward_weight_cropped(
+                    _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
+                    cout, k, pad, dil, ctx.crop[0], ctx.crop[1], _native.ptr(ws), ws.numel(),
+                    _native.stream_ptr()), "afd_conv2d_backward_weight")
         return dx, dw, db, None, None, None
 
 
