@@ -198,8 +198,13 @@ class _Conv2d(torch.autograd.Function):
                 _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             b = ctx.bias_ref
+            # only for parameters whose .grad is a FusedAdam arena view (flagged by the optimizer):
+            # there the gradient is wanted in .grad, as loss.backward() leaves it; a caller of
+            # torch.autograd.grad(.., weights) on such a model must set AFD_WGRAD_STREAM=0
             side = (_side_enabled() and x.is_cuda and w.grad is not None
-                    and (not ctx.has_bias or (b is not None and b.grad is not None)))
+                    and getattr(w, "_afd_arena", False)
+                    and (not ctx.has_bias or (b is not None and b.grad is not None
+                                              and getattr(b, "_afd_arena", False))))
             if side:
                 main = torch.cuda.current_stream(x.device)
                 st = _side_stream(x.device)
@@ -628,6 +633,7 @@ class FusedAdam(torch.optim.Optimizer):
         for p, off in zip(self._params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+            p._afd_arena = True  # ops._Conv2d may add its weight gradient into the view directly
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
