@@ -169,10 +169,16 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    ddp = world > 1
+    # AFD_FORCE_DDP=1: take the data-parallel path (RCCL process group, replica broadcast, SyncBN and
+    # gradient all-reduce) even with one rank -- lets a 1-GPU box exercise the collectives
+    ddp = world > 1 or bool(os.environ.get("AFD_FORCE_DDP"))
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
 
     from audiofakedetect import _native
 
@@ -184,7 +190,7 @@ def main() -> None:
 
     def sync():
         if ddp:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     log(f"built {a.workload}: features {args.input_dim}, batch/GPU {a.batch}, world {world}")
