@@ -416,7 +416,26 @@ class _BatchNorm(torch.autograd.Function):
         x, slope, mean, invstd, gamma = ctx.saved_tensors
         has_slope, has_gamma, training, sync = ctx.flags
         if not training:
-            raise RuntimeError("BatchNorm backward in eval mode is not part of the hot path")
+            # running statistics are constants: a per-channel scale (attribution passes such as
+            # integrated gradients differentiate the evaluation-mode model with respect to its
+            # input).  Off the training path: elementwise torch ops on the device.
+            slope = slope if has_slope else None
+            gamma = gamma if has_gamma else None
+            shp = (1, -1) + (1,) * (x.dim() - 2)
+            dy = _f32c(dy)
+            v = torch.where(x > 0, x, x * slope) if has_slope else x
+            scale = invstd * gamma if has_gamma else invstd
+            g = dy * scale.reshape(shp)
+            dgamma = dbeta = dslope = None
+            if has_gamma:
+                red = [d for d in range(x.dim()) if d != 1]
+                dgamma = (dy * (v - mean.reshape(shp)) * invstd.reshape(shp)).sum(red)
+                dbeta = dy.sum(red)
+            if has_slope:
+                neg = x <= 0
+                dslope = (g * x * neg).sum().reshape(1)
+                g = torch.where(neg, g * slope, g)
+            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]

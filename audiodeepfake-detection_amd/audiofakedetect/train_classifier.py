@@ -307,6 +307,86 @@ class Trainer:
         self.last_eval = {"pred": preds_t, "truth": truth_t, "per_label": per_label, "name": name}
         return acc, eer
 
+    # ---- integrated gradients (reference train_classifier.py:576-844) -------------------
+    def integrated_grad(self, baseline: torch.Tensor, image: torch.Tensor, target_class_idx,
+                        m_steps: int = 50, batch_size: int = 32) -> torch.Tensor:
+        """Integrated gradients of one image along the straight path from ``baseline``:
+        ``m_steps + 1`` path points in batches of ``batch_size``, trapezoidal integral, scaled
+        by ``image - baseline`` (reference :576-627)."""
+        from .integrated_gradients import integral_approximation
+
+        alphas = torch.linspace(0.0, 1.0, m_steps + 1, device=image.device)
+        grads = [self.one_batch(baseline, image, alphas[i:i + batch_size], target_class_idx)
+                 for i in range(0, alphas.numel(), batch_size)]
+        return (image - baseline) * integral_approximation(torch.cat(grads, dim=0))
+
+    def one_batch(self, baseline, image, alpha_batch, target_class_idx):
+        from .integrated_gradients import interpolate_images
+
+        return self.compute_gradients(interpolate_images(baseline, image, alpha_batch), target_class_idx)
+
+    def compute_gradients(self, images: torch.Tensor, target_class_idx) -> torch.Tensor:
+        """d softmax(logits)[target] / d images for a batch of images (reference :658-676)."""
+        images = images.detach().requires_grad_(True)
+        probs = torch.softmax(self.model(images), dim=-1)[:, target_class_idx]
+        probs.backward(torch.ones_like(probs))
+        return images.grad
+
+    def integrated_gradients(self, model_file: str = "ig", pbar: bool = True) -> None:
+        """Mean attribution map over test frames, written as ``.npy`` (reference :678-844; the
+        figures of the reference are drawn from these arrays by tooling outside this package)."""
+        from .integrated_gradients import Mean
+
+        plot_path = os.path.join(self.args.log_dir, "plots")
+        os.makedirs(plot_path, exist_ok=True)
+        loader = self.cross_loader_test if self.cross_loader_test is not None else self.test_data_loader
+        times = self.args.ig_times_per_target if self.args.ig_times_per_target is not None else 2500
+        target = self.args.target
+        both = target is None
+        try:
+            target_value = 1 if both else int(target)
+        except ValueError:
+            target_value = 1
+        counts = {0: 0, 1: 0}
+        mean_ig, mean_img = Mean(), Mean()
+        image = None
+        self.model.zero_grad()
+
+        def wanted(lbl: int) -> bool:
+            if both:
+                return counts[lbl] < times
+            return lbl == target_value and counts[lbl] < times
+
+        def done() -> bool:
+            return all(c >= times for c in counts.values()) if both else counts[target_value] >= times
+
+        for batch in loader:
+            labels = (batch["label"].cuda(non_blocking=True) != 0).long()
+            feats = self.normalize(self.transforms(batch["audio"].cuda(non_blocking=True))[0])
+            baseline = torch.zeros_like(feats[0])
+            for i in range(feats.shape[0]):
+                lbl = int(labels[i])
+                if not wanted(lbl):
+                    continue
+                image = feats[i]
+                attributions = self.integrated_grad(baseline, image, lbl, m_steps=200)
+                mean_ig.update(attributions.sum(dim=0).unsqueeze(0))
+                mean_img.update(image)
+                counts[lbl] += 1
+                if done():
+                    break
+            if done():
+                break
+        if image is None:
+            raise RuntimeError("integrated_gradients: the loader held no frame of the requested target")
+        if is_lead(self.args):
+            target_str = "01" if both else str(target_value)
+            sources = "-".join(self.args.cross_sources or [])
+            path = os.path.join(plot_path, f"{model_file.replace('/', '_')}_{sources}x{times}_target-{target_str}")
+            np.save(path + "_integrated_gradients.npy", mean_ig.finalize().cpu().numpy())
+            np.save(path + "_mean_images.npy", mean_img.finalize().squeeze().cpu().numpy())
+            np.save(path + "_last_image.npy", image.squeeze().detach().cpu().numpy())
+
     def testing(self):
         acc, eer = self.val_test_loop(self.test_data_loader, name="test")
         self.test_results = (acc, eer)

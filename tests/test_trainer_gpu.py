@@ -49,3 +49,54 @@ def test_trainer_train_eval_snapshot_roundtrip(tmp_path):
     trainer.load_snapshot(trainer.snapshot_path)
     trainer.val_test_loop(loader, name="again")
     assert torch.equal(before, trainer.last_eval["pred"])
+
+
+def test_integrated_gradients_match_cpu_restatement(tmp_path):
+    """Trainer.integrated_grad (reference train_classifier.py:576-676) on the HIP model in eval
+    mode against the same path integral on oracle/torch_ref.DCNNRef in float64; then the driver
+    writes the three .npy files of the reference (:826-844)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import numpy as np
+    from audiofakedetect.data_loader import SyntheticFrames
+    from audiofakedetect.integrated_gradients import integral_approximation, interpolate_images
+    from oracle import torch_ref
+    from torch.utils.data import DataLoader
+
+    torch.manual_seed(1)
+    args, trainer = bench.build("sym5-l8", 4, False, torch.device("cuda", 0))
+    net = trainer.model
+    net.eval()
+    ref = torch_ref.DCNNRef(args.input_dim, time_dim_add=1).double()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in net.state_dict().items()})
+    ref.eval()
+    x = (0.1 * torch.randn(1, 1, 22050)).clamp_(-1, 1)
+    with torch.no_grad():
+        image = trainer._features(x.cuda())[0]
+    baseline = torch.zeros_like(image)
+    got = trainer.integrated_grad(baseline, image, 1, m_steps=12, batch_size=5)
+    # reference computation on the CPU restatement
+    alphas = torch.linspace(0.0, 1.0, 13, dtype=torch.float64)
+    imgs = interpolate_images(baseline.cpu().double(), image.cpu().double(), alphas).requires_grad_(True)
+    torch.softmax(ref(imgs), dim=-1)[:, 1].sum().backward()
+    want = (image.cpu().double() - baseline.cpu().double()) * integral_approximation(imgs.grad)
+    # the first path point is the all-zero baseline: every 2x2 pool window ties there and the
+    # argmax convention routes that point's gradient differently per implementation, so the
+    # agreement is bounded by its 1/(2 m_steps) quadrature weight, not by fp32 rounding
+    err = (got.cpu().double() - want).abs().max().item()
+    assert err <= 3e-2 * want.abs().max().item(), (err, want.abs().max().item())
+    # completeness axiom (up to the quadrature error of 12 steps): sum of attributions ~ f(x) - f(0)
+    with torch.no_grad():
+        p = torch.softmax(net(torch.stack([baseline, image])), dim=-1)[:, 1]
+    assert abs(got.sum().item() - (p[1] - p[0]).item()) <= 0.1 * abs((p[1] - p[0]).item()) + 1e-3
+
+    args.log_dir = str(tmp_path)
+    args.ig_times_per_target = 1
+    args.target = None
+    args.cross_sources = ["synthetic"]
+    trainer.cross_loader_test = DataLoader(SyntheticFrames(8, 22050, num_labels=3), batch_size=4)
+    trainer.integrated_gradients("ig_test", pbar=False)
+    files = sorted(os.listdir(tmp_path / "plots"))
+    assert [f.split("_target-01_")[1] for f in files] == ["integrated_gradients.npy", "last_image.npy", "mean_images.npy"]
+    ig = np.load(tmp_path / "plots" / files[0])
+    assert ig.shape == (256, image.shape[-1]) and np.isfinite(ig).all()

@@ -72,3 +72,22 @@ def test_dotdict_and_griderator():
     assert build_new_grid({"x": [1]}, seeds=["5", 6]).init_config["seed"] == [5, 6]
     with pytest.raises(TypeError):
         _Griderator([1, 2])
+
+
+def test_integrated_gradient_helpers():
+    # straight path, trapezoidal rule, running mean (reference integrated_gradients.py:13-47,104-138)
+    import torch
+    from audiofakedetect.integrated_gradients import Mean, integral_approximation, interpolate_images
+
+    base = torch.zeros(2, 3, 4)
+    img = torch.arange(24, dtype=torch.float32).reshape(2, 3, 4)
+    alphas = torch.tensor([0.0, 0.25, 1.0])
+    path = interpolate_images(base, img, alphas)
+    assert path.shape == (3, 2, 3, 4)
+    assert torch.equal(path[0], base) and torch.equal(path[2], img) and torch.allclose(path[1], 0.25 * img)
+    g = torch.stack([torch.full((2, 2), v) for v in (1.0, 3.0, 5.0)])
+    assert torch.allclose(integral_approximation(g), torch.full((2, 2), 3.0))  # ((1+3)/2 + (3+5)/2) / 2
+    m = Mean()
+    for v in (1.0, 2.0, 6.0):
+        m.update(torch.full((1, 2, 2), v))
+    assert torch.allclose(m.finalize(), torch.full((2, 2), 3.0))
