@@ -1,14 +1,18 @@
 """Data-side pieces the hot path touches.
 
 ``WelfordEstimator`` mirrors reference ``src/audiofakedetect/data_loader.py:27-71``.
-The reference's folder indexer / windowed WAV reader (``CustomDataset``, :74-507) is
-out of scope this round; ``SyntheticFrames`` produces the
-item format it emits (``{"audio": f32[1, N], "label": int64}``, :351-353,392) so the
-trainer and ``get_input_dims`` run unchanged on synthetic data.
+``CustomDataset`` / ``get_costum_dataset`` keep the reference's folder
+convention, balanced 70/10/20 split and cached ``.npy`` index format (:74-507) with a standard-library
+WAV reader in place of torchaudio; ``SyntheticFrames`` produces the same item format
+(``{"audio": f32[1, N], "label": int64}``, :351-353,392) without a dataset on disk.
 """
 
 from __future__ import annotations
 
+import glob
+import math
+import os
+import wave
 from typing import Optional, Tuple
 
 import numpy as np
@@ -63,15 +67,179 @@ class SyntheticFrames(Dataset):
         return {"audio": audio, "label": label, "index": idx}
 
 
-def get_costum_dataset(data_path=None, ds_type="train", only_use=None, save_path=None,
-                       limit=None, asvspoof_name=None, file_type="wav", resample_rate=22050,
-                       seconds=1, synthetic=False, **_):
-    """Dataset factory (name kept from the reference, data_loader.py:397-507)."""
+def _wav_info(path: str) -> Tuple[int, int]:
+    """(frames, sample rate) of a PCM WAV file."""
+    with wave.open(path, "rb") as fh:
+        return fh.getnframes(), fh.getframerate()
+
+
+def read_wav_window(path: str, frame_offset: int, num_frames: int) -> Tuple[torch.Tensor, int]:
+    """[1, num_frames] float32 in [-1, 1) (mono: first channel) and the file's sample rate.
+
+    Stands in for ``torchaudio.load(path, frame_offset, num_frames)`` of the reference
+    (data_loader.py:323-327) for 8/16/32-bit PCM WAV files, read with the standard library.
+    """
+    with wave.open(path, "rb") as fh:
+        rate, width, channels = fh.getframerate(), fh.getsampwidth(), fh.getnchannels()
+        fh.setpos(int(frame_offset))
+        raw = fh.readframes(int(num_frames))
+    if width == 2:
+        data = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        data = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+    elif width == 1:
+        data = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+    else:
+        raise RuntimeError(f"{path}: unsupported PCM sample width {width}")
+    data = data.reshape(-1, channels)[:, 0]
+    if data.shape[0] < num_frames:
+        data = np.pad(data, (0, int(num_frames) - data.shape[0]))
+    return torch.from_numpy(np.ascontiguousarray(data)).unsqueeze(0), rate
+
+
+class CustomDataset(Dataset):
+    """Balanced frame dataset over ``<letter>_<name>/`` folders of WAV files.
+
+    Same on-disk contract as the reference's ``CustomDataset`` (data_loader.py:74-353): every file
+    is cut into windows of ``seconds``; per folder the windows are split 70 / 10 / 20 into train /
+    val / test in file order; every label contributes the same number of windows (the minimum over
+    the folders); the split is cached as an object array ``[label][frame] = (path, frame index,
+    window size in samples, label)`` in ``<save_path>/dataset_<names>_meta_<seconds>sec_<split>.npy``
+    and re-used on the next run.  ``__getitem__`` reads the window (``frame index * window size``
+    samples into the file), converts PCM to float32 and resamples down to ``resample_rate``.
+    Folders named in ``only_test_folders`` contribute to val / test only.
+    """
+
+    def __init__(self, paths: list, labels: list, save_path: str, only_test_folders: Optional[list] = None,
+                 abort_on_save: bool = False, ds_type: str = "train", seconds: float = 1,
+                 resample_rate: int = 16000, train_ratio: float = 0.7, val_ratio: float = 0.1,
+                 key: Optional[str] = "audio", limit: int = 555000, verbose: Optional[bool] = False,
+                 filetype: str = "wav", asvspoof_name: Optional[str] = None) -> None:
+        if ds_type not in ("train", "val", "test"):
+            raise RuntimeError("Dataset type does not exists.")
+        if ds_type == "train" and only_test_folders:
+            raise ValueError("Since there are folders in only_test_folders this cannot be a train dataset.")
+        names = [str(p).rstrip("/").split("/")[-1].split("_")[-1] for p in paths]
+        self.label_names = {lab: name for lab, name in zip(labels, names)}
+        destination = f"{save_path}/dataset_{'-'.join(names)}_meta_{seconds}sec"
+        cache = f"{destination}_{ds_type}.npy"
+        if os.path.exists(cache):
+            result_set = np.load(cache, allow_pickle=True)
+        else:
+            os.makedirs(save_path, exist_ok=True)
+            splits: dict = {"train": [], "val": [], "test": []}
+            counts = []
+            for path, label, name in zip(paths, labels, names):
+                pattern = f"{asvspoof_name}*.{filetype}" if asvspoof_name else f"*.{filetype}"
+                rows = []
+                for file_name in sorted(glob.glob(os.path.join(str(path), pattern))):
+                    frames, rate = _wav_info(file_name)
+                    win = int(seconds * rate)
+                    rows += [(file_name, i, win, label) for i in range(frames // win)]
+                arr = np.empty((len(rows), 4), dtype=object)
+                for r, row in enumerate(rows):
+                    arr[r] = row
+                n = len(rows)
+                if only_test_folders and name in only_test_folders:
+                    n_train = 0
+                    if counts and n >= counts[-1][1] + counts[-1][2]:
+                        n_val, n_test = counts[-1][1], counts[-1][2]
+                    else:
+                        n_val = int(val_ratio / (1.0 - train_ratio) * n)
+                        n_test = n - n_val
+                else:
+                    n_train, n_val = int(train_ratio * n), int(val_ratio * n)
+                    n_test = n - n_train - n_val
+                splits["train"].append(arr[:n_train])
+                splits["val"].append(arr[n_train:n_train + n_val])
+                splits["test"].append(arr[n_train + n_val:n_train + n_val + n_test])
+                if only_test_folders and name in only_test_folders:
+                    n_train = counts[-1][0] if counts else (55500 if limit == -1 else limit)
+                counts.append([n_train, n_val, n_test])
+            mins = np.asarray(counts).min(axis=0)
+            which = {"train": 0, "val": 1, "test": 2}[ds_type]
+            result_set = np.stack([a[:mins[which]] for a in splits[ds_type]]) if mins[which] > 0 \
+                else np.empty((len(paths), 0, 4), dtype=object)
+            np.save(cache, result_set, allow_pickle=True)
+            if abort_on_save:
+                raise SystemExit("Aborting on dataset saving.")
+        result_set = result_set[:, :limit] if limit is not None and limit >= 0 else result_set
+        if result_set.shape[1] and resample_rate > int(result_set[:, :, 2].min() / seconds):
+            raise RuntimeError("Sample rate is smaller than desired sample rate. No upsampling possible here.")
+        self.audio_data = result_set.reshape(-1, 4)  # (number of samples, 4)
+        self.ds_type = ds_type
+        self.key = key
+        self.resample_rate = resample_rate
+        self.seconds = seconds
+        if verbose:
+            print(f"{ds_type}: {len(self)} frames from {names}", flush=True)
+
+    def get_label_name(self, key) -> str:
+        return self.label_names.get(key, f"John Doe Generator {key}")
+
+    def __len__(self) -> int:
+        return int(len(self.audio_data))
+
+    def _load(self, idx: int) -> Tuple[torch.Tensor, int]:
+        path, frame, win, _ = self.audio_data[idx]
+        audio, rate = read_wav_window(str(path), int(frame) * int(win), int(win))
+        if rate > self.resample_rate:
+            from scipy.signal import resample_poly
+
+            g = math.gcd(int(rate), int(self.resample_rate))
+            res = resample_poly(audio.numpy(), self.resample_rate // g, rate // g, axis=-1)
+            audio = torch.from_numpy(np.ascontiguousarray(res, dtype=np.float32))
+        elif rate < self.resample_rate:
+            raise RuntimeError("Sample rate is smaller than desired sample rate. No upsampling possible here.")
+        return audio, rate
+
+    def __getitem__(self, idx: int) -> dict:
+        audio, _ = self._load(idx)
+        return {self.key: audio, "label": torch.tensor(int(self.audio_data[idx, 3]))}
+
+
+class CustomDatasetDetailed(CustomDataset):
+    """``__getitem__`` additionally names the file, frame and offset (reference :356-394)."""
+
+    def __getitem__(self, idx: int) -> dict:
+        audio, rate = self._load(idx)
+        path, frame, win, label = self.audio_data[idx]
+        return {self.key: audio, "label": torch.tensor(int(label)), "sample_rate": rate, "index": idx,
+                "path": str(path), "frame": int(frame), "offset": int(frame) * int(win)}
+
+
+def get_costum_dataset(data_path=None, save_path=None, ds_type="train", only_test_folders=None,
+                       only_use=None, seconds=1, resample_rate=22050, limit=55504, abort_on_save=False,
+                       asvspoof_name=None, train_ratio=0.7, val_ratio=0.1, file_type="wav",
+                       get_details=False, synthetic=False, **_):
+    """Dataset factory (name kept from the reference, data_loader.py:396-507).
+
+    Folders ``<letter>_<name>`` under ``data_path`` become labels ``ord(letter) - 65`` (A = real),
+    the next free integer on a clash; ``only_use`` filters by ``<name>``.  ``synthetic=True`` (or no
+    ``data_path``) returns seeded synthetic frames instead.
+    """
     if synthetic or data_path is None:
         length = int(limit) if limit else 1024
         seed = {"train": 1234, "val": 4321, "test": 9876}.get(ds_type, 1)
         return SyntheticFrames(length, int(resample_rate * (seconds or 1)), seed)
-    raise NotImplementedError(
-        "The on-disk dataset indexer of the reference is out of scope this round "
-        "(SURVEY.md 8(f-3)); pass --synthetic or build the dataset yourself."
-    )
+    paths = sorted(glob.glob(os.path.join(str(data_path), "*_*")))
+    if not paths:
+        raise RuntimeError("Given data_path is empty.")
+    labels: list = []
+    use: list = []
+    for path in paths:
+        base = path.rstrip("/").split("/")[-1]
+        if only_use is not None and base.split("_")[-1] not in only_use:
+            continue
+        want = ord(base.split("_")[0][0]) - 65
+        while want in labels:
+            want += 1
+        labels.append(want)
+        use.append(path)
+    if 0 not in labels and ds_type == "train":
+        raise RuntimeError("No real training data. Aborting...")
+    cls = CustomDatasetDetailed if get_details else CustomDataset
+    return cls(paths=use, labels=labels, save_path=save_path, abort_on_save=abort_on_save, seconds=seconds,
+               resample_rate=resample_rate, verbose=False, limit=limit, ds_type=ds_type,
+               only_test_folders=only_test_folders, asvspoof_name=asvspoof_name, train_ratio=train_ratio,
+               val_ratio=val_ratio, filetype=file_type)

@@ -91,3 +91,45 @@ def test_integrated_gradient_helpers():
     for v in (1.0, 2.0, 6.0):
         m.update(torch.full((1, 2, 2), v))
     assert torch.allclose(m.finalize(), torch.full((2, 2), 3.0))
+
+
+def test_custom_dataset_index_split_and_window_reader(tmp_path):
+    # folder convention, balanced 70/10/20 split, cached .npy index format and windowed WAV reads
+    # of the reference's CustomDataset (data_loader.py:74-353, 396-507)
+    import wave
+
+    import numpy as np
+    import torch
+    from audiofakedetect.data_loader import get_costum_dataset
+
+    rate = 8000
+    rng = np.random.default_rng(0)
+    signals = {}
+    for folder, files in (("A_real", (10, 7)), ("B_fakegan", (9, 12)), ("C_other", (30,))):
+        (tmp_path / "data" / folder).mkdir(parents=True)
+        for j, secs in enumerate(files):
+            pcm = rng.integers(-20000, 20000, size=int(secs * rate + 123), dtype=np.int16)
+            path = tmp_path / "data" / folder / f"f{j}.wav"
+            with wave.open(str(path), "wb") as fh:
+                fh.setnchannels(1); fh.setsampwidth(2); fh.setframerate(rate)
+                fh.writeframes(pcm.tobytes())
+            signals[str(path)] = pcm
+    kw = dict(data_path=str(tmp_path / "data"), save_path=str(tmp_path / "meta"), only_use=["real", "fakegan"],
+              seconds=1, resample_rate=rate, limit=1000)
+    sets = {t: get_costum_dataset(ds_type=t, **kw) for t in ("train", "val", "test")}
+    # 17 and 21 one-second windows -> 11/1/5 and 14/2/5 -> balanced to 11/1/5 per label
+    assert [len(sets[t]) for t in ("train", "val", "test")] == [22, 2, 10]
+    idx = np.load(tmp_path / "meta" / "dataset_real-fakegan_meta_1sec_train.npy", allow_pickle=True)
+    assert idx.shape == (2, 11, 4) and idx[1, 0, 3] == 1 and idx[0, 3, 1] == 3 and idx[0, 0, 2] == rate
+    item = sets["train"][14]  # label 1, its 4th training window
+    path, frame, win, label = sets["train"].audio_data[14]
+    assert label == 1 and item["label"].item() == 1 and item["audio"].shape == (1, rate)
+    want = signals[str(path)][frame * win:(frame + 1) * win].astype(np.float32) / 32768.0
+    assert torch.equal(item["audio"][0], torch.from_numpy(want))
+    assert sets["train"].get_label_name(1) == "fakegan" and len(get_costum_dataset(ds_type="train", **kw)) == 22
+    # resampling down (polyphase) keeps the one-second frame length at the new rate
+    half = get_costum_dataset(ds_type="val", **{**kw, "resample_rate": rate // 2})
+    assert half[0]["audio"].shape == (1, rate // 2)
+    import pytest
+    with pytest.raises(RuntimeError):
+        get_costum_dataset(ds_type="val", **{**kw, "resample_rate": 2 * rate})
