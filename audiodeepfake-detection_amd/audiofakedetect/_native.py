@@ -52,6 +52,8 @@ _SIGNATURES = {
     "afd_conv1_pool_backward": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p]),
     "afd_moments_accumulate": (c_i, [c_p, c_sz, c_p, c_p]),
     "afd_normalize_forward": (c_i, [c_p, c_p, c_sz, c_f, c_f, c_p]),
+    "afd_packet_stats": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
+    "afd_packet_block_norm": (c_i, [c_p, c_i, c_i, c_i, c_p, c_u, c_f, c_f, c_f, c_f, c_p, c_p]),
     "afd_transpose_last2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_prelu_dropout_forward": (c_i, [c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),
     "afd_prelu_dropout_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),

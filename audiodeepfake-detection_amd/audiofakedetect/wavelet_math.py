@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import os
 import pickle
+from collections.abc import Mapping
 from math import log
 from typing import Optional, Tuple
 
@@ -94,6 +95,108 @@ def wpt_forward(
     return out
 
 
+def graycode_keys(level: int) -> list:
+    """Node paths of a level in frequency order (ptwt ``WaveletPacket.get_level``)."""
+    order = ["a", "d"]
+    for _ in range(level - 1):
+        order = ["a" + path for path in order] + ["d" + path for path in order[::-1]]
+    return order
+
+
+class _NodeEstimator:
+    """One node's view onto a `PacketWelford` (the reference keeps a WelfordEstimator per node)."""
+
+    def __init__(self, owner: "PacketWelford", index: int) -> None:
+        self.owner, self.index = owner, index
+
+    def finalize(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        mean, std = self.owner.moments()
+        return mean[self.index:self.index + 1], std[self.index:self.index + 1]
+
+
+class PacketWelford(Mapping):
+    """The reference's ``block_norm_dict`` (node path -> running estimator,
+    wavelet_math.py:188-200) with all of a level's estimators in one device buffer: every
+    update is one fused reduction over the raw coefficients (``afd_packet_stats``) in place
+    of 2^level WelfordEstimator updates.  ``finalize()`` gives the dict the reference stores,
+    ``{path: {"mean": [1], "std": [1]}}`` with population statistics ``sqrt(M2 / count)``."""
+
+    def __init__(self, level: int, device) -> None:
+        self.level = level
+        self.paths = graycode_keys(level)
+        self._index = {k: i for i, k in enumerate(self.paths)}
+        self.sums = torch.zeros((2, 1 << level), dtype=torch.float64, device=device)
+        self.count = 0
+
+    def __getitem__(self, key: str) -> _NodeEstimator:
+        return _NodeEstimator(self, self._index[key])
+
+    def __iter__(self):
+        return iter(self.paths)
+
+    def __len__(self) -> int:
+        return len(self.paths)
+
+    def moments(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.count == 0:
+            raise RuntimeError("PacketWelford: no data seen")
+        mean = self.sums[0] / self.count
+        var = (self.sums[1] / self.count - mean * mean).clamp_min(0.0)
+        return mean.float(), var.sqrt().float()
+
+    def finalize(self) -> dict:
+        mean, std = self.moments()
+        return {k: {"mean": mean[i:i + 1], "std": std[i:i + 1]} for i, k in enumerate(self.paths)}
+
+
+def packet_block_norm(
+    frames: torch.Tensor,
+    wavelet: Wavelet,
+    max_lev: int,
+    log_scale: bool,
+    loss_less: bool,
+    power: float,
+    block_norm: bool,
+    estimators: Optional[PacketWelford],
+    mean: Optional[float] = None,
+    std: Optional[float] = None,
+) -> torch.Tensor:
+    """Packet image with per-node statistics / max normalisation (wavelet_math.py:194-218).
+
+    Raw coefficients -> one statistics pass (per-packet sums into `estimators`, max |v| of this
+    batch) -> divide by the batch's per-node maximum and apply the log / sign / normalise
+    epilogue.  Memory order [B, C, T, P] like `wpt_forward`."""
+    lib = _native.load()
+    raw = wpt_forward(frames, wavelet, max_lev)
+    b, _, t_len, npk = raw.shape
+    if estimators is not None and len(estimators) != npk:
+        raise ValueError("block_norm_dict belongs to another decomposition level")
+    sums = estimators.sums if estimators is not None else torch.zeros(
+        (2, npk), dtype=torch.float64, device=raw.device)
+    absmax = torch.zeros(npk, dtype=torch.float32, device=raw.device)
+    _native.check(lib.afd_packet_stats(_native.ptr(raw), b * t_len, npk, _native.ptr(sums),
+                                       _native.ptr(absmax), _native.stream_ptr()), "afd_packet_stats")
+    if estimators is not None:
+        estimators.count += b * t_len
+    flags = 0
+    nch = 1
+    if log_scale:
+        flags |= _WPT_LOG
+        if loss_less:
+            flags |= _WPT_SIGN
+            nch = 2
+    if mean is not None:
+        flags |= _WPT_NORM
+    if flags == 0 and not block_norm:
+        return raw
+    out = torch.empty((b, nch, t_len, npk), dtype=torch.float32, device=raw.device)
+    _native.check(lib.afd_packet_block_norm(
+        _native.ptr(raw), b, t_len, npk, _native.ptr(absmax) if block_norm else None, flags,
+        float(power), 1e-12, float(mean or 0.0), float(std if std is not None else 1.0),
+        _native.ptr(out), _native.stream_ptr()), "afd_packet_block_norm")
+    return out
+
+
 def compute_pytorch_packet_representation(
     pt_data: torch.Tensor,
     wavelet: Wavelet,
@@ -105,20 +208,21 @@ def compute_pytorch_packet_representation(
     compute_welford: bool = False,
     block_norm_dict=None,
 ) -> Tuple[torch.Tensor, dict]:
-    """Packet image [B, C, T, P] (+ the per-node statistics dict of the reference API).
+    """Packet image [B, C, T, P] (+ the per-node statistics of the reference API).
 
     The reference updates one Welford estimator per node on every call
     (wavelet_math.py:194-200) although the result is only read when ``--block-norm`` is set;
-    here the dict is passed through untouched unless block normalisation is requested.
+    here the estimators run when the caller hands in a `PacketWelford` as ``block_norm_dict``
+    (``calc_normalization`` does under ``--block-norm``), otherwise the dict is passed through.
     """
-    if block_norm:
-        raise NotImplementedError(
-            "block_norm (per-packet max normalisation, wavelet_math.py:202-203) is not part "
-            "of this round's hot path (SURVEY.md 8(f-1))."
-        )
+    estimators = block_norm_dict if (compute_welford and isinstance(block_norm_dict, PacketWelford)) else None
     if block_norm_dict is None:
         block_norm_dict = {}
-    out = wpt_forward(pt_data, wavelet, max_lev, log_scale, loss_less, power)
+    if block_norm or estimators is not None:
+        out = packet_block_norm(pt_data, wavelet, max_lev, log_scale, loss_less, power,
+                                block_norm, estimators)
+    else:
+        out = wpt_forward(pt_data, wavelet, max_lev, log_scale, loss_less, power)
     return out, block_norm_dict
 
 
@@ -149,11 +253,16 @@ class Packets(torch.nn.Module):
         self.fused_norm: Optional[Tuple[float, float]] = None
 
     def forward(self, pt_data: torch.Tensor) -> Tuple[torch.Tensor, dict]:
-        if self.block_norm:
-            raise NotImplementedError("block_norm is not part of this round's hot path")
         mean, std = self.fused_norm if self.fused_norm is not None else (None, None)
-        packets = wpt_forward(pt_data, self.wavelet, self.max_lev, self.log_scale,
-                              self.loss_less, self.power, mean, std)
+        estimators = self.block_norm_dict if (
+            self.compute_welford and isinstance(self.block_norm_dict, PacketWelford)) else None
+        if self.block_norm or estimators is not None:
+            packets = packet_block_norm(pt_data, self.wavelet, self.max_lev, self.log_scale,
+                                        self.loss_less, self.power, self.block_norm, estimators,
+                                        mean, std)
+        else:
+            packets = wpt_forward(pt_data, self.wavelet, self.max_lev, self.log_scale,
+                                  self.loss_less, self.power, mean, std)
         bdict = self.block_norm_dict if self.block_norm_dict is not None else {}
         # logical [B, C, P, T]; memory stays [B, C, T, P] exactly like the reference's view
         return packets.permute(0, 1, 3, 2), bdict
@@ -250,24 +359,38 @@ def get_transforms(
         args.transform, args.wavelet, args.num_of_scales, args.power, loss_less,
         args.sample_rate, args.seconds,
     )
-    if args.block_norm:
-        raise NotImplementedError("block_norm is not part of this round's hot path")
-    if os.path.exists(f"{norm_dir}_mean_std.pkl"):
+    welford_dict: dict = {}
+    bn_files = [f"{norm_dir}_mean_std_bn.pt", f"{norm_dir}_mean_std_bn.pkl"]
+    if os.path.exists(f"{norm_dir}_mean_std.pkl") and not args.block_norm:
         if verbose:
             print("Loading pre calculated mean and std from file.")
         with open(f"{norm_dir}_mean_std.pkl", "rb") as file:
             mean, std = pickle.load(file)
         mean = torch.from_numpy(np.asarray(mean, dtype=np.float32))
         std = torch.from_numpy(np.asarray(std, dtype=np.float32))
+    elif args.block_norm and any(os.path.exists(f) for f in bn_files):
+        # the reference writes `_mean_std_bn.pkl` (:447) and looks for `_mean_std_bn.pt` (:356);
+        # both names are accepted here, `.pt` is what calc_normalization writes
+        if verbose:
+            print("Loading pre calculated mean and std from file.")
+        welford_dict = torch.load(next(f for f in bn_files if os.path.exists(f)), map_location=device)
     elif normalization:
         if verbose:
             print("computing mean and std values.", flush=True)
-        _, mean, std = calc_normalization(args, pbar, transforms, norm_dir)
+        welford_dict, mean, std = calc_normalization(args, pbar, transforms, norm_dir)
     else:
         if verbose:
             print("Using default mean and std.")
         mean = torch.tensor(args.mean if args.mean is not None else 0.0)
         std = torch.tensor(args.std if args.std is not None else 1.0)
+    if args.block_norm:
+        if args.transform != "packets":
+            raise ValueError("--block-norm is defined for the packet transform only")
+        # per-node max normalisation inside the transform, identity Normalize (:373-378)
+        mean, std = torch.tensor(0.0), torch.tensor(1.0)
+        transforms[0].block_norm_dict = welford_dict
+        transforms[0].compute_welford = False
+        transforms[0].block_norm = True
     normalize = torch.nn.Sequential(Normalize(mean, std))
     return transforms, normalize
 
@@ -289,6 +412,10 @@ def calc_normalization(args: DotDict, pbar: bool, transforms: torch.nn.Sequentia
     # scalar mean / std; two-channel (loss-less) features keep the per-channel estimator
     welford = None
     welford_dict = None
+    if args.block_norm:
+        # per-node estimators ride along with the transform (:436-439)
+        transforms[0].block_norm_dict = PacketWelford(transforms[0].max_lev, "cuda")
+        transforms[0].compute_welford = True
     with torch.no_grad():
         for batch in loader:
             feats, welford_dict = transforms(batch["audio"].cuda(non_blocking=True))
@@ -300,6 +427,10 @@ def calc_normalization(args: DotDict, pbar: bool, transforms: torch.nn.Sequentia
                 welford.update(feats.permute(0, 3, 2, 1))
         mean, std = welford.finalize()
     os.makedirs(os.path.dirname(norm_dir), exist_ok=True)
-    with open(f"{norm_dir}_mean_std.pkl", "wb") as f:
-        pickle.dump([mean.cpu().numpy(), std.cpu().numpy()], f)
+    if args.block_norm:
+        welford_dict = welford_dict.finalize()
+        torch.save(welford_dict, f"{norm_dir}_mean_std_bn.pt")
+    else:
+        with open(f"{norm_dir}_mean_std.pkl", "wb") as f:
+            pickle.dump([mean.cpu().numpy(), std.cpu().numpy()], f)
     return welford_dict, mean, std

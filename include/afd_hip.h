@@ -155,6 +155,21 @@ int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx,
  * (acc is device memory, zeroed by the caller before the first batch). */
 int afd_moments_accumulate(const float* x, size_t n, double* acc, afd_stream_t stream);
 
+/* Per-packet statistics and "block norm" of the packet front end: replaces the per-node
+ * WelfordEstimator update and `node_wp / torch.max(torch.abs(node_wp))` inside the node loop of
+ * compute_pytorch_packet_representation (wavelet_math.py:194-203) and the stack / log / sign
+ * steps after it (:206-218).
+ * x      [dev] raw coefficients [rows = B*T][P], P fastest (afd_wpt_forward with flags == 0)
+ * sums   [dev] [2][P] doubles, += sum v and += sum v^2 per packet (zeroed by the caller)
+ * absmax [dev] [P] floats, = max(absmax, max |v|) per packet (zeroed by the caller)
+ * afd_packet_block_norm: out [B][C][T][P] = epilogue(x / absmax[p]) with the AFD_WPT_* flags of
+ * afd_wpt_forward; absmax == NULL applies the epilogue alone. */
+int afd_packet_stats(const float* x, long rows, int P, double* sums, float* absmax,
+                     afd_stream_t stream);
+int afd_packet_block_norm(const float* x, int B, int T, int P, const float* absmax /* may be NULL */,
+                          unsigned flags, float power, float eps, float mean, float std, float* out,
+                          afd_stream_t stream);
+
 /* torchvision Normalize with scalar statistics (wavelet_math.py:380-382): y = (x-mean)/std */
 int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,
                           afd_stream_t stream);

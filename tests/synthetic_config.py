@@ -2,6 +2,8 @@
 (scripts/gridsearch_config.py: a module exposing get_config() -> dict of lists; the model class
 is passed as an object under "module")."""
 
+import os
+
 from src.audiofakedetect.models import DCNN
 
 
@@ -13,5 +15,5 @@ def get_config() -> dict:
         "kernel1": [3], "ochannels1": [64], "ochannels2": [64], "ochannels3": [96],
         "ochannels4": [128], "ochannels5": [32], "hop_length": [220], "sample_rate": [22050],
         "seconds": [1], "time_dim_add": [1], "flattend_size": [320], "validation_interval": [1],
-        "limit_train": [(16, 8, 8)], "block_norm": [False],
+        "limit_train": [(16, 8, 8)], "block_norm": [os.environ.get("AFD_TEST_BLOCK_NORM") == "1"],
     }

@@ -22,6 +22,24 @@ def test_entry_point_runs_like_train_sh(tmp_path):
     assert "seed 0: steps 2" in out.stdout, out.stdout[-2000:]
 
 
+def test_entry_point_with_block_norm_statistics(tmp_path):
+    """--block-norm --calc-normalization: per-node statistics file + max-normalised features
+    (reference wavelet_math.py:356-378, :436-447)."""
+    cmd = [sys.executable, "-m", "src.audiofakedetect.train_classifier", "--log-dir", str(tmp_path),
+           "--transform", "packets", "--wavelet", "sym5", "--num-of-scales", "256", "--log-scale",
+           "--model", "modules", "--init-seeds", "0", "--synthetic", "--block-norm",
+           "--calc-normalization", "--config", os.path.join(ROOT, "tests", "synthetic_config.py")]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, AFD_TEST_BLOCK_NORM="1"))  # the config's grid value wins
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "seed 0: steps 2" in out.stdout, out.stdout[-2000:]
+    files = [f for f in os.listdir(tmp_path / "norms") if f.endswith("_mean_std_bn.pt")]
+    assert len(files) == 1
+    stats = torch.load(tmp_path / "norms" / files[0], map_location="cpu")
+    assert len(stats) == 256 and set(next(iter(stats.values()))) == {"mean", "std"}
+    assert all(k in stats for k in ("a" * 8, "d" + "a" * 7))
+
+
 def test_trainer_train_eval_snapshot_roundtrip(tmp_path):
     sys.path.insert(0, ROOT)
     import bench

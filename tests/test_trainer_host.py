@@ -133,3 +133,13 @@ def test_custom_dataset_index_split_and_window_reader(tmp_path):
     import pytest
     with pytest.raises(RuntimeError):
         get_costum_dataset(ds_type="val", **{**kw, "resample_rate": 2 * rate})
+
+
+def test_graycode_keys_match_oracle_order():
+    from audiofakedetect.wavelet_math import graycode_keys
+    from oracle.wpt_oracle import graycode_paths
+
+    assert graycode_keys(1) == ["a", "d"]
+    assert graycode_keys(2) == ["aa", "ad", "dd", "da"]
+    for level in (3, 8, 14):
+        assert graycode_keys(level) == graycode_paths(level)

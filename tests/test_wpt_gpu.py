@@ -156,3 +156,78 @@ def test_bad_arguments_raise():
         Packets("coif4", max_lev=3)(torch.randn(2, 20).cuda())  # pad >= node length
     with pytest.raises(ValueError):
         Packets("haar", max_lev=3)(torch.randn(2, 2, 100).cuda())
+
+
+@pytest.mark.parametrize("name,level,log_scale,loss_less", [
+    ("haar", 1, False, False), ("sym5", 8, False, False), ("sym5", 8, True, True),
+    ("coif4", 8, True, False), ("haar", 14, True, True), ("coif4", 14, False, False),
+])
+def test_block_norm_matches_oracle(name, level, log_scale, loss_less):
+    """Per-node division by the batch maximum (reference wavelet_math.py:202-203)."""
+    x = _parity_inputs(seed=3)
+    w = wavelets.Wavelet(name)
+    p = Packets(name, max_lev=level, log_scale=log_scale, loss_less=loss_less, block_norm=True)
+    got, _ = p(x.cuda())
+    got = got.cpu().double().numpy()
+    xd = x.double().numpy()
+    coef = wpt_oracle.packet_features(xd, w.dec_lo, level, block_norm=True)[:, 0]
+    ref = wpt_oracle.packet_features(xd, w.dec_lo, level, log_scale=log_scale, loss_less=loss_less,
+                                     block_norm=True)
+    assert got.shape == ref.shape
+    # a node's values are its raw coefficients over the node maximum: both carry COEF_RTOL of the
+    # raw scale, so the quotient is good to a few COEF_RTOL of 1 only where the node maximum is
+    # itself well above the transform's error floor
+    raw = wpt_oracle.packet_features(xd, w.dec_lo, level)[:, 0]
+    node_max = np.max(np.abs(raw), axis=(0, 2), keepdims=True)
+    d = 3 * COEF_RTOL * np.max(np.abs(raw)) / node_max  # error of the quotient, per node
+    d = np.broadcast_to(d, coef.shape)
+    if not log_scale:
+        assert np.all(np.abs(got[:, 0] - coef) <= d + 1e-7)
+        assert np.max(np.abs(got)) <= 1.0 + 1e-6
+        return
+    bound = 1e-5 + 2 * np.abs(coef) * d / (coef ** 2 + 1e-12) + 2e-6 * np.abs(ref[:, 0])
+    assert np.all(np.abs(got[:, 0] - ref[:, 0]) <= bound)
+    if loss_less:
+        sure = np.abs(coef) > d
+        assert np.array_equal(got[:, 1][sure], ref[:, 1][sure])
+
+
+def test_block_norm_is_batch_global():
+    """The maximum runs over the whole batch node tensor, not per frame."""
+    x = _parity_inputs(seed=4).cuda()
+    p = Packets("sym5", max_lev=6, block_norm=True)
+    raw, _ = Packets("sym5", max_lev=6)(x)
+    got, _ = p(x)
+    node_max = raw.abs().amax(dim=(0, 1, 3), keepdim=True)
+    assert torch.equal(got, raw / node_max)
+    assert torch.equal(got.abs().amax(dim=(0, 1, 3)), torch.ones(64, device="cuda"))
+
+
+def test_per_node_estimators_match_reference_welford():
+    """`PacketWelford` vs one WelfordEstimator per node (reference wavelet_math.py:194-200)."""
+    from audiofakedetect.wavelet_math import PacketWelford, graycode_keys
+    from oracle import torch_ref
+
+    level = 5
+    w = wavelets.Wavelet("sym5")
+    batches = [_parity_inputs(seed=5), _parity_inputs(seed=6)[:4]]
+    est = PacketWelford(level, "cuda")
+    p = Packets("sym5", max_lev=level, log_scale=True, compute_welford=True, block_norm_dict=est)
+    plain = Packets("sym5", max_lev=level, log_scale=True)
+    ref_dict = None
+    for xb in batches:
+        got, d = p(xb.cuda())
+        assert d is est
+        # statistics do not touch the features (two log implementations: a few ulp)
+        assert torch.allclose(got, plain(xb.cuda())[0], atol=1e-5, rtol=1e-6)
+        _, ref_dict = torch_ref.packets_torch(xb.double(), w.dec_lo, level, log_scale=True,
+                                              compute_welford=True, welford_dict=ref_dict)
+    assert list(est.keys()) == graycode_keys(level) == wpt_oracle.graycode_paths(level)
+    assert list(ref_dict.keys()) == list(est.keys())
+    final = est.finalize()
+    for k in est.keys():
+        rm, rs = ref_dict[k].finalize()
+        gm, gs = est[k].finalize()
+        assert torch.equal(gm.cpu(), final[k]["mean"].cpu()) and gm.shape == (1,)
+        assert abs(float(gm) - float(rm)) <= 1e-6 * max(1.0, abs(float(rm))) + 2e-7
+        assert abs(float(gs) - float(rs)) <= 1e-5 * float(rs) + 1e-7
