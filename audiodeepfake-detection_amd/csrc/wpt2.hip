@@ -44,6 +44,9 @@ struct W2Params {
     float* ws;
     int B, N, L, level, K1, Ks, G;
     int offA, offB, deepFloats;  // deep kernel LDS carve (floats)
+    // MFMA deep kernel (levels Ks+1 .. Ks+6): per level j the k-steps, the 32-row tiles of the
+    // level matrix, the offset of its fragment table; LDS carve in floats
+    int mf, mfKs[6], mfTiles[6], mfOff[6], mfTab, mfX, mfY, mfC13;
     int n[kMaxLevel + 1];
     unsigned flags;
     float power, eps, mean, std, inv_std;
@@ -82,18 +85,23 @@ __device__ __noinline__ float pow_log_slow(float v, float power, float eps) {
     return logf(powf(fabsf(v), power) + eps);
 }
 
-__device__ __forceinline__ float epilogue2(float v, const W2Params& p, unsigned flags) {
+__device__ __forceinline__ float epilogue_value(float v, unsigned flags, float power, float eps, float mean,
+                                                float inv_std) {
     if (flags & AFD_WPT_LOG) {
-        if (p.power == 2.0f) {
+        if (power == 2.0f) {
             // v*v + eps >= 1e-12 is a normal float: the bare v_log_f32 (log2) needs no
             // denormal pre-scaling; ~1 ulp of log2, < 2e-6 absolute on these features
-            v = __builtin_amdgcn_logf(fmaf(v, v, p.eps)) * 0.6931471805599453f;
+            v = __builtin_amdgcn_logf(fmaf(v, v, eps)) * 0.6931471805599453f;
         } else {
-            v = pow_log_slow(v, p.power, p.eps);
+            v = pow_log_slow(v, power, eps);
         }
     }
-    if (flags & AFD_WPT_NORM) v = (v - p.mean) * p.inv_std;
+    if (flags & AFD_WPT_NORM) v = (v - mean) * inv_std;
     return v;
+}
+
+__device__ __forceinline__ float epilogue2(float v, const W2Params& p, unsigned flags) {
+    return epilogue_value(v, flags, p.power, p.eps, p.mean, p.inv_std);
 }
 
 __device__ __forceinline__ void emit(const W2Params& p, const Sink& s, int mode, int i, int q, int M2,
@@ -456,6 +464,335 @@ __global__ void __launch_bounds__(kDeepThreads) wpt2_deep_kernel(const W2Params 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deep levels on the matrix cores.
+//
+// One analysis step is the same linear map for every node of a level: children = A_k * parent,
+// A_k [2 n_out x n_in] with row 2i + c = filter c (0 = lo, 1 = hi) placed for output i and the
+// reflect extension folded back onto the columns it mirrors.  From level 9 on the rows are mostly
+// dense (L = 24 taps over 25..66 columns), so a level is the GEMM
+//     Y [2 n_out x nodes] = A_k [2 n_out x n_in] * X [n_in x nodes]
+// on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation): no per-tap addressing, no
+// reflect index arithmetic, the nodes (position-major in LDS, as everywhere in this file) are the
+// N dimension.  The D fragment holds rows (2i, 2i+1) = (cA[i], cD[i]) of one node in neighbouring
+// accumulator registers: one 8-byte store puts the two children side by side in the next level.
+//
+// workgroup = (frame, 32 neighbouring level-8 nodes), 8 waves.  Levels 9-11 for all 32 subtrees
+// (32 / 64 / 128 columns), then four passes of 64 level-11 nodes each through levels 12-14
+// (128 / 256 columns; level 14 goes to HBM through the epilogue) -- ~75 KB of LDS, 2 workgroups
+// per CU.  A wave owns one 32-row tile of A_k (fragments in registers, loaded once per level
+// from the table `wpt2_matrices_kernel` wrote) and walks the 32-column tiles.
+// ---------------------------------------------------------------------------------------------
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kMfWaves = 8;
+constexpr int kMfThreads = kMfWaves * 64;
+constexpr int kMfG = 32;       // level-Ks nodes per workgroup
+
+// what the table kernel needs: taps, node lengths, and per level the banded k-range of each tile
+struct MfTabParams {
+    float lo[kMaxTaps], hi[kMaxTaps];
+    int L;
+    int n[7];
+    int ksb[6], tiles[6], off[6];
+    short kst[6][kMfWaves];
+};
+
+// entry (row 2i + c, column col) of the level matrix: the taps m with refl(2i + 1 - m) == col
+__device__ __forceinline__ float level_matrix_entry(const float* lo, const float* hi, int L, int i, int c,
+                                                    int col, int n_in, int n_out) {
+    if (i >= n_out || col >= n_in) return 0.f;
+    const float* f = c ? hi : lo;
+    float v = 0.f;
+    int m = 2 * i + 1 - col;  // position col itself
+    if (m >= 0 && m < L) v += f[m];
+    m = 2 * i + 1 + col;  // position -col, mirrored at the left border
+    if (col > 0 && m < L) v += f[m];
+    m = 2 * i + 1 - (2 * (n_in - 1) - col);  // position 2(n-1) - col, mirrored at the right border
+    if (col < n_in - 1 && m >= 0 && m < L) v += f[m];
+    return v;
+}
+
+// fragment table: for level j, tile mt, k-step s, lane l:
+//   A_j[32 mt + (l & 31)][2 (kst[j][mt] + s) + (l >> 5)],   s < ksb[j] (the tile's band)
+__global__ void __launch_bounds__(64) wpt2_matrices_kernel(const MfTabParams p, float* __restrict__ tab) {
+    __shared__ float lo[kMaxTaps], hi[kMaxTaps];
+    const int lane = threadIdx.x;
+    if (lane < kMaxTaps) {
+        lo[lane] = lane < p.L ? p.lo[lane] : 0.f;
+        hi[lane] = lane < p.L ? p.hi[lane] : 0.f;
+    }
+    __syncthreads();
+    int e = blockIdx.x;
+    int j = 0;
+    while (j < 5 && e >= p.tiles[j] * p.ksb[j]) {
+        e -= p.tiles[j] * p.ksb[j];
+        ++j;
+    }
+    const int mt = e / p.ksb[j], st = e - mt * p.ksb[j];
+    const int row = 32 * mt + (lane & 31), col = 2 * (p.kst[j][mt] + st) + (lane >> 5);
+    tab[p.off[j] + e * 64 + lane] = level_matrix_entry(lo, hi, p.L, row >> 1, row & 1, col, p.n[j], p.n[j + 1]);
+}
+
+// what the deep kernel needs of the plan (a small kernel argument: the full W2Params costs
+// ~250 scalar registers here)
+struct MfParams {
+    const float* ws;
+    const float* tab;
+    float* out;
+    int off[6];                 // fragment-table offset of each level
+    short kst[6][kMfWaves];     // first k-step of each row tile's band
+    int X, Y, C13, level;
+    unsigned flags;
+    float power, eps, mean, inv_std;
+};
+
+struct MfSink {
+    float* outb;     // &out[b][0][0][0] + first packet of this workgroup's pass
+    size_t P, chan;  // packets per row, offset of the sign channel
+};
+
+// Node lengths of the standard 1 s frame (N = 22 050) at levels 8..14: with the shapes known at
+// compile time the k-loops are straight-line code (every LDS offset an immediate, the reads of a
+// tile issued ahead of its MFMAs).  Other geometries stay on the vector kernel above.
+template <int L> struct MfShape;
+template <> struct MfShape<24> { static constexpr int L = 24; static constexpr int n[7] = {109, 66, 44, 33, 28, 25, 24}; };
+template <> struct MfShape<10> { static constexpr int L = 10; static constexpr int n[7] = {95, 52, 30, 19, 14, 11, 10}; };
+template <> struct MfShape<16> { static constexpr int L = 16; static constexpr int n[7] = {101, 58, 36, 25, 20, 17, 16}; };
+
+template <class SH, int J> struct MfLevel {
+    static constexpr int n_in = SH::n[J], n_out = SH::n[J + 1];
+    static constexpr int KS = (n_in + 1) / 2;           // k-steps of the dense matrix (two columns each)
+    static constexpr int T = (2 * n_out + 31) / 32;     // 32-row tiles of the level matrix
+    static constexpr int G = kMfWaves / T;              // waves per tile
+    // a row tile holds outputs 16 t .. 16 t + 15: its non-zero columns are a band of ~L + 30
+    static constexpr int band(int t, bool hi) {
+        int lo_c = n_in, hi_c = 0;
+        for (int i = 16 * t; i < 16 * t + 16 && i < n_out; ++i)
+            for (int m = 0; m < SH::L; ++m) {
+                const int c = refl_c(2 * i + 1 - m, n_in);
+                lo_c = c < lo_c ? c : lo_c;
+                hi_c = c > hi_c ? c : hi_c;
+            }
+        return hi ? hi_c : lo_c;
+    }
+    static constexpr int steps(int t) { return (band(t, true) - (band(t, false) & ~1)) / 2 + 1; }
+    static constexpr int max_steps() {
+        int m = 0;
+        for (int t = 0; t < T; ++t) m = steps(t) > m ? steps(t) : m;
+        return m;
+    }
+    static constexpr int KSB = max_steps();             // k-steps issued per tile
+    static constexpr int kstart(int t) {
+        const int s0 = band(t, false) / 2;
+        return s0 + KSB > KS ? KS - KSB : s0;
+    }
+};
+
+// tiles of one level for one wave: A fragments of row tile mt, column tiles nt0, nt0 + G, ...
+// src: parents, position-major with row stride 1 << LOGS; dst: children with row stride 1 << LOGD
+template <class LV, int LOGS, int LOGD, int NTILES, bool FINAL>
+__device__ __forceinline__ void mfma_level(const MfParams& p, const float (&a)[LV::KSB], int mt, int kst,
+                                           int nt0, const float* __restrict__ src, float* __restrict__ dst,
+                                           const MfSink& fs, int lane) {
+    constexpr int S = 1 << LOGS;
+    const int half = lane >> 5, col = lane & 31;
+    src += (size_t)kst * 2 * S;
+#pragma unroll
+    for (int t = 0; t < (NTILES + LV::G - 1) / LV::G; ++t) {
+        const int nt = nt0 + t * LV::G;
+        if (nt < NTILES) {
+            f16v acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* bp = src + half * S + nt * 32 + col;
+#pragma unroll
+            for (int st = 0; st < LV::KSB; ++st)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], bp[st * 2 * S], acc, 0, 0, 0);
+            // D: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows (2i, 2i+1) = (cA, cD)
+            const int n = nt * 32 + col;
+            // rows of this lane: i = i0 + {0, 1, 4, 5, 8, 9, 12, 13}; the compare masks are rebuilt per
+            // tile (kept across the kernel they would fill the scalar registers)
+            int i0 = mt * 16 + half * 2;
+            asm volatile("" : "+v"(i0));
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int i = i0 + (r >> 2) * 4 + ((r & 3) >> 1);
+                if (i < LV::n_out) {
+                    // odd-frequency parents list their children (d, a).  The values are pinned first:
+                    // a select between acc[r] and acc[r + 1] is otherwise turned into a dynamic
+                    // vector index (a 16-way compare / select chain per element)
+                    float e0 = acc[r], e1 = acc[r + 1];
+                    asm volatile("" : "+v"(e0), "+v"(e1));
+                    f2 v;
+                    v.x = (col & 1) ? e1 : e0;
+                    v.y = (col & 1) ? e0 : e1;
+                    if (!FINAL) {
+                        *reinterpret_cast<f2*>(dst + ((size_t)i << LOGD) + 2 * n) = v;
+                    } else {
+                        const size_t o = (size_t)i * fs.P + 2 * n;
+                        f2 q;
+                        q.x = epilogue_value(v.x, p.flags, p.power, p.eps, p.mean, p.inv_std);
+                        q.y = epilogue_value(v.y, p.flags, p.power, p.eps, p.mean, p.inv_std);
+                        *reinterpret_cast<f2*>(fs.outb + o) = q;
+                        if (p.flags & AFD_WPT_SIGN) {
+                            f2 sg;
+                            sg.x = v.x < 0.f ? -1.f : 1.f;
+                            sg.y = v.y < 0.f ? -1.f : 1.f;
+                            if (p.flags & AFD_WPT_NORM) {
+                                sg.x = (sg.x - p.mean) * p.inv_std;
+                                sg.y = (sg.y - p.mean) * p.inv_std;
+                            }
+                            *reinterpret_cast<f2*>(fs.outb + fs.chan + o) = sg;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void load_fragments(float (&a)[KS], const float* tab, int mt, int lane) {
+    const float* t = tab + (size_t)mt * KS * 64 + lane;
+#pragma unroll
+    for (int st = 0; st < KS; ++st) a[st] = t[st * 64];
+}
+
+template <class SH>
+__global__ void __launch_bounds__(kMfThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+wpt2_deep_mfma_kernel(const MfParams p) {
+    using L0 = MfLevel<SH, 0>;
+    using L1 = MfLevel<SH, 1>;
+    using L2 = MfLevel<SH, 2>;
+    using L3 = MfLevel<SH, 3>;
+    using L4 = MfLevel<SH, 4>;
+    using L5 = MfLevel<SH, 5>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int groups = 256 / kMfG;
+    const int b = blockIdx.x / groups;
+    const int grp = blockIdx.x - b * groups;
+    float* X = lds;
+    float* Y = lds + p.X;
+    // every float the k-loops can touch must be finite (rows past n_in meet zero matrix columns)
+    for (int e = tid; e < p.X + p.Y; e += kMfThreads) lds[e] = 0.f;
+    __syncthreads();
+    {
+        constexpr int n8 = SH::n[0];
+        const float* wsb = p.ws + (size_t)b * n8 * 256 + grp * kMfG;
+        for (int e = tid; e < n8 * kMfG; e += kMfThreads) {
+            const int pos = e >> 5, j = e & 31;
+            X[e] = wsb[(size_t)pos * 256 + j];
+        }
+    }
+    __syncthreads();
+    MfSink fs{};
+    // levels 9 .. 11 over all 32 subtrees: 32 -> 64 -> 128 -> 256 columns
+    if (wave < L0::G * L0::T) {
+        float a[L0::KSB];
+        load_fragments<L0::KSB>(a, p.tab + p.off[0], wave % L0::T, lane);
+        mfma_level<L0, 5, 6, 1, false>(p, a, wave % L0::T, p.kst[0][wave % L0::T], wave / L0::T, X, Y, fs, lane);
+    }
+    __syncthreads();
+    if (wave < L1::G * L1::T) {
+        float a[L1::KSB];
+        load_fragments<L1::KSB>(a, p.tab + p.off[1], wave % L1::T, lane);
+        mfma_level<L1, 6, 7, 2, false>(p, a, wave % L1::T, p.kst[1][wave % L1::T], wave / L1::T, Y, X, fs, lane);
+    }
+    __syncthreads();
+    if (wave < L2::G * L2::T) {
+        float a[L2::KSB];
+        load_fragments<L2::KSB>(a, p.tab + p.off[2], wave % L2::T, lane);
+        mfma_level<L2, 7, 8, 4, false>(p, a, wave % L2::T, p.kst[2][wave % L2::T], wave / L2::T, X, Y, fs, lane);
+    }
+    __syncthreads();
+    // keep the fragment loads of the last three levels below the wide levels (register pressure)
+    asm volatile("" ::: "memory");
+    // levels 12 .. 14 in four passes of 64 level-11 nodes: 64 -> 128 -> 256 columns -> HBM
+    float a3[L3::KSB], a4[L4::KSB], a5[L5::KSB];
+    load_fragments<L3::KSB>(a3, p.tab + p.off[3], wave % L3::T, lane);
+    load_fragments<L4::KSB>(a4, p.tab + p.off[4], wave % L4::T, lane);
+    load_fragments<L5::KSB>(a5, p.tab + p.off[5], wave % L5::T, lane);
+    const int k3 = p.kst[3][wave % L3::T], k4 = p.kst[4][wave % L4::T], k5 = p.kst[5][wave % L5::T];
+    float* C12 = X;
+    float* C13 = X + p.C13;
+    fs.P = (size_t)1 << p.level;
+    fs.chan = (size_t)SH::n[6] * fs.P;
+    const size_t nch = (p.flags & AFD_WPT_SIGN) ? 2 : 1;
+    float* outb = p.out + (size_t)b * nch * fs.chan + (size_t)grp * kMfG * 64;
+    for (int c = 0; c < 4; ++c) {
+        if (wave < L3::G * L3::T)
+            mfma_level<L3, 8, 7, 2, false>(p, a3, wave % L3::T, k3, wave / L3::T, Y + c * 64, C12, fs, lane);
+        __syncthreads();
+        if (wave < L4::G * L4::T)
+            mfma_level<L4, 7, 8, 4, false>(p, a4, wave % L4::T, k4, wave / L4::T, C12, C13, fs, lane);
+        __syncthreads();
+        fs.outb = outb + c * 512;
+        if (wave < L5::G * L5::T)
+            mfma_level<L5, 8, 0, 8, true>(p, a5, wave % L5::T, k5, wave / L5::T, C13, nullptr, fs, lane);
+        // the next pass overwrites C12 only after every wave left this pass's first two levels;
+        // C13 is rewritten after the barrier that follows the next pass's first level
+    }
+}
+
+template <int L> struct MfHas { static constexpr bool value = false; };
+template <> struct MfHas<24> { static constexpr bool value = true; };
+template <> struct MfHas<10> { static constexpr bool value = true; };
+template <> struct MfHas<16> { static constexpr bool value = true; };
+
+template <int L>
+bool mf_shape_matches(const W2Params& p) {
+    if constexpr (MfHas<L>::value) {
+        for (int j = 0; j < 7; ++j)
+            if (p.n[8 + j] != MfShape<L>::n[j]) return false;
+        return true;
+    }
+    return false;
+}
+
+template <int L>
+int launch_deep_mfma(const W2Params& p, hipStream_t stream) {
+    if constexpr (MfHas<L>::value) {
+        static bool mf_attr = false;
+        if (!mf_attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt2_deep_mfma_kernel<MfShape<L>>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            mf_attr = true;
+        }
+        using SH = MfShape<L>;
+        float* tab = p.ws + (size_t)p.B * p.n[p.Ks] * ((size_t)1 << p.Ks);
+        MfTabParams tp{};
+        MfParams q{};
+        for (int m = 0; m < L; ++m) { tp.lo[m] = p.lo[m]; tp.hi[m] = p.hi[m]; }
+        tp.L = L;
+        for (int j = 0; j < 7; ++j) tp.n[j] = SH::n[j];
+        int off = 0;
+        auto level = [&](int j, int ksb, int tiles, auto kstart) {
+            tp.ksb[j] = ksb; tp.tiles[j] = tiles; tp.off[j] = q.off[j] = off;
+            for (int t = 0; t < tiles; ++t) tp.kst[j][t] = q.kst[j][t] = (short)kstart(t);
+            off += tiles * ksb * 64;
+        };
+        level(0, MfLevel<SH, 0>::KSB, MfLevel<SH, 0>::T, MfLevel<SH, 0>::kstart);
+        level(1, MfLevel<SH, 1>::KSB, MfLevel<SH, 1>::T, MfLevel<SH, 1>::kstart);
+        level(2, MfLevel<SH, 2>::KSB, MfLevel<SH, 2>::T, MfLevel<SH, 2>::kstart);
+        level(3, MfLevel<SH, 3>::KSB, MfLevel<SH, 3>::T, MfLevel<SH, 3>::kstart);
+        level(4, MfLevel<SH, 4>::KSB, MfLevel<SH, 4>::T, MfLevel<SH, 4>::kstart);
+        level(5, MfLevel<SH, 5>::KSB, MfLevel<SH, 5>::T, MfLevel<SH, 5>::kstart);
+        if (off > p.mfTab) return afd::fail(AFD_ERR_WORKSPACE, "wpt: fragment table larger than planned");
+        hipLaunchKernelGGL(wpt2_matrices_kernel, dim3((unsigned)(off / 64)), dim3(64), 0, stream, tp, tab);
+        q.ws = p.ws; q.tab = tab; q.out = p.out;
+        q.X = p.mfX; q.Y = p.mfY; q.C13 = p.mfC13; q.level = p.level;
+        q.flags = p.flags; q.power = p.power; q.eps = p.eps; q.mean = p.mean; q.inv_std = p.inv_std;
+        hipLaunchKernelGGL(wpt2_deep_mfma_kernel<MfShape<L>>, dim3((unsigned)p.B * (256 / kMfG)), dim3(kMfThreads),
+                           (size_t)(p.mfX + p.mfY) * 4, stream, q);
+    }
+    return AFD_OK;
+}
+
 int child_len2(int n, int L) { return (n + L - 2 + (n & 1)) / 2; }
 
 // returns 0, or 1 when this geometry is left to the first-generation kernel
@@ -504,6 +841,28 @@ int make_plan2(W2Params& p) {
         if (best == 0) return 1;
         p.G = best;
     }
+    // matrix-core path for the six levels below Ks = 8 (the level-14 transforms of 1 s frames)
+    p.mf = 0;
+    if (p.Ks == 8 && p.level == 14 && p.L > 2 && !getenv("AFD_WPT_NO_MFMA")) {
+        bool ok = true;
+        int off = 0;
+        for (int j = 0; j < 6; ++j) {
+            p.mfKs[j] = (p.n[8 + j] + 1) / 2;
+            p.mfTiles[j] = (2 * p.n[9 + j] + 31) / 32;
+            p.mfOff[j] = off;
+            off += p.mfTiles[j] * p.mfKs[j] * 64;
+            ok = ok && p.mfTiles[j] <= kMfWaves;
+        }
+        p.mfTab = off;
+        auto mx = [](int a, int b) { return a > b ? a : b; };
+        // buffers hold 2 * k-steps rows (the k-loop's reach) of the level's column count
+        p.mfC13 = 2 * p.mfKs[4] * 128;
+        p.mfX = mx(mx(2 * p.mfKs[0] * 32, 2 * p.mfKs[2] * 128), p.mfC13 + 2 * p.mfKs[5] * 256);
+        p.mfY = mx(2 * p.mfKs[1] * 64, 2 * p.mfKs[3] * 256);
+        // children written by a level must fit the rows its reader allocates
+        for (int j = 0; j < 5; ++j) ok = ok && p.n[9 + j] <= 2 * p.mfKs[j + 1];
+        if (ok && (size_t)(p.mfX + p.mfY) * 4 <= 80 * 1024) p.mf = 1;
+    }
     return 0;
 }
 
@@ -524,7 +883,10 @@ int launch2(const W2Params& p, hipStream_t stream) {
     afd::ScopedTiming timing(AFD_K_WPT, 4.0 * p.B * ((double)p.N + (double)C * p.n[p.level] * (double)(1L << p.level)), stream);
     hipLaunchKernelGGL(wpt2_top_kernel<L>, dim3((unsigned)p.B << p.K1), dim3(kTopThreads),
                        (size_t)kTopLdsFloats * 4, stream, p);
-    if (p.level > p.Ks) {
+    if (p.level > p.Ks && p.mf && mf_shape_matches<L>(p)) {
+        const int rc = launch_deep_mfma<L>(p, stream);
+        if (rc != AFD_OK) return rc;
+    } else if (p.level > p.Ks) {
         const unsigned groups = (1u << p.Ks) / p.G;
         hipLaunchKernelGGL(wpt2_deep_kernel<L>, dim3((unsigned)p.B * groups), dim3(kDeepThreads),
                            (size_t)p.deepFloats * 4, stream, p);
@@ -541,7 +903,7 @@ size_t wpt2_workspace_bytes(int B, int N, int L, int level) {
     W2Params p{};
     p.B = B; p.N = N; p.L = L; p.level = level;
     if (make_plan2(p) != 0 || level <= p.Ks) return 0;
-    return (size_t)B * p.n[p.Ks] * ((size_t)1 << p.Ks) * sizeof(float);
+    return ((size_t)B * p.n[p.Ks] * ((size_t)1 << p.Ks) + (p.mf ? (size_t)p.mfTab : 0)) * sizeof(float);
 }
 
 // returns AFD_OK, an error, or 1 = "not handled here, use the first-generation kernel"
@@ -561,7 +923,7 @@ int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float*
     }
     if (make_plan2(p) != 0) return 1;
     if (level > p.Ks) {
-        const size_t need = (size_t)B * p.n[p.Ks] * ((size_t)1 << p.Ks) * sizeof(float);
+        const size_t need = ((size_t)B * p.n[p.Ks] * ((size_t)1 << p.Ks) + (p.mf ? (size_t)p.mfTab : 0)) * sizeof(float);
         if (!ws || ws_bytes < need) return afd::fail(AFD_ERR_WORKSPACE, "wpt: workspace of %zu bytes needed", need);
     }
     switch (L) {
