@@ -65,20 +65,33 @@ class DCNN(nn.Module):
             # STFT features are dense [B, C, F, T]: one tiled transpose on the GPU
             h = ops.transpose_contiguous(x.contiguous())
         cnn = self.cnn
-        for conv_i, prelu_i, pooled, bn_i in self._cnn_plan:
+        pending_bn = None  # a BatchNorm waiting to be folded into the 1x1 convolution after it
+        for step, (conv_i, prelu_i, pooled, bn_i) in enumerate(self._cnn_plan):
             conv = cnn[conv_i]
             slope = cnn[prelu_i].weight
+            nxt = self._cnn_plan[step + 1] if step + 1 < len(self._cnn_plan) else None
+            fold_next = (bn_i is not None and pooled and nxt is not None
+                         and ops.bn_conv1x1_applicable(cnn[bn_i], cnn[nxt[0]]))
             if (pooled and conv.in_channels == 1 and conv.kernel_size == (3, 3)
                     and conv.dilation == (1, 1) and not h.requires_grad):
                 # single-channel first block: conv + PReLU + pool in one kernel
                 h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0])
-                if bn_i is not None:
+                if fold_next:
+                    pending_bn = cnn[bn_i]
+                elif bn_i is not None:
                     h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
                 continue
-            z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled)
+            if pending_bn is not None:
+                # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
+                z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)
+                pending_bn = None
+            else:
+                z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled)
             if pooled:
                 h = ops.prelu_maxpool2x2(z, slope)
-                if bn_i is not None:
+                if fold_next:
+                    pending_bn = cnn[bn_i]
+                elif bn_i is not None:
                     h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
             else:
                 h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn)

@@ -470,6 +470,126 @@ class _BatchNorm(torch.autograd.Function):
         return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None
 
 
+class _BNConv1x1(torch.autograd.Function):
+    """BatchNorm2d(affine=False) followed by Conv2d(k=1, pad 0) as ONE pass over the activations
+    in each direction (DCNN blocks 1 -> 2, reference models.py:260-262).
+
+    The normalisation is a per-channel scale and shift of the convolution's input, so it folds into
+    the weights: z = (w * invstd) . u + (b - (w * invstd) . mean), with u the un-normalised tensor
+    (the normalised one is never written).  Backward: the weight / bias gradients against u give
+    those against xhat by the same algebra, the two batch means of the BatchNorm backward are
+    sum_co w dbias and sum_co w dw, and the input gradient is the backward-data GEMM with the folded
+    weights plus alpha * u + beta (`afd_conv1x1_bn_backward_data`)."""
+
+    @staticmethod
+    def forward(ctx, u, w, b, running_mean, running_var, nbt, training, momentum, eps, sync):
+        lib = _lib()
+        u = _f32c(u)
+        n, c, h, wd = u.shape
+        cout = w.shape[0]
+        hw = h * wd
+        dev = u.device
+        count = float(n * hw)
+        if training:
+            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+            _native.check(lib.afd_bn_stats(_native.ptr(u), None, _native.ptr(sums), n, c, hw,
+                                           _native.stream_ptr()), "afd_bn_stats")
+            dist_on = _dist_on(sync)
+            if dist_on:
+                sums[2 * c] = count
+                dist.all_reduce(sums)
+            mean = torch.empty(c, dtype=torch.float32, device=dev)
+            invstd = torch.empty(c, dtype=torch.float32, device=dev)
+            cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
+            mom = momentum
+            if mom is None:
+                mom = 1.0 / float(int(nbt) + 1) if nbt is not None else 0.0
+            with torch.no_grad():
+                _native.check(lib.afd_bn_finalize(
+                    _native.ptr(sums), c, -1.0 if dist_on else count, float(eps), float(mom),
+                    _native.ptr(mean), _native.ptr(invstd), _native.ptr(running_mean),
+                    _native.ptr(running_var), _native.ptr(nbt), _native.ptr(cnt),
+                    _native.stream_ptr()), "afd_bn_finalize")
+            ctx.count = cnt if dist_on else count
+        else:
+            mean = running_mean
+            invstd = torch.rsqrt(running_var + eps)
+        w2 = _f32c(w).reshape(cout, c)
+        wf = (w2 * invstd).contiguous()
+        bf = -(wf @ mean)
+        if b is not None:
+            bf = bf + b
+        z = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
+        nbytes = lib.afd_conv2d_workspace_bytes(n, c, h, wd, cout, 1, 0, 1)
+        ws = _ws(nbytes, dev)
+        _native.check(lib.afd_conv2d_forward(
+            _native.ptr(u), _native.ptr(wf), _native.ptr(bf), _native.ptr(z), n, c, h, wd, cout, 1, 0, 1,
+            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_forward")
+        ctx.save_for_backward(u, w2, wf, mean, invstd)
+        ctx.geom = (n, c, h, wd, cout)
+        ctx.flags = (training, sync, b is not None, tuple(w.shape))
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = _lib()
+        u, w2, wf, mean, invstd = ctx.saved_tensors
+        n, c, h, wd, cout = ctx.geom
+        training, sync, has_bias, wshape = ctx.flags
+        dz = _f32c(dz)
+        dev = u.device
+        nbytes = lib.afd_conv2d_workspace_bytes(n, c, h, wd, cout, 1, 0, 1)
+        ws = _ws(nbytes, dev)
+        # gradients against the un-normalised input, then against xhat = (u - mean) * invstd
+        g = torch.empty((cout, c), dtype=torch.float32, device=dev)
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
+        _native.check(lib.afd_conv2d_backward_weight(
+            _native.ptr(u), _native.ptr(dz), _native.ptr(g), _native.ptr(db), n, c, h, wd, cout, 1, 0, 1,
+            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_weight")
+        dw = (g - db[:, None] * mean[None, :]) * invstd[None, :]
+        du = None
+        if ctx.needs_input_grad[0]:
+            du = torch.empty_like(u)
+            if training:
+                # sum over pixels of dxhat and of dxhat * xhat, from the small matrices alone
+                sums = torch.stack([w2.t() @ db, (w2 * dw).sum(0)]).double().reshape(-1)
+                if _dist_on(sync):
+                    dist.all_reduce(sums)
+                cnt = ctx.count if torch.is_tensor(ctx.count) else float(ctx.count)
+                m1 = (sums[:c] / cnt).float()
+                m2 = (sums[c:] / cnt).float()
+                s2m2 = invstd * invstd * m2
+                alpha = (-s2m2).contiguous()
+                beta = (s2m2 * mean - invstd * m1).contiguous()
+                _native.check(lib.afd_conv1x1_bn_backward_data(
+                    _native.ptr(dz), _native.ptr(wf), _native.ptr(u), _native.ptr(alpha),
+                    _native.ptr(beta), _native.ptr(du), n, c, cout, h * wd, _native.stream_ptr()),
+                    "afd_conv1x1_bn_backward_data")
+            else:
+                _native.check(lib.afd_conv2d_backward_data(
+                    _native.ptr(dz), _native.ptr(wf), _native.ptr(du), n, c, h, wd, cout, 1, 0, 1,
+                    _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
+        return (du, dw.reshape(wshape) if ctx.needs_input_grad[1] else None,
+                db if (has_bias and ctx.needs_input_grad[2]) else None,
+                None, None, None, None, None, None, None)
+
+
+def bn_conv1x1(u, bn: torch.nn.Module, w, b, sync: bool = True):
+    """conv1x1(batch_norm(u)) for a BatchNorm without affine parameters, without materialising the
+    normalised tensor (see `_BNConv1x1`)."""
+    training = bn.training or bn.running_mean is None
+    return _BNConv1x1.apply(u, w, b, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                            training, bn.momentum, bn.eps, sync)
+
+
+def bn_conv1x1_applicable(bn: torch.nn.Module, conv: torch.nn.Module) -> bool:
+    import os
+    return (not os.environ.get("AFD_NO_BN_FOLD") and bn.weight is None and bn.bias is None
+            and bn.running_mean is not None
+            and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.stride == (1, 1)
+            and conv.in_channels <= 128 and conv.out_channels <= 128)
+
+
 def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True):
     """BatchNorm (batch statistics across all ranks when a process group is up) of
     PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats."""

@@ -59,6 +59,9 @@ int conv1x1_forward(const float* x, const float* w, const float* bias, float* y,
                     int Cout, long HW, hipStream_t s);
 int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout,
                           long HW, hipStream_t s);
+int conv1x1_backward_data_affine(const float* dy, const float* w, const float* res, const float* alpha,
+                                 const float* beta, float* dx, int N, int Cin, int Cout, long HW,
+                                 hipStream_t s);
 int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin,
                             int Cout, long HW, void* ws, size_t ws_bytes, hipStream_t s);
 

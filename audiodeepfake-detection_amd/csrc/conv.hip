@@ -1357,6 +1357,17 @@ extern "C" int afd_conv2d_forward_cropped(const float* x, const float* w, const 
     return launch_igemm(g, x, wp, bias, y, s);
 }
 
+extern "C" int afd_conv1x1_bn_backward_data(const float* dz, const float* wf, const float* u,
+                                            const float* alpha, const float* beta, float* du, int N,
+                                            int Cin, int Cout, long HW, afd_stream_t stream) {
+    if (!dz || !wf || !u || !alpha || !beta || !du) return afd::fail(AFD_ERR_ARG, "conv1x1 bn dgrad: null pointer");
+    if (N < 1 || Cin < 1 || Cout < 1 || HW < 1 || HW > 0x7fffffffL)
+        return afd::fail(AFD_ERR_ARG, "conv1x1 bn dgrad: bad shape");
+    if (Cin > 128 || Cout > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1 bn dgrad: more than 128 channels");
+    return afd::conv1x1_backward_data_affine(dz, wf, u, alpha, beta, du, N, Cin, Cout, HW,
+                                             static_cast<hipStream_t>(stream));
+}
+
 extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* dx, int N, int Cin,
                                         int H, int W, int Cout, int K, int pad, int dil, void* ws,
                                         size_t ws_bytes, afd_stream_t stream) {

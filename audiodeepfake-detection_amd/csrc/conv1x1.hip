@@ -39,10 +39,14 @@ struct VecU<4> { typedef float type __attribute__((ext_vector_type(4), aligned(4
 // pixels.  Lane l of the B fragment holds pixels NW*l .. NW*l+NW-1 (one wide load per channel
 // row): MFMA pixel tile i is the pixels NW*l + i, so the NW accumulator tiles of a lane are
 // NW consecutive pixels again and leave as one wide store per output channel.
-template <int MW, int NW>
+// AFF: the epilogue adds a per-output-channel affine function of a second tensor of the output's
+// shape, y = W.x + alpha[c] * res + beta[c] (the BatchNorm backward folded into the backward-data
+// GEMM of the 1x1 convolution that follows the normalisation, see afd_conv1x1_bn_backward_data).
+template <int MW, int NW, bool AFF>
 __global__ void __launch_bounds__(256)
 conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict__ w,
-               const float* __restrict__ bias, float* __restrict__ y) {
+               const float* __restrict__ bias, float* __restrict__ y, const float* __restrict__ res,
+               const float* __restrict__ alpha) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];  // [Kpad][MW*32], k-major
     typedef typename VecU<NW>::type vec_t;
     constexpr int CO_PAD = MW * 32;
@@ -130,6 +134,51 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
             const bool full = p + NW <= g.HW;
             if (p < g.HW) {
                 float* yn = y + (size_t)n * g.Cout * HW + p;
+                if constexpr (AFF) {
+                    const float* rn = res + (size_t)n * g.Cout * HW + p;
+#pragma unroll
+                    for (int m = 0; m < MW; ++m) {
+#pragma unroll
+                        for (int r0 = 0; r0 < 16; r0 += 8) {
+                            // eight rows of the second operand in flight, then their FMAs and stores
+                            vec_t u[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = m * 32 + ((r0 + j) & 3) + 8 * ((r0 + j) >> 2) + 4 * half;
+#pragma unroll
+                                for (int i = 0; i < NW; ++i) u[j][i] = 0.f;
+                                if (co < g.Cout) {
+                                    const float* q = rn + (size_t)co * HW;
+                                    if (full) {
+                                        u[j] = *reinterpret_cast<const vec_t*>(q);
+                                    } else {
+#pragma unroll
+                                        for (int i = 0; i < NW; ++i)
+                                            if (p + i < g.HW) u[j][i] = q[i];
+                                    }
+                                }
+                            }
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int r = r0 + j;
+                                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                                if (co >= g.Cout) continue;
+                                const float bv = bias[co], av = alpha[co];
+                                float* o = yn + (size_t)co * HW;
+                                if (full) {
+                                    vec_t v;
+#pragma unroll
+                                    for (int i = 0; i < NW; ++i) v[i] = fmaf(av, u[j][i], acc[m][i][r] + bv);
+                                    *reinterpret_cast<vec_t*>(o) = v;
+                                } else {
+#pragma unroll
+                                    for (int i = 0; i < NW; ++i)
+                                        if (p + i < g.HW) o[i] = fmaf(av, u[j][i], acc[m][i][r] + bv);
+                                }
+                            }
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int m = 0; m < MW; ++m) {
 #pragma unroll
@@ -307,7 +356,8 @@ int num_cus() {
 }
 
 template <int MW, int NW>
-int launch_gemm(G1 g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+int launch_gemm(G1 g, const float* x, const float* w, const float* bias, float* y, hipStream_t s,
+                const float* res = nullptr, const float* alpha = nullptr) {
     g.tiles_per_img = (g.HW + 32 * NW - 1) / (32 * NW);
     const long nt = (long)g.N * g.tiles_per_img;
     if (nt > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1: too many tiles");
@@ -317,16 +367,22 @@ int launch_gemm(G1 g, const float* x, const float* w, const float* bias, float* 
     long blocks = (nt + 3) / 4;
     const long cap = (long)num_cus() * 4;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((conv1x1_kernel<MW, NW>), dim3((unsigned)blocks), dim3(256), lds, s, g, x, w, bias, y);
+    if (res)
+        hipLaunchKernelGGL((conv1x1_kernel<MW, NW, true>), dim3((unsigned)blocks), dim3(256), lds, s, g, x, w,
+                           bias, y, res, alpha);
+    else
+        hipLaunchKernelGGL((conv1x1_kernel<MW, NW, false>), dim3((unsigned)blocks), dim3(256), lds, s, g, x, w,
+                           bias, y, res, alpha);
     return afd::check_launch("conv1x1_kernel");
 }
 
-int run_gemm(const G1& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s) {
+int run_gemm(const G1& g, const float* x, const float* w, const float* bias, float* y, hipStream_t s,
+             const float* res = nullptr, const float* alpha = nullptr) {
     switch ((g.Cout + 31) / 32) {
-        case 1: return launch_gemm<1, 4>(g, x, w, bias, y, s);
-        case 2: return launch_gemm<2, 4>(g, x, w, bias, y, s);
-        case 3: return launch_gemm<3, 2>(g, x, w, bias, y, s);
-        case 4: return launch_gemm<4, 2>(g, x, w, bias, y, s);
+        case 1: return launch_gemm<1, 4>(g, x, w, bias, y, s, res, alpha);
+        case 2: return launch_gemm<2, 4>(g, x, w, bias, y, s, res, alpha);
+        case 3: return launch_gemm<3, 2>(g, x, w, bias, y, s, res, alpha);
+        case 4: return launch_gemm<4, 2>(g, x, w, bias, y, s, res, alpha);
     }
     return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1: Cout %d > 128", g.Cout);
 }
@@ -395,6 +451,16 @@ int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int
     g.N = N; g.Cin = Cout; g.Cout = Cin; g.HW = (int)HW; g.trans = 1;
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
     return run_gemm(g, dy, w, nullptr, dx, s);
+}
+
+// dx[n][ci][p] = sum_co w[co][ci] dy[n][co][p] + alpha[ci] * res[n][ci][p] + beta[ci]
+int conv1x1_backward_data_affine(const float* dy, const float* w, const float* res, const float* alpha,
+                                 const float* beta, float* dx, int N, int Cin, int Cout, long HW,
+                                 hipStream_t s) {
+    G1 g{};
+    g.N = N; g.Cin = Cout; g.Cout = Cin; g.HW = (int)HW; g.trans = 1;
+    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    return run_gemm(g, dy, w, beta, dx, s, res, alpha);
 }
 
 int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin,

@@ -111,6 +111,18 @@ int afd_conv2d_forward(const float* x, const float* w, const float* bias /* may 
 int afd_conv2d_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int H,
                              int W, int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
                              afd_stream_t stream);
+
+/* BatchNorm2d(affine=False) -> Conv2d(k=1, pad 0) pair (reference models.py:260-262, DCNN blocks 1-2).
+ * Forward needs no kernel of its own: the normalisation is a per-input-channel scale and shift, so the
+ * caller folds it into the weights (wf[co][ci] = w[co][ci] * invstd[ci], bf = b - wf . mean) and runs
+ * afd_conv2d_forward on the un-normalised tensor u.  Backward through both layers in one GEMM:
+ *   du[n][ci][p] = sum_co wf[co][ci] dz[n][co][p] + alpha[ci] * u[n][ci][p] + beta[ci]
+ * with alpha = -invstd^2 * E[dxhat xhat], beta = invstd^2 * E[dxhat xhat] * mean - invstd * E[dxhat]
+ * (the batch means follow from the 1x1 weight / bias gradients, no pass over the activations).
+ * Replaces, for this pair, cudnn's batch-norm backward + the convolution's backward-data. */
+int afd_conv1x1_bn_backward_data(const float* dz, const float* wf, const float* u, const float* alpha,
+                                 const float* beta, float* du, int N, int Cin, int Cout, long HW,
+                                 afd_stream_t stream);
 int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                float* dbias /* may be NULL */, int N, int Cin, int H, int W,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,

@@ -318,3 +318,50 @@ def test_conv_feeding_maxpool_skips_the_unused_row_and_column(shape):
     _close(wg.grad, wr.grad, 3e-5, "wgrad")
     _close(bg.grad, br.grad, 2e-5, "dbias")
     _close(sg.grad, sr.grad, 1e-4, "dslope")
+
+
+@pytest.mark.parametrize("shape,cout,training", [
+    ((4, 64, 13, 257), 64, True), ((3, 64, 5, 1031), 64, True), ((2, 32, 7, 130), 96, True),
+    ((4, 64, 13, 257), 64, False),
+])
+def test_batchnorm_folded_into_the_1x1_convolution(shape, cout, training):
+    """BatchNorm2d(affine=False) -> Conv2d(k=1) in one pass per direction (reference
+    models.py:260-262) against the same two layers in float64: output, input gradient (the
+    BatchNorm backward rebuilt from the 1x1 weight / bias gradients), weight and bias gradients,
+    running statistics."""
+    torch.manual_seed(5)
+    n, c, h, w = shape
+    # post-pool activations: positive, mean comparable to the spread
+    u = (torch.randn(shape).abs() * 0.7 + 0.3 * torch.rand(1, c, 1, 1)).cuda().requires_grad_(True)
+    conv = torch.nn.Conv2d(c, cout, 1).cuda()
+    bn = torch.nn.BatchNorm2d(c, affine=False).cuda()
+    bn.train(training)
+    if not training:
+        bn.running_mean.copy_(torch.rand(c) * 0.5)
+        bn.running_var.copy_(torch.rand(c) + 0.5)
+    assert ops.bn_conv1x1_applicable(bn, conv)
+    ref_bn = torch.nn.BatchNorm2d(c, affine=False).double().cuda()
+    ref_bn.load_state_dict(bn.state_dict())
+    ref_bn.train(training)
+    ref_conv = torch.nn.Conv2d(c, cout, 1).double().cuda()
+    ref_conv.load_state_dict(conv.state_dict())
+    u64 = u.detach().double().requires_grad_(True)
+    dz = torch.randn(n, cout, h, w, device="cuda")
+
+    z = ops.bn_conv1x1(u, bn, conv.weight, conv.bias, sync=False)
+    z.backward(dz)
+    zr = ref_conv(ref_bn(u64))
+    zr.backward(dz.double())
+
+    def close(a, b, tol):
+        scale = b.abs().max().item()
+        assert (a.double() - b).abs().max().item() <= tol * scale, ((a.double() - b).abs().max().item(), scale)
+
+    close(z, zr, 2e-6)
+    close(u.grad, u64.grad, 2e-5)
+    close(conv.weight.grad, ref_conv.weight.grad, 2e-5)
+    close(conv.bias.grad, ref_conv.bias.grad, 2e-6)
+    if training:
+        close(bn.running_mean, ref_bn.running_mean, 1e-6)
+        close(bn.running_var, ref_bn.running_var, 1e-6)
+        assert int(bn.num_batches_tracked) == 1
