@@ -1,0 +1,305 @@
+// 3x3 / pad 1 / stride 1 convolutions, forward and backward-data, as Winograd F(2x2, 3x3) on the
+// f32 MFMA: 16 multiplies per 2x2 output tile and channel pair instead of 36 (2.25x fewer matrix
+// instructions than the direct implicit GEMM of conv3x3.hip), arithmetic still fp32 end to end.
+//
+// Reference: the cuDNN launches behind nn.Conv2d(k=3, padding=1) of DCNN blocks 3-6
+// (src/audiofakedetect/models.py:263-278) and their backward-data passes.
+//
+//   V = B^T d B   (4x4 input patch d of a tile, per input channel)           vector ALU
+//   U = G g G^T   (3x3 filter g, per (cout, cin))                            wino_weights_kernel
+//   M[p] = sum_cin U[p][cout][cin] V[p][cin][tile]   for the 16 positions p  16 GEMMs on the MFMA
+//   Y = A^T M A   (2x2 outputs of the tile, per output channel)              vector ALU via LDS
+//
+// workgroup = 8 waves = one row of 32 tiles (2 output rows x 64 output columns) x all output
+// channels.  Wave w owns positions 2w, 2w+1 for every 32-channel tile of Cout (accumulators:
+// 2 x MT x 16 registers).  Per chunk of 8 input channels: thread (channel, tile) loads its 4x4
+// patch straight from global memory (interior workgroups: four unaligned 16-byte loads), transforms
+// it and writes its 8 or 16 values of V into a double-buffered LDS image [position][channel][tile]
+// -- B fragments are rows of 32 consecutive floats; the U fragments come from a table in fragment
+// order (one 256-byte load each, L2 resident) issued before the transform.  One barrier per chunk.
+// Epilogue: per 32-channel tile the 16 positions meet in LDS, thread (cout, tile) applies A^T . A,
+// adds the bias and stores two 8-byte pairs.
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+constexpr int kCh = 8;        // input channels per chunk (4 k-steps)
+constexpr int kTiles = 32;    // tiles per workgroup (one MFMA column tile)
+constexpr int kThreads = 512;
+
+struct GW {
+    int N, Cin, Cout, H, W;
+    int rows, cols;      // output rows / columns that are wanted (crop for a following 2x2 pool)
+    int tilesX, tilesY;  // 2x2 tiles covering rows x cols
+    int wgX;             // workgroups per tile row
+    int nchunks;
+};
+
+// U table: [chunk][position][mt][kstep][lane] = U_p[32 mt + (lane & 31)][8 chunk + 2 kstep + (lane >> 5)]
+// dgrad: the GEMM's output channels are the forward's input channels, taps flipped
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
+                                    int MT, int nchunks, int dgrad) {
+    const int total = nchunks * 16 * MT * 4 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane = i & 63;
+        const int ks = (i >> 6) & 3;
+        int r = i >> 8;
+        const int mt = r % MT;
+        r /= MT;
+        const int p = r & 15;
+        const int chunk = r >> 4;
+        const int co = 32 * mt + (lane & 31);
+        const int ci = kCh * chunk + 2 * ks + (lane >> 5);
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            float g[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    g[ky][kx] = dgrad ? w[((size_t)ci * Cout + co) * 9 + (8 - (ky * 3 + kx))]
+                                      : w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+            // row xi of G g, then column nu of (G g) G^T;  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+            const int xi = p >> 2, nu = p & 3;
+            float t[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float a = g[0][kx], b = g[1][kx], c = g[2][kx];
+                t[kx] = xi == 0 ? a : xi == 1 ? 0.5f * (a + b + c) : xi == 2 ? 0.5f * (a - b + c) : c;
+            }
+            v = nu == 0 ? t[0] : nu == 1 ? 0.5f * (t[0] + t[1] + t[2]) : nu == 2 ? 0.5f * (t[0] - t[1] + t[2]) : t[2];
+        }
+        U[i] = v;
+    }
+}
+
+template <int MT>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ U,
+                 const float* __restrict__ bias, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* V = lds;  // [2][16][kCh][kTiles]; the epilogue reuses the whole allocation as E[16][32][kTiles]
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id = blockIdx.x;
+    const int wx = id % g.wgX;
+    id /= g.wgX;
+    const int ty = id % g.tilesY;
+    const int n = id / g.tilesY;
+    const int tx0 = wx * kTiles;
+
+    // transform role: pair (channel ch of the chunk, tile tl); part 0 writes rows xi = 0, 1, part 1 rows 2, 3
+    const int tl = tid & 31, ch = (tid >> 5) & 7, part = tid >> 8;
+    const int tx = tx0 + tl;
+    const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
+    const bool tile_ok = tx < g.tilesX;
+    // all 4 columns of every tile of the workgroup inside the image?
+    const bool interior = (tx0 > 0) && (2 * (tx0 + kTiles - 1) + 2 < g.W);
+    const size_t plane = (size_t)g.H * g.W;
+    const float* xn = x + (size_t)n * g.Cin * plane;
+
+    float d[4][4];
+    auto load_patch = [&](int c) {
+        const float* xc = xn + (size_t)(c * kCh + ch) * plane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = iy0 + r;
+            const bool row_ok = iy >= 0 && iy < g.H;  // uniform over the workgroup
+            if (row_ok && interior) {
+                const f4u v = *reinterpret_cast<const f4u*>(xc + (size_t)iy * g.W + ix0);
+                d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ix = ix0 + j;
+                    d[r][j] = (row_ok && tile_ok && ix >= 0 && ix < g.W) ? xc[(size_t)iy * g.W + ix] : 0.f;
+                }
+            }
+        }
+    };
+    // B^T d B: rows t = B^T d (part 0: t0 = r0 - r2, t1 = r1 + r2; part 1: t2 = r2 - r1, t3 = r1 - r3),
+    // then (a, b, c, e) -> (a - c, b + c, c - b, b - e) along the row
+    auto store_v = [&](int buf) {
+        float* vb = V + buf * (16 * kCh * kTiles) + ch * kTiles + tl + (2 * part * 4) * (kCh * kTiles);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // both parts' rows are formed and one is picked: a select between d[][] elements
+                // themselves would be compiled into a dynamically indexed (scratch) array
+                const float lo = q == 0 ? d[0][j] - d[2][j] : d[1][j] + d[2][j];
+                const float hi = q == 0 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+                t[j] = part ? hi : lo;
+            }
+            float* o = vb + (q * 4) * (kCh * kTiles);
+            o[0 * kCh * kTiles] = t[0] - t[2];
+            o[1 * kCh * kTiles] = t[1] + t[2];
+            o[2 * kCh * kTiles] = t[2] - t[1];
+            o[3 * kCh * kTiles] = t[1] - t[3];
+        }
+    };
+
+    f32x16 acc[2][MT];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[pi][m][r] = 0.f;
+
+    const float* Uw = U + (size_t)(2 * wave) * MT * 256 + lane;  // + chunk * 16 * MT * 256
+    float uf[2][MT][4];
+    load_patch(0);
+    for (int c = 0; c < g.nchunks; ++c) {
+        const int buf = c & 1;
+        // U fragments of this chunk (consumed after the barrier), then the transform
+        const float* uc = Uw + (size_t)c * 16 * MT * 256;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) uf[pi][m][s] = uc[((pi * MT + m) * 4 + s) * 64];
+        store_v(buf);
+        if (c + 1 < g.nchunks) load_patch(c + 1);
+        __syncthreads();
+        const float* vb = V + buf * (16 * kCh * kTiles) + half * kTiles + l31;
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            const float* vp = vb + (2 * wave + pi) * (kCh * kTiles);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float b = vp[2 * s * kTiles];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    acc[pi][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[pi][m][s], b, acc[pi][m], 0, 0, 0);
+            }
+        }
+    }
+
+    // output transform: Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]
+    float* E = lds;  // [16][32][kTiles]
+    const int co_l = tid >> 5;          // 0..15 (+16 for the second pair)
+    const int oy = 2 * ty, ox = 2 * tx;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        __syncthreads();  // the previous round's reads / the last chunk's fragment reads are done
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi) {
+            float* e = E + (size_t)(2 * wave + pi) * (32 * kTiles) + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                e[row * kTiles] = acc[pi][m][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cl = co_l + 16 * j;
+            const int co = 32 * m + cl;
+            const float* e = E + cl * kTiles + tl;
+            float mm[4][4];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) mm[p >> 2][p & 3] = e[(size_t)p * (32 * kTiles)];
+            float s0[4], s1[4];  // rows of A^T M
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                s0[q] = mm[0][q] + mm[1][q] + mm[2][q];
+                s1[q] = mm[1][q] - mm[2][q] - mm[3][q];
+            }
+            const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+            const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+            const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+            if (co < g.Cout && tile_ok) {
+                float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
+                const bool two = ox + 1 < g.cols;
+                if (two) {
+                    f2u v0 = {y00, y01};
+                    *reinterpret_cast<f2u*>(yo) = v0;
+                    if (oy + 1 < g.rows) {
+                        f2u v1 = {y10, y11};
+                        *reinterpret_cast<f2u*>(yo + g.W) = v1;
+                    }
+                } else {
+                    yo[0] = y00;
+                    if (oy + 1 < g.rows) yo[g.W] = y10;
+                }
+            }
+        }
+    }
+}
+
+template <int MT>
+int launch_wino(const GW& g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
+    constexpr size_t lds = (size_t)16 * 32 * kTiles * sizeof(float);  // 64 KB (V double buffer uses half)
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd conv: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    const long blocks = (long)g.N * g.tilesY * g.wgX;
+    if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: grid too large");
+    hipLaunchKernelGGL((wino_conv_kernel<MT>), dim3((unsigned)blocks), dim3(kThreads), lds, s, g, x, U, bias, y);
+    return afd::check_launch("wino_conv_kernel");
+}
+
+}  // namespace
+
+namespace afd {
+
+bool wino_applicable(int Cin, int H, int W, int Cout) {
+    if (getenv("AFD_NO_WINOGRAD")) return false;
+    if (Cin % kCh != 0 || Cin < kCh || Cout > 128 || Cout < 1) return false;
+    if (W < 64 || H < 2) return false;
+    return (size_t)H * W < 0x7fffffffULL;
+}
+
+size_t wino_workspace_bytes(int Cin, int Cout) {
+    const size_t mt = (size_t)(Cout + 31) / 32;
+    return (size_t)(Cin / kCh) * 16 * mt * 4 * 64 * sizeof(float);
+}
+
+// same contract as conv3x3_run (conv3x3.hip)
+int wino_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+             int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (!ws || ws_bytes < wino_workspace_bytes(Cin, Cout))
+        return afd::fail(AFD_ERR_WORKSPACE, "winograd conv: workspace too small");
+    GW g{};
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.H = H; g.W = W;
+    g.rows = out_rows < H ? out_rows : H;
+    g.cols = out_cols < W ? out_cols : W;
+    g.tilesX = (g.cols + 1) / 2;
+    g.tilesY = (g.rows + 1) / 2;
+    g.wgX = (g.tilesX + kTiles - 1) / kTiles;
+    g.nchunks = Cin / kCh;
+    const int MT = (Cout + 31) / 32;
+    float* U = static_cast<float*>(ws);
+    const int total = g.nchunks * 16 * MT * 4 * 64;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, MT,
+                       g.nchunks, dgrad);
+    int rc = afd::check_launch("wino_weights_kernel");
+    if (rc) return rc;
+    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    switch (MT) {
+        case 1: return launch_wino<1>(g, x, U, bias, y, s);
+        case 2: return launch_wino<2>(g, x, U, bias, y, s);
+        case 3: return launch_wino<3>(g, x, U, bias, y, s);
+        case 4: return launch_wino<4>(g, x, U, bias, y, s);
+    }
+    return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: Cout %d > 128", Cout);
+}
+
+}  // namespace afd
