@@ -80,12 +80,17 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
-template <int MT>
+// MT = 32-channel tiles of Cout, NT = 32-tile column groups per workgroup (1: 32 tiles, two threads
+// share a patch transform; 2: 64 tiles, one thread per (channel, tile) patch -- every U fragment
+// then feeds two column tiles, halving the fragment traffic per MFMA)
+template <int MT, int NT>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ U,
                  const float* __restrict__ bias, float* __restrict__ y) {
+    constexpr int TILES = kTiles * NT;
+    constexpr int VBUF = 16 * kCh * TILES;  // floats per V buffer
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* V = lds;  // [2][16][kCh][kTiles]; the epilogue reuses the whole allocation as E[16][32][kTiles]
+    float* V = lds;  // [2][16][kCh][TILES]; the epilogue reuses the allocation as E[16][32][kTiles]
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -95,15 +100,18 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     id /= g.wgX;
     const int ty = id % g.tilesY;
     const int n = id / g.tilesY;
-    const int tx0 = wx * kTiles;
+    const int tx0 = wx * TILES;
 
-    // transform role: pair (channel ch of the chunk, tile tl); part 0 writes rows xi = 0, 1, part 1 rows 2, 3
-    const int tl = tid & 31, ch = (tid >> 5) & 7, part = tid >> 8;
+    // transform role: (channel ch of the chunk, tile tl); NT == 1: part 0 writes rows xi = 0, 1 and
+    // part 1 rows 2, 3 of the pair's V; NT == 2: the thread writes all four rows
+    const int tl = tid & (TILES - 1);
+    const int ch = (tid / TILES) & 7;
+    const int part = NT == 1 ? (tid >> 8) : 0;
     const int tx = tx0 + tl;
     const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
     const bool tile_ok = tx < g.tilesX;
     // all 4 columns of every tile of the workgroup inside the image?
-    const bool interior = (tx0 > 0) && (2 * (tx0 + kTiles - 1) + 2 < g.W);
+    const bool interior = (tx0 > 0) && (2 * (tx0 + TILES - 1) + 2 < g.W);
     const size_t plane = (size_t)g.H * g.W;
     const float* xn = x + (size_t)n * g.Cin * plane;
 
@@ -126,36 +134,42 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
             }
         }
     };
-    // B^T d B: rows t = B^T d (part 0: t0 = r0 - r2, t1 = r1 + r2; part 1: t2 = r2 - r1, t3 = r1 - r3),
-    // then (a, b, c, e) -> (a - c, b + c, c - b, b - e) along the row
+    // B^T d B: rows t = B^T d (t0 = r0 - r2, t1 = r1 + r2, t2 = r2 - r1, t3 = r1 - r3), then
+    // (a, b, c, e) -> (a - c, b + c, c - b, b - e) along the row
     auto store_v = [&](int buf) {
-        float* vb = V + buf * (16 * kCh * kTiles) + ch * kTiles + tl + (2 * part * 4) * (kCh * kTiles);
+        float* vb = V + buf * VBUF + ch * TILES + tl + (2 * part * 4) * (kCh * TILES);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < (NT == 1 ? 2 : 4); ++q) {
             float t[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // both parts' rows are formed and one is picked: a select between d[][] elements
-                // themselves would be compiled into a dynamically indexed (scratch) array
-                const float lo = q == 0 ? d[0][j] - d[2][j] : d[1][j] + d[2][j];
-                const float hi = q == 0 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
-                t[j] = part ? hi : lo;
+                if (NT == 1) {
+                    // both parts' rows are formed and one is picked: a select between d[][] elements
+                    // themselves would be compiled into a dynamically indexed (scratch) array
+                    const float lo = q == 0 ? d[0][j] - d[2][j] : d[1][j] + d[2][j];
+                    const float hi = q == 0 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+                    t[j] = part ? hi : lo;
+                } else {
+                    t[j] = q == 0 ? d[0][j] - d[2][j] : q == 1 ? d[1][j] + d[2][j] : q == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+                }
             }
-            float* o = vb + (q * 4) * (kCh * kTiles);
-            o[0 * kCh * kTiles] = t[0] - t[2];
-            o[1 * kCh * kTiles] = t[1] + t[2];
-            o[2 * kCh * kTiles] = t[2] - t[1];
-            o[3 * kCh * kTiles] = t[1] - t[3];
+            float* o = vb + (q * 4) * (kCh * TILES);
+            o[0 * kCh * TILES] = t[0] - t[2];
+            o[1 * kCh * TILES] = t[1] + t[2];
+            o[2 * kCh * TILES] = t[2] - t[1];
+            o[3 * kCh * TILES] = t[1] - t[3];
         }
     };
 
-    f32x16 acc[2][MT];
+    f32x16 acc[2][MT][NT];
 #pragma unroll
     for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[pi][m][r] = 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[pi][m][nt][r] = 0.f;
 
     const float* Uw = U + (size_t)(2 * wave) * MT * 256 + lane;  // + chunk * 16 * MT * 256
     float uf[2][MT][4];
@@ -173,86 +187,98 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
         store_v(buf);
         if (c + 1 < g.nchunks) load_patch(c + 1);
         __syncthreads();
-        const float* vb = V + buf * (16 * kCh * kTiles) + half * kTiles + l31;
+        const float* vb = V + buf * VBUF + half * TILES + l31;
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
-            const float* vp = vb + (2 * wave + pi) * (kCh * kTiles);
+            const float* vp = vb + (2 * wave + pi) * (kCh * TILES);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float b = vp[2 * s * kTiles];
+                float b[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b[nt] = vp[2 * s * TILES + nt * 32];
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    acc[pi][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[pi][m][s], b, acc[pi][m], 0, 0, 0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[pi][m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[pi][m][s], b[nt], acc[pi][m][nt], 0, 0, 0);
             }
         }
     }
 
-    // output transform: Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]
+    // output transform: Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; one (channel tile, column tile) per round
     float* E = lds;  // [16][32][kTiles]
-    const int co_l = tid >> 5;          // 0..15 (+16 for the second pair)
-    const int oy = 2 * ty, ox = 2 * tx;
+    const int tl_e = tid & 31;
+    const int co_l = tid >> 5;  // 0..15 (+16 for the second pair)
+    const int oy = 2 * ty;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        __syncthreads();  // the previous round's reads / the last chunk's fragment reads are done
 #pragma unroll
-        for (int pi = 0; pi < 2; ++pi) {
-            float* e = E + (size_t)(2 * wave + pi) * (32 * kTiles) + l31;
+        for (int nt = 0; nt < NT; ++nt) {
+            __syncthreads();  // the previous round's reads / the last chunk's fragment reads are done
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                e[row * kTiles] = acc[pi][m][r];
+            for (int pi = 0; pi < 2; ++pi) {
+                float* e = E + (size_t)(2 * wave + pi) * (32 * kTiles) + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    e[row * kTiles] = acc[pi][m][nt][r];
+                }
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            const int txe = tx0 + nt * 32 + tl_e;
+            const int ox = 2 * txe;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int cl = co_l + 16 * j;
-            const int co = 32 * m + cl;
-            const float* e = E + cl * kTiles + tl;
-            float mm[4][4];
+            for (int j = 0; j < 2; ++j) {
+                const int cl = co_l + 16 * j;
+                const int co = 32 * m + cl;
+                const float* e = E + cl * kTiles + tl_e;
+                float mm[4][4];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) mm[p >> 2][p & 3] = e[(size_t)p * (32 * kTiles)];
-            float s0[4], s1[4];  // rows of A^T M
+                for (int p = 0; p < 16; ++p) mm[p >> 2][p & 3] = e[(size_t)p * (32 * kTiles)];
+                float s0[4], s1[4];  // rows of A^T M
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                s0[q] = mm[0][q] + mm[1][q] + mm[2][q];
-                s1[q] = mm[1][q] - mm[2][q] - mm[3][q];
-            }
-            const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
-            const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
-            const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
-            if (co < g.Cout && tile_ok) {
-                float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
-                const bool two = ox + 1 < g.cols;
-                if (two) {
-                    f2u v0 = {y00, y01};
-                    *reinterpret_cast<f2u*>(yo) = v0;
-                    if (oy + 1 < g.rows) {
-                        f2u v1 = {y10, y11};
-                        *reinterpret_cast<f2u*>(yo + g.W) = v1;
+                for (int q = 0; q < 4; ++q) {
+                    s0[q] = mm[0][q] + mm[1][q] + mm[2][q];
+                    s1[q] = mm[1][q] - mm[2][q] - mm[3][q];
+                }
+                const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+                const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+                const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+                if (co < g.Cout && txe < g.tilesX) {
+                    float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
+                    const bool two = ox + 1 < g.cols;
+                    if (two) {
+                        f2u v0 = {y00, y01};
+                        *reinterpret_cast<f2u*>(yo) = v0;
+                        if (oy + 1 < g.rows) {
+                            f2u v1 = {y10, y11};
+                            *reinterpret_cast<f2u*>(yo + g.W) = v1;
+                        }
+                    } else {
+                        yo[0] = y00;
+                        if (oy + 1 < g.rows) yo[g.W] = y10;
                     }
-                } else {
-                    yo[0] = y00;
-                    if (oy + 1 < g.rows) yo[g.W] = y10;
                 }
             }
         }
     }
 }
 
-template <int MT>
-int launch_wino(const GW& g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
-    constexpr size_t lds = (size_t)16 * 32 * kTiles * sizeof(float);  // 64 KB (V double buffer uses half)
+template <int MT, int NT>
+int launch_wino(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
+    constexpr size_t lds = (size_t)16 * 32 * kTiles * sizeof(float) * (NT == 2 ? 1 : 1);  // 64 KB either way
+    static_assert(2 * 16 * kCh * kTiles * NT * sizeof(float) <= lds, "V double buffer fits the epilogue image");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd conv: %s", hipGetErrorString(e));
         attr = true;
     }
+    g.wgX = (g.tilesX + kTiles * NT - 1) / (kTiles * NT);
     const long blocks = (long)g.N * g.tilesY * g.wgX;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: grid too large");
-    hipLaunchKernelGGL((wino_conv_kernel<MT>), dim3((unsigned)blocks), dim3(kThreads), lds, s, g, x, U, bias, y);
+    hipLaunchKernelGGL((wino_conv_kernel<MT, NT>), dim3((unsigned)blocks), dim3(kThreads), lds, s, g, x, U, bias, y);
     return afd::check_launch("wino_conv_kernel");
 }
 
@@ -262,7 +288,8 @@ namespace afd {
 
 bool wino_applicable(int Cin, int H, int W, int Cout) {
     if (getenv("AFD_NO_WINOGRAD")) return false;
-    if (Cin % kCh != 0 || Cin < kCh || Cout > 128 || Cout < 1) return false;
+    // one 32-channel tile of Cout leaves 8 MFMAs per wave between barriers: the direct kernel wins
+    if (Cin % kCh != 0 || Cin < kCh || Cout > 128 || Cout <= 32) return false;
     if (W < 64 || H < 2) return false;
     return (size_t)H * W < 0x7fffffffULL;
 }
@@ -293,11 +320,12 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     int rc = afd::check_launch("wino_weights_kernel");
     if (rc) return rc;
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    const bool wide = !getenv("AFD_WINO_NT1");
     switch (MT) {
-        case 1: return launch_wino<1>(g, x, U, bias, y, s);
-        case 2: return launch_wino<2>(g, x, U, bias, y, s);
-        case 3: return launch_wino<3>(g, x, U, bias, y, s);
-        case 4: return launch_wino<4>(g, x, U, bias, y, s);
+        case 1: return wide ? launch_wino<1, 2>(g, x, U, bias, y, s) : launch_wino<1, 1>(g, x, U, bias, y, s);
+        case 2: return wide ? launch_wino<2, 2>(g, x, U, bias, y, s) : launch_wino<2, 1>(g, x, U, bias, y, s);
+        case 3: return wide ? launch_wino<3, 2>(g, x, U, bias, y, s) : launch_wino<3, 1>(g, x, U, bias, y, s);
+        case 4: return launch_wino<4, 1>(g, x, U, bias, y, s);
     }
     return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: Cout %d > 128", Cout);
 }
