@@ -128,7 +128,8 @@ def float_array(vals):
     return (c_f * len(vals))(*[float(v) for v in vals])
 
 
-KERNEL_CLASSES = {"wpt": 0, "conv_igemm": 1, "conv_wgrad": 2, "stft": 3, "conv_direct": 4}
+KERNEL_CLASSES = {"wpt": 0, "conv_igemm": 1, "conv_wgrad": 2, "stft": 3, "conv_direct": 4,
+                  "conv_winograd": 5}
 
 
 def timing_enable(on: bool) -> None:

@@ -319,7 +319,7 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
                        g.nchunks, dgrad);
     int rc = afd::check_launch("wino_weights_kernel");
     if (rc) return rc;
-    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     const bool wide = !getenv("AFD_WINO_NT1");
     switch (MT) {
         case 1: return wide ? launch_wino<1, 2>(g, x, U, bias, y, s) : launch_wino<1, 1>(g, x, U, bias, y, s);

@@ -232,7 +232,7 @@ def main() -> None:
     step()
     torch.cuda.synchronize()
     _native.timing_enable(False)
-    for name in ("wpt", "conv_igemm", "conv_wgrad", "stft", "conv_direct"):
+    for name in ("wpt", "conv_igemm", "conv_wgrad", "stft", "conv_direct", "conv_winograd"):
         ms, n, work = _native.timing_collect(name)
         if n:
             kernels[name] = {"launches": n, "total_ms": ms, "avg_ms": ms / n, "work": work}
@@ -252,6 +252,13 @@ def main() -> None:
             roofline = {"kernel": dom, "bound": "mfma", "achieved": ach,
                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None}
+            if dom == "conv_winograd":
+                # `achieved` counts the layer's direct-form flops (the algorithmic figure of the
+                # contract); the F(2x2,3x3) kernel issues 16 of every 36 of them on the matrix cores
+                roofline["mfma_issued"] = ach * 16.0 / 36.0
+                roofline["mfma_issued_frac"] = ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS
+                roofline["note"] = ("achieved = direct-form flops / time; Winograd F(2x2,3x3) issues 16/36 "
+                                    "of them as exact-fp32 MFMAs (mfma_issued*)")
         # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process):
         # read back from the committed counter summary when it covers this workload
         try:
@@ -260,6 +267,7 @@ def main() -> None:
             if pmc.get("workload") == a.workload and pmc.get("batch") == a.batch:
                 # the class's launches are spread over these kernels: launch-weighted mean
                 names = {"conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
+                         "conv_winograd": ("wino_conv_kernel",),
                          "conv_wgrad": ("wgrad3x3_kernel", "conv1x1_wgrad_kernel", "conv_wgrad2_kernel",
                                         "conv_wgrad_kernel"),
                          "wpt": ("wpt2_deep_kernel", "wpt2_top_kernel"), "stft": ("stft_mfma_kernel",)}[dom]

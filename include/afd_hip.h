@@ -44,6 +44,8 @@ int afd_version(void);
 #define AFD_K_CONV_WGRAD 2
 #define AFD_K_STFT 3
 #define AFD_K_CONV_DIRECT 4 /* small-channel direct convolutions (dilated stack at time_dim <= 4) */
+#define AFD_K_CONV_WINOGRAD 5 /* 3x3 forward / backward-data launches on the Winograd F(2x2,3x3) kernel:
+                                  work = direct-form flops, of which the kernel issues 16/36 as MFMAs */
 int afd_timing_enable(int on);
 int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work);
 int afd_timing_reset(void);

@@ -365,3 +365,52 @@ def test_batchnorm_folded_into_the_1x1_convolution(shape, cout, training):
         close(bn.running_mean, ref_bn.running_mean, 1e-6)
         close(bn.running_var, ref_bn.running_var, 1e-6)
         assert int(bn.num_batches_tracked) == 1
+
+
+WIDE3X3 = [(2, 32, 6, 1100, 64), (1, 96, 4, 1025, 128), (1, 64, 13, 1157, 96), (2, 64, 51, 129, 96)]
+
+
+@pytest.mark.parametrize("shape", WIDE3X3)
+@pytest.mark.parametrize("winograd", [True, False])
+def test_3x3_layers_on_both_kernels(shape, winograd, monkeypatch):
+    """The 3x3 / pad 1 layers with more than 32 output channels run on the Winograd F(2x2,3x3)
+    kernel (wino.hip); AFD_NO_WINOGRAD=1 keeps them on the direct implicit GEMM (conv3x3.hip).
+    Both against float64, forward and backward-data, and against each other: the transform adds
+    rounding (inputs and filters are combined before the products) but stays inside the same bar."""
+    if not winograd:
+        monkeypatch.setenv("AFD_NO_WINOGRAD", "1")
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, wt, b))
+    yr = F.conv2d(xr, wr, br, padding=1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg, wg, bg = (t.cuda().requires_grad_() for t in (x, wt, b))
+    yg = ops.conv2d(xg, wg, bg, 1, 1)
+    yg.backward(dy.cuda())
+    _close(yg, yr.detach(), 1e-5, "fwd")
+    _close(xg.grad, xr.grad, 1e-5, "dgrad")
+    _close(wg.grad, wr.grad, 3e-5, "wgrad")
+
+
+def test_winograd_class_is_what_runs():
+    """The timing classes tell the two 3x3 kernels apart (bench.py's roofline object relies on it)."""
+    from audiofakedetect import _native
+
+    x = torch.randn(1, 64, 6, 260, device="cuda")
+    wt = torch.randn(96, 64, 3, 3, device="cuda") / 24
+    _native.timing_reset()
+    _native.timing_enable(True)
+    try:
+        ops.conv2d(x, wt, None, 1, 1)
+        torch.cuda.synchronize()
+        _, n_w, work = _native.timing_collect("conv_winograd")
+        _, n_d, _ = _native.timing_collect("conv_igemm")
+    finally:
+        _native.timing_enable(False)
+        _native.timing_reset()
+    assert n_w == 1 and n_d == 0
+    assert work == 2.0 * 96 * 6 * 260 * 64 * 9
