@@ -39,6 +39,7 @@ struct GW {
     int rows, cols;      // output rows / columns that are wanted (crop for a following 2x2 pool)
     int tilesX, tilesY;  // 2x2 tiles covering rows x cols
     int wgX;             // workgroups per tile row
+    int wxCount;         // workgroup columns covered by this launch
     int nchunks;
 };
 
@@ -83,7 +84,10 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
 // MT = 32-channel tiles of Cout, NT = 32-tile column groups per workgroup (1: 32 tiles, two threads
 // share a patch transform; 2: 64 tiles, one thread per (channel, tile) patch -- every U fragment
 // then feeds two column tiles, halving the fragment traffic per MFMA)
-template <int MT, int NT>
+// BORDER: the launch covers the first and last workgroup column of every tile row (patches that
+// reach outside the image: element loads with clamped addresses); the other launch covers the
+// columns in between with one unaligned 16-byte load per patch row.  No divergent paths inside.
+template <int MT, int NT, bool BORDER>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ U,
                  const float* __restrict__ bias, float* __restrict__ y) {
@@ -96,8 +100,9 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int id = blockIdx.x;
-    const int wx = id % g.wgX;
-    id /= g.wgX;
+    const int wi = id % g.wxCount;
+    id /= g.wxCount;
+    const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
     const int ty = id % g.tilesY;
     const int n = id / g.tilesY;
     const int tx0 = wx * TILES;
@@ -110,30 +115,42 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     const int tx = tx0 + tl;
     const int iy0 = 2 * ty - 1, ix0 = 2 * tx - 1;
     const bool tile_ok = tx < g.tilesX;
-    // all 4 columns of every tile of the workgroup inside the image?
-    const bool interior = (tx0 > 0) && (2 * (tx0 + TILES - 1) + 2 < g.W);
     const size_t plane = (size_t)g.H * g.W;
     const float* xn = x + (size_t)n * g.Cin * plane;
 
+    // branch-free: elements outside the image are read from a clamped address and zeroed by a select
+    // when the patch is CONSUMED (store_v) -- a branch per row, or a select right after the load,
+    // makes the wave wait for the loads where they are issued instead of a chunk later
+    unsigned okmask = 0;  // bit 4 r + j: patch element (r, j) lies inside the image
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = iy0 + r, ix = ix0 + j;
+            const bool ok = iy >= 0 && iy < g.H && (!BORDER || (tile_ok && ix >= 0 && ix < g.W));
+            okmask |= ok ? (1u << (4 * r + j)) : 0u;
+        }
     float d[4][4];
     auto load_patch = [&](int c) {
         const float* xc = xn + (size_t)(c * kCh + ch) * plane;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int iy = iy0 + r;
-            const bool row_ok = iy >= 0 && iy < g.H;  // uniform over the workgroup
-            if (row_ok && interior) {
-                const f4u v = *reinterpret_cast<const f4u*>(xc + (size_t)iy * g.W + ix0);
+            const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+            const float* row = xc + (size_t)iyc * g.W;
+            if (!BORDER) {
+                const f4u v = *reinterpret_cast<const f4u*>(row + ix0);
                 d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int ix = ix0 + j;
-                    d[r][j] = (row_ok && tile_ok && ix >= 0 && ix < g.W) ? xc[(size_t)iy * g.W + ix] : 0.f;
+                    d[r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
                 }
             }
         }
     };
+    auto dv = [&](int r, int j) { return (okmask >> (4 * r + j)) & 1u ? d[r][j] : 0.f; };
     // B^T d B: rows t = B^T d (t0 = r0 - r2, t1 = r1 + r2, t2 = r2 - r1, t3 = r1 - r3), then
     // (a, b, c, e) -> (a - c, b + c, c - b, b - e) along the row
     auto store_v = [&](int buf) {
@@ -146,11 +163,11 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
                 if (NT == 1) {
                     // both parts' rows are formed and one is picked: a select between d[][] elements
                     // themselves would be compiled into a dynamically indexed (scratch) array
-                    const float lo = q == 0 ? d[0][j] - d[2][j] : d[1][j] + d[2][j];
-                    const float hi = q == 0 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+                    const float lo = q == 0 ? dv(0, j) - dv(2, j) : dv(1, j) + dv(2, j);
+                    const float hi = q == 0 ? dv(2, j) - dv(1, j) : dv(1, j) - dv(3, j);
                     t[j] = part ? hi : lo;
                 } else {
-                    t[j] = q == 0 ? d[0][j] - d[2][j] : q == 1 ? d[1][j] + d[2][j] : q == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j];
+                    t[j] = q == 0 ? dv(0, j) - dv(2, j) : q == 1 ? dv(1, j) + dv(2, j) : q == 2 ? dv(2, j) - dv(1, j) : dv(1, j) - dv(3, j);
                 }
             }
             float* o = vb + (q * 4) * (kCh * TILES);
@@ -173,10 +190,7 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
 
     const float* Uw = U + (size_t)(2 * wave) * MT * 256 + lane;  // + chunk * 16 * MT * 256
     float uf[2][MT][4];
-    load_patch(0);
-    for (int c = 0; c < g.nchunks; ++c) {
-        const int buf = c & 1;
-        // U fragments of this chunk (consumed after the barrier), then the transform
+    auto load_u = [&](int c) {
         const float* uc = Uw + (size_t)c * 16 * MT * 256;
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi)
@@ -184,9 +198,8 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) uf[pi][m][s] = uc[((pi * MT + m) * 4 + s) * 64];
-        store_v(buf);
-        if (c + 1 < g.nchunks) load_patch(c + 1);
-        __syncthreads();
+    };
+    auto mfma_phase = [&](int buf) {
         const float* vb = V + buf * VBUF + half * TILES + l31;
 #pragma unroll
         for (int pi = 0; pi < 2; ++pi) {
@@ -203,6 +216,35 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
                         acc[pi][m][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[pi][m][s], b[nt], acc[pi][m][nt], 0, 0, 0);
             }
         }
+    };
+    // The two waves of a SIMD run the phases of an iteration in opposite order, so one is in its
+    // matrix phase while the other transforms the next chunk (vector ALU + LDS writes):
+    //   waves 0-3: U(c) loads, transform(c+1), patch loads (c+2), MFMAs(c)
+    //   waves 4-7: MFMAs(c) on fragments loaded an iteration ago, U(c+1) loads, transform(c+1), ...
+    // Iteration c reads V[c & 1] (written before the previous barrier) and writes V[(c+1) & 1]
+    // (last read before the previous barrier): one barrier per chunk.
+    const bool early = wave < 4;
+    load_patch(0);
+    store_v(0);
+    if (g.nchunks > 1) load_patch(1);
+    if (!early) load_u(0);
+    __syncthreads();
+    for (int c = 0; c < g.nchunks; ++c) {
+        const bool more = c + 1 < g.nchunks;
+        if (early) {
+            load_u(c);
+            if (more) store_v((c + 1) & 1);
+            if (c + 2 < g.nchunks) load_patch(c + 2);
+        }
+        mfma_phase(c & 1);  // one copy of the matrix phase: the accumulators stay in place
+        if (!early) {
+            if (more) {
+                load_u(c + 1);
+                store_v((c + 1) & 1);
+            }
+            if (c + 2 < g.nchunks) load_patch(c + 2);
+        }
+        __syncthreads();
     }
 
     // output transform: Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; one (channel tile, column tile) per round
@@ -266,19 +308,32 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
 
 template <int MT, int NT>
 int launch_wino(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
-    constexpr size_t lds = (size_t)16 * 32 * kTiles * sizeof(float) * (NT == 2 ? 1 : 1);  // 64 KB either way
+    constexpr size_t lds = (size_t)16 * 32 * kTiles * sizeof(float);  // 64 KB: epilogue image / V double buffer
     static_assert(2 * 16 * kCh * kTiles * NT * sizeof(float) <= lds, "V double buffer fits the epilogue image");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd conv: %s", hipGetErrorString(e));
         attr = true;
     }
     g.wgX = (g.tilesX + kTiles * NT - 1) / (kTiles * NT);
-    const long blocks = (long)g.N * g.tilesY * g.wgX;
-    if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: grid too large");
-    hipLaunchKernelGGL((wino_conv_kernel<MT, NT>), dim3((unsigned)blocks), dim3(kThreads), lds, s, g, x, U, bias, y);
+    const long rows = (long)g.N * g.tilesY;
+    const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
+    const int edge = g.wgX >= 2 ? 2 : 1;
+    if (rows * (inner > edge ? inner : edge) > 0x7fffffffL)
+        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: grid too large");
+    if (inner > 0) {
+        g.wxCount = inner;
+        hipLaunchKernelGGL((wino_conv_kernel<MT, NT, false>), dim3((unsigned)(rows * inner)), dim3(kThreads), lds,
+                           s, g, x, U, bias, y);
+    }
+    g.wxCount = edge;
+    hipLaunchKernelGGL((wino_conv_kernel<MT, NT, true>), dim3((unsigned)(rows * edge)), dim3(kThreads), lds, s,
+                       g, x, U, bias, y);
     return afd::check_launch("wino_conv_kernel");
 }
 
