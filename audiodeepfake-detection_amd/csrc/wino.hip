@@ -248,7 +248,8 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     }
 
     // output transform: Y = A^T M A,  A^T = [1 1 1 0; 0 1 -1 -1]; one (channel tile, column tile) per round
-    float* E = lds;  // [16][32][kTiles]
+    // two images, used alternately: a round's writes need not wait for the previous round's reads
+    // (the main loop's last barrier covers the first round: every fragment read of V is done)
     const int tl_e = tid & 31;
     const int co_l = tid >> 5;  // 0..15 (+16 for the second pair)
     const int oy = 2 * ty;
@@ -256,7 +257,7 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            __syncthreads();  // the previous round's reads / the last chunk's fragment reads are done
+            float* E = lds + ((m * NT + nt) & 1) * (16 * 32 * kTiles);  // [16][32][kTiles]
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
                 float* e = E + (size_t)(2 * wave + pi) * (32 * kTiles) + l31;
@@ -308,7 +309,7 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
 
 template <int MT, int NT>
 int launch_wino(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
-    constexpr size_t lds = (size_t)16 * 32 * kTiles * sizeof(float);  // 64 KB: epilogue image / V double buffer
+    constexpr size_t lds = (size_t)2 * 16 * 32 * kTiles * sizeof(float);  // 128 KB: two epilogue images (V double buffer inside)
     static_assert(2 * 16 * kCh * kTiles * NT * sizeof(float) <= lds, "V double buffer fits the epilogue image");
     static bool attr = false;
     if (!attr) {
