@@ -237,6 +237,27 @@ def main() -> None:
         if n:
             kernels[name] = {"launches": n, "total_ms": ms, "avg_ms": ms / n, "work": work}
     _native.timing_reset()
+    # the same once more with the backward-weight kernels on the main stream: launch durations
+    # without another stream's kernels sharing the CUs (reported as roofline["serial"])
+    serial = {}
+    if not eval_only:
+        prev = os.environ.get("AFD_WGRAD_STREAM")
+        os.environ["AFD_WGRAD_STREAM"] = "0"
+        try:
+            _native.timing_enable(True)
+            step()
+            torch.cuda.synchronize()
+            _native.timing_enable(False)
+            for name in kernels:
+                ms, n, work = _native.timing_collect(name)
+                if n:
+                    serial[name] = {"launches": n, "total_ms": ms, "avg_ms": ms / n, "work": work}
+        finally:
+            _native.timing_reset()
+            if prev is None:
+                os.environ.pop("AFD_WGRAD_STREAM", None)
+            else:
+                os.environ["AFD_WGRAD_STREAM"] = prev
     step_ms = 1e3 * elapsed / a.steps
     roofline = None
     if kernels:
@@ -283,6 +304,13 @@ def main() -> None:
                                                   "+ WRITE_SIZE, launch-weighted over the class's kernels)")
         except (OSError, ValueError, KeyError):
             pass
+        if dom in serial:
+            ks = serial[dom]
+            div = 1e9 if dom in ("wpt", "stft") else 1e12
+            sa = ks["work"] / (ks["total_ms"] * 1e-3) / div
+            roofline["serial"] = {"achieved": sa, "frac": sa / roofline["peak"], "avg_launch_ms": ks["avg_ms"],
+                                  "note": "same step with the backward-weight stream off (AFD_WGRAD_STREAM=0): "
+                                          "no other stream's kernels on the CUs during these launches"}
         roofline["launches_per_step"] = k["launches"]
         roofline["avg_launch_ms"] = k["avg_ms"]
         roofline["share_of_step"] = k["total_ms"] / step_ms
@@ -311,7 +339,7 @@ def main() -> None:
                        "features": list(args.input_dim[1:]), "flattend_size": args.flattend_size,
                        "optimizer": "Adam lr 4e-4 wd 1e-3", "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend,
-            "kernels": kernels, "last_loss": loss,
+            "kernels": kernels, "kernels_serial": serial, "last_loss": loss,
         }
         print(json.dumps(line), flush=True)
     if ddp:
