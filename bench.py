@@ -149,8 +149,8 @@ def log(msg: str) -> None:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
     ap.add_argument("--cpu-frames", type=int, default=4, help="CPU baseline sample (0 = skip)")
