@@ -236,8 +236,12 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
             if (more) store_v((c + 1) & 1);
             if (c + 2 < g.nchunks) load_patch(c + 2);
         }
+        // the late wave's MFMAs go first: it still has its transform to do before the barrier,
+        // which then runs under the early wave's remaining MFMAs
+        if (!early) __builtin_amdgcn_s_setprio(2);
         mfma_phase(c & 1);  // one copy of the matrix phase: the accumulators stay in place
         if (!early) {
+            __builtin_amdgcn_s_setprio(0);
             if (more) {
                 load_u(c + 1);
                 store_v((c + 1) & 1);
