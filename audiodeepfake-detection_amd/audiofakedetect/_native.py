@@ -129,7 +129,7 @@ def float_array(vals):
 
 
 KERNEL_CLASSES = {"wpt": 0, "conv_igemm": 1, "conv_wgrad": 2, "stft": 3, "conv_direct": 4,
-                  "conv_winograd": 5}
+                  "conv_winograd": 5, "conv_wgrad_1x1": 6}
 
 
 def timing_enable(on: bool) -> None:

@@ -468,7 +468,7 @@ int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* d
     if (!ws || ws_bytes < conv1x1_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "conv1x1 wgrad: workspace too small");
     float* partial = static_cast<float*>(ws);
-    afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)HW * Cin, s);
+    afd::ScopedTiming timing(AFD_K_CONV_WGRAD_1X1, 2.0 * N * Cout * (double)HW * Cin, s);
     const int cot = (Cout + 31) / 32, cit = (Cin + 31) / 32;
     const int key = (cot == 3 ? 0 : cot) * 10 + (cit == 3 ? 0 : cit);
     switch (key) {

@@ -232,7 +232,7 @@ def main() -> None:
     step()
     torch.cuda.synchronize()
     _native.timing_enable(False)
-    for name in ("wpt", "conv_igemm", "conv_wgrad", "stft", "conv_direct", "conv_winograd"):
+    for name in ("wpt", "conv_igemm", "conv_wgrad", "stft", "conv_direct", "conv_winograd", "conv_wgrad_1x1"):
         ms, n, work = _native.timing_collect(name)
         if n:
             kernels[name] = {"launches": n, "total_ms": ms, "avg_ms": ms / n, "work": work}
@@ -292,8 +292,8 @@ def main() -> None:
                 # the class's launches are spread over these kernels: launch-weighted mean
                 names = {"conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
                          "conv_winograd": ("wino_conv_kernel",),
-                         "conv_wgrad": ("wgrad3x3_kernel", "conv1x1_wgrad_kernel", "conv_wgrad2_kernel",
-                                        "conv_wgrad_kernel"),
+                         "conv_wgrad": ("wgrad3x3_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
+                         "conv_wgrad_1x1": ("conv1x1_wgrad_kernel",),
                          "wpt": ("wpt2_deep_kernel", "wpt2_top_kernel"), "stft": ("stft_mfma_kernel",)}[dom]
                 tot = cnt = 0.0
                 for nm in names:

@@ -44,6 +44,7 @@ int afd_version(void);
 #define AFD_K_CONV_WGRAD 2
 #define AFD_K_STFT 3
 #define AFD_K_CONV_DIRECT 4 /* small-channel direct convolutions (dilated stack at time_dim <= 4) */
+#define AFD_K_CONV_WGRAD_1X1 6 /* backward-weight of the 1x1 layers (a plain GEMM over pixels, HBM-leaning) */
 #define AFD_K_CONV_WINOGRAD 5 /* 3x3 forward / backward-data launches on the Winograd F(2x2,3x3) kernel:
                                   work = direct-form flops, of which the kernel issues 16/36 as MFMAs */
 int afd_timing_enable(int on);
