@@ -78,6 +78,12 @@ size_t wino_workspace_bytes(int Cin, int Cout);
 int wino_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
              int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s);
 
+// wino16.hip: the same with 16x16x4 tiles and a register-only output transform
+bool wino16_applicable(int Cin, int H, int W, int Cout);
+size_t wino16_workspace_bytes(int Cin, int Cout);
+int wino16_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+               int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s);
+
 bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int dz_cols, int* S,
                        int* nchunks, int* CI_T, int* CO_PAD, int* NCOL);

@@ -620,7 +620,8 @@ bool conv3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil
 size_t conv3x3_workspace_bytes(int Cin, int Cout) {
     const size_t co_pad = (size_t)(Cout + 31) / 32 * 32;
     const size_t direct = (size_t)(Cin / kCT) * kKsteps * 2 * co_pad * sizeof(float);
-    const size_t wino = wino_workspace_bytes(Cin, Cout);
+    size_t wino = wino_workspace_bytes(Cin, Cout);
+    if (wino16_workspace_bytes(Cin, Cout) > wino) wino = wino16_workspace_bytes(Cin, Cout);
     return direct > wino ? direct : wino;
 }
 
@@ -632,6 +633,8 @@ int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int
                 hipStream_t s) {
     if (!ws || ws_bytes < conv3x3_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "conv3x3: workspace too small");
+    if (wino16_applicable(Cin, H, W, Cout))
+        return wino16_run(x, w, bias, y, N, Cin, H, W, Cout, dgrad, out_rows, out_cols, ws, ws_bytes, s);
     if (wino_applicable(Cin, H, W, Cout))
         return wino_run(x, w, bias, y, N, Cin, H, W, Cout, dgrad, out_rows, out_cols, ws, ws_bytes, s);
     G3 g{};
