@@ -805,7 +805,22 @@ int make_plan2(W2Params& p) {
     }
     auto pad = [](long n) { return n + (n >> 5) + 2; };
     if (pad(p.N) > kTopLdsFloats) return 1;
-    p.K1 = p.level >= 3 ? 2 : p.level - 1;
+    // K1 = levels walked as a single path before the breadth-first part (2^K1 workgroups per frame).
+    // K1 = 1: each workgroup owns a level-1 subtree -- 25 % fewer filter instructions than K1 = 2 (the
+    // path levels compute both filters and keep one) and one round of workgroups at B = 128:
+    // coif4 l14 front end 231 -> 182 us, sym5 l14 145 -> 106 us.  K1 = 2 remains the fallback when the
+    // breadth-first levels of a level-1 subtree do not fit the LDS carve.
+    p.K1 = p.level >= 3 ? 1 : p.level - 1;
+    if (getenv("AFD_WPT_K1") && p.level >= 3) p.K1 = atoi(getenv("AFD_WPT_K1")) == 2 ? 2 : 1;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool fits = true;
+        auto szk = [&](int k) { return (long)(1L << (k - p.K1)) * pad(p.n[k]); };
+        const int ks = p.level < kKsMax ? p.level : kKsMax;
+        for (int k = p.K1 + 1; k < ks; ++k) fits = fits && szk(k - 1) + szk(k) <= kTopLdsFloats;
+        if (ks > p.K1 + 1) fits = fits && szk(ks - 1) <= kTopLdsFloats;
+        if (fits || p.K1 == 2 || p.level < 3) break;
+        p.K1 = 2;
+    }
     for (int k = 1; k <= p.K1; ++k)
         if (pad(p.n[k - 1]) + pad(p.n[k]) > kTopLdsFloats) return 1;
     p.Ks = p.level < kKsMax ? p.level : kKsMax;
