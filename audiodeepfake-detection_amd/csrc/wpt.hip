@@ -331,6 +331,7 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
                        unsigned flags, float power, float eps, float mean, float std, float* out,
                        hipStream_t stream);
 size_t wpt2_workspace_bytes(int B, int N, int L, int level);
+bool wpt2_preferred(int L, int level);
 int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
                  int level, unsigned flags, float power, float eps, float mean, float std, float* out,
                  void* ws, size_t ws_bytes, hipStream_t stream);
@@ -361,11 +362,12 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
                                                 out, static_cast<hipStream_t>(stream));
         if (rch != 1) return rch;
     }
-    // Deep transforms (level >= 11) run on the second-generation kernels (wpt2.hip: register
-    // window + packed FMAs, dense compile-time deep levels): measured 389 vs 627 us on coif4
-    // level 14, B = 128; up to level 10 the single-launch kernel below is faster (94 vs 117 us
-    // at level 8).  AFD_WPT_V1 / AFD_WPT_V2 force one or the other (development).
-    if ((level >= 11 || getenv("AFD_WPT_V2")) && !getenv("AFD_WPT_V1")) {
+    // Which generation: wpt2.hip (register window + packed FMAs, level-1 subtree per workgroup, MFMA
+    // deep levels) for every level >= 11 and, up to level 10, for the long and the 2-tap filters
+    // (coif4 level 8: 64 vs 92 us, haar level 8 at B = 4096: 0.88 vs 1.23 ms); the single-launch
+    // kernel below stays for 4..10 taps up to level 10 (sym5 level 8: 47 vs 50 us).
+    // AFD_WPT_V1 / AFD_WPT_V2 force one or the other (development).
+    if (afd::wpt2_preferred(L, level)) {
         // 1 = geometry left to the kernel below
         const int rc2 = afd::wpt2_forward(x, B, N, dec_lo, dec_hi, L, level, flags, power, eps, mean,
                                           std, out, ws, ws_bytes, static_cast<hipStream_t>(stream));

@@ -913,8 +913,14 @@ int launch2(const W2Params& p, hipStream_t stream) {
 
 namespace afd {
 
+bool wpt2_preferred(int L, int level) {
+    if (getenv("AFD_WPT_V1")) return false;
+    if (getenv("AFD_WPT_V2")) return true;
+    return level >= 11 || L >= 12 || L == 2;
+}
+
 size_t wpt2_workspace_bytes(int B, int N, int L, int level) {
-    if (level < 11 && !getenv("AFD_WPT_V2")) return 0;
+    if (!wpt2_preferred(L, level)) return 0;
     W2Params p{};
     p.B = B; p.N = N; p.L = L; p.level = level;
     if (make_plan2(p) != 0 || level <= p.Ks) return 0;
