@@ -150,7 +150,7 @@ def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=128, help="frames per GPU")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
     ap.add_argument("--cpu-frames", type=int, default=4, help="CPU baseline sample (0 = skip)")
@@ -291,7 +291,7 @@ def main() -> None:
             if pmc.get("workload") == a.workload and pmc.get("batch") == a.batch:
                 # the class's launches are spread over these kernels: launch-weighted mean
                 names = {"conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
-                         "conv_winograd": ("wino_conv_kernel",),
+                         "conv_winograd": ("wino_conv_kernel", "wino16_conv_kernel"),
                          "conv_wgrad": ("wgrad3x3_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
                          "conv_wgrad_1x1": ("conv1x1_wgrad_kernel",),
                          "wpt": ("wpt2_deep_kernel", "wpt2_top_kernel"), "stft": ("stft_mfma_kernel",)}[dom]

@@ -6,7 +6,7 @@ whose staging loads are dwordx4; other widths are uncalibrated and recorded raw.
 """
 import collections, csv, glob, json, os, re, sys
 
-WIDE = ("wino_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "conv1x1_kernel", "wpt_haar14_kernel", "conv_wgrad2_kernel",
+WIDE = ("wino_conv_kernel", "wino16_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "conv1x1_kernel", "wpt_haar14_kernel", "conv_wgrad2_kernel",
         "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel", "bn_bwd_apply_kernel",
         "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
 out = {"note": __doc__.strip(), "workload": "coif4-l14", "batch": 128, "kernels": {}}
