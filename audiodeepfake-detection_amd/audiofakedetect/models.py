@@ -81,14 +81,20 @@ class DCNN(nn.Module):
                 elif bn_i is not None:
                     h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
                 continue
+            fused_pool = False
             if pending_bn is not None:
                 # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
                 z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)
                 pending_bn = None
+            elif pooled and ops.conv3x3_prelu_maxpool_applicable(h, conv):
+                # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue: the conv output is never written
+                h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope)
+                fused_pool = True
             else:
                 z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled)
             if pooled:
-                h = ops.prelu_maxpool2x2(z, slope)
+                if not fused_pool:
+                    h = ops.prelu_maxpool2x2(z, slope)
                 if fold_next:
                     pending_bn = cnn[bn_i]
                 elif bn_i is not None:

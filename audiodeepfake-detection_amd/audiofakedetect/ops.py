@@ -184,54 +184,62 @@ class _Conv2d(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _lib()
         x, w = ctx.saved_tensors
-        n, cin, h, wd, cout, k, pad, dil = ctx.geom
-        dy = _f32c(dy)
-        nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
-        ws = _ws(nbytes, x.device)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _native.check(lib.afd_conv2d_backward_data(
-                _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
-                _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            b = ctx.bias_ref
-            # only for parameters whose .grad is a FusedAdam arena view (flagged by the optimizer):
-            # there the gradient is wanted in .grad, as loss.backward() leaves it; a caller of
-            # torch.autograd.grad(.., weights) on such a model must set AFD_WGRAD_STREAM=0
-            side = (_side_enabled() and x.is_cuda and w.grad is not None
-                    and getattr(w, "_afd_arena", False)
-                    and (not ctx.has_bias or (b is not None and b.grad is not None
-                                              and getattr(b, "_afd_arena", False))))
-            if side:
-                main = torch.cuda.current_stream(x.device)
-                st = _side_stream(x.device)
-                st.wait_stream(main)  # dy (and the zeroed arena) are ready
-                with torch.cuda.stream(st):
-                    dwt = torch.empty_like(w)
-                    dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                    ws2 = _ws(nbytes, x.device, "side")
-                    _native.check(lib.afd_conv2d_backward_weight_cropped(
-                        _native.ptr(x), _native.ptr(dy), _native.ptr(dwt), _native.ptr(dbt), n, cin, h,
-                        wd, cout, k, pad, dil, ctx.crop[0], ctx.crop[1], _native.ptr(ws2), ws2.numel(),
-                        _native.stream_ptr()), "afd_conv2d_backward_weight")
-                    with torch.no_grad():
-                        w.grad.add_(dwt)
-                        if dbt is not None:
-                            b.grad.add_(dbt)
-                x.record_stream(st)
-                dy.record_stream(st)
-                _queue_join(x.device)
-            else:
-                dw = torch.empty_like(w)
-                db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-                _native.check(lib.afd_conv2d_backward_weight_cropped(
-                    _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
-                    cout, k, pad, dil, ctx.crop[0], ctx.crop[1], _native.ptr(ws), ws.numel(),
-                    _native.stream_ptr()), "afd_conv2d_backward_weight")
+        dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dy,
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None
+
+
+def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db):
+    """Backward-data on the current stream; backward-weight on the second stream, added straight into
+    the FusedAdam gradient arena, when the parameters live there (see `_Conv2d`)."""
+    lib = _lib()
+    n, cin, h, wd, cout, k, pad, dil = geom
+    dy = _f32c(dy)
+    nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
+    ws = _ws(nbytes, x.device)
+    dx = dw = db = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        _native.check(lib.afd_conv2d_backward_data(
+            _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
+            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
+    if need_dw or need_db:
+        # only for parameters whose .grad is a FusedAdam arena view (flagged by the optimizer):
+        # there the gradient is wanted in .grad, as loss.backward() leaves it; a caller of
+        # torch.autograd.grad(.., weights) on such a model must set AFD_WGRAD_STREAM=0
+        side = (_side_enabled() and x.is_cuda and w.grad is not None
+                and getattr(w, "_afd_arena", False)
+                and (not has_bias or (b is not None and b.grad is not None
+                                      and getattr(b, "_afd_arena", False))))
+        if side:
+            main = torch.cuda.current_stream(x.device)
+            st = _side_stream(x.device)
+            st.wait_stream(main)  # dy (and the zeroed arena) are ready
+            with torch.cuda.stream(st):
+                dwt = torch.empty_like(w)
+                dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+                ws2 = _ws(nbytes, x.device, "side")
+                _native.check(lib.afd_conv2d_backward_weight_cropped(
+                    _native.ptr(x), _native.ptr(dy), _native.ptr(dwt), _native.ptr(dbt), n, cin, h,
+                    wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws2), ws2.numel(),
+                    _native.stream_ptr()), "afd_conv2d_backward_weight")
+                with torch.no_grad():
+                    w.grad.add_(dwt)
+                    if dbt is not None:
+                        b.grad.add_(dbt)
+            x.record_stream(st)
+            dy.record_stream(st)
+            _queue_join(x.device)
+        else:
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+            _native.check(lib.afd_conv2d_backward_weight_cropped(
+                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
+                cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
+                _native.stream_ptr()), "afd_conv2d_backward_weight")
+    return dx, dw, db
 
 
 def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1, pooled: bool = False):
@@ -320,6 +328,66 @@ def conv1_prelu_maxpool(x, w, b, slope, padding: int):
 def prelu_maxpool2x2(z, slope: Optional[torch.Tensor]):
     """MaxPool2d(2,2)(PReLU(z)); slope=None -> plain max pool."""
     return _PReLUPool.apply(z, slope)
+
+
+class _Conv3x3PReLUPool(torch.autograd.Function):
+    """Conv2d(k=3, padding=1) + PReLU + MaxPool2d(2, 2) in one launch (DCNN blocks 3 and 6): on the
+    Winograd kernel the 2x2 output tile is the pooling window, so the convolution output is never
+    written.  Backward: pool/PReLU backward from (u, code), then the convolution's backward."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, slope):
+        lib = _lib()
+        x = _f32c(x)
+        w = _f32c(w)
+        n, cin, h, wd = x.shape
+        cout = w.shape[0]
+        u = torch.empty((n, cout, h // 2, wd // 2), dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, cout, h // 2, wd // 2), dtype=torch.uint8, device=x.device)
+        nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1)
+        ws = _ws(nbytes, x.device)
+        _native.check(lib.afd_conv3x3_prelu_pool_forward(
+            _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
+            _native.ptr(idx), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+            "afd_conv3x3_prelu_pool_forward")
+        ctx.save_for_backward(x, w, u, idx, slope)
+        ctx.geom = (n, cin, h, wd, cout, 3, 1, 1)
+        ctx.crop = (2 * (h // 2), 2 * (wd // 2))
+        ctx.has_bias = b is not None
+        ctx.bias_ref = b
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        lib = _lib()
+        x, w, u, idx, slope = ctx.saved_tensors
+        n, cin, h, wd, cout = ctx.geom[:5]
+        du = _f32c(du)
+        dz = torch.empty((n, cout, h, wd), dtype=torch.float32, device=u.device)
+        dslope = torch.zeros(1, dtype=torch.float32, device=u.device)
+        _native.check(lib.afd_prelu_pool_backward(
+            _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(dz),
+            _native.ptr(dslope), n * cout, h, wd, _native.stream_ptr()), "afd_prelu_pool_backward")
+        dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dz,
+                                      ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                      ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dw, db, dslope
+
+
+def conv3x3_prelu_maxpool_applicable(x, conv: torch.nn.Module) -> bool:
+    import os
+    if os.environ.get("AFD_NO_CONV_POOL_FUSE") or not x.is_cuda:
+        return False
+    if (conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.dilation != (1, 1)
+            or conv.stride != (1, 1)):
+        return False
+    n, cin, h, w = x.shape
+    return bool(_lib().afd_conv3x3_prelu_pool_applicable(cin, h, w, conv.out_channels))
+
+
+def conv3x3_prelu_maxpool(x, w, b, slope):
+    """MaxPool2d(2, 2)(PReLU(conv2d(x, w, b, padding=1))) without materialising the convolution output."""
+    return _Conv3x3PReLUPool.apply(x, w, b, slope)
 
 
 # --------------------------------------------------------------------------------------

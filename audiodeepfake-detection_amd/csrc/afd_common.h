@@ -76,7 +76,8 @@ int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int
 bool wino_applicable(int Cin, int H, int W, int Cout);
 size_t wino_workspace_bytes(int Cin, int Cout);
 int wino_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
-             int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s);
+             int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
+             const float* slope = nullptr, float* u = nullptr, unsigned char* idx = nullptr);
 
 // wino16.hip: the same with 16x16x4 tiles and a register-only output transform
 bool wino16_applicable(int Cin, int H, int W, int Cout);

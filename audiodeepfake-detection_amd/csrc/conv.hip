@@ -1357,6 +1357,25 @@ extern "C" int afd_conv2d_forward_cropped(const float* x, const float* w, const 
     return launch_igemm(g, x, wp, bias, y, s);
 }
 
+// 3x3 / pad 1 convolution + PReLU + MaxPool2d(2, 2) in one launch: the Winograd output tile is the
+// pooling window.  Returns AFD_ERR_UNSUPPORTED when the layer is not one the Winograd kernel of
+// wino.hip takes (the caller then runs convolution and pool separately).
+extern "C" int afd_conv3x3_prelu_pool_applicable(int Cin, int H, int W, int Cout) {
+    return afd::wino_applicable(Cin, H, W, Cout) && !afd::wino16_applicable(Cin, H, W, Cout) && H >= 2 && W >= 2 ? 1 : 0;
+}
+
+extern "C" int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, const float* bias,
+                                              const float* slope, float* u, uint8_t* idx, int N, int Cin,
+                                              int H, int W, int Cout, void* ws, size_t ws_bytes,
+                                              afd_stream_t stream) {
+    if (!x || !w || !slope || !u || !idx) return afd::fail(AFD_ERR_ARG, "conv3x3+pool: null pointer");
+    if (N < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return afd::fail(AFD_ERR_ARG, "conv3x3+pool: bad shape");
+    if (!afd_conv3x3_prelu_pool_applicable(Cin, H, W, Cout))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3+pool: layer not on the Winograd kernel");
+    return afd::wino_run(x, w, bias, nullptr, N, Cin, H, W, Cout, 0, 2 * (H / 2), 2 * (W / 2), ws, ws_bytes,
+                         static_cast<hipStream_t>(stream), slope, u, idx);
+}
+
 extern "C" int afd_conv1x1_bn_backward_data(const float* dz, const float* wf, const float* u,
                                             const float* alpha, const float* beta, float* du, int N,
                                             int Cin, int Cout, long HW, afd_stream_t stream) {

@@ -40,6 +40,11 @@ struct GW {
     int tilesX, tilesY;  // 2x2 tiles covering rows x cols
     int wgX;             // workgroups per tile row
     int wxCount;         // workgroup columns covered by this launch
+    // pooled epilogue (afd_conv3x3_prelu_pool_forward): PReLU + MaxPool2d(2, 2) of the tile, which IS
+    // the pooling window; u / idx [N][Cout][H/2][W/2] are written instead of y
+    const float* slope;
+    float* u;
+    unsigned char* idx;
     int nchunks;
 };
 
@@ -87,7 +92,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
 // BORDER: the launch covers the first and last workgroup column of every tile row (patches that
 // reach outside the image: element loads with clamped addresses); the other launch covers the
 // columns in between with one unaligned 16-byte load per patch row.  No divergent paths inside.
-template <int MT, int NT, bool BORDER>
+template <int MT, int NT, bool BORDER, bool POOL>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ U,
                  const float* __restrict__ bias, float* __restrict__ y) {
@@ -291,7 +296,24 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
                 const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
                 const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
                 const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
-                if (co < g.Cout && txe < g.tilesX) {
+                if (POOL) {
+                    // same order and tie rule as prelu_pool_fwd_kernel (nn.hip): first maximum wins
+                    if (co < g.Cout && txe < g.tilesX) {
+                        const float a = g.slope[0];
+                        auto act = [a](float z) { return z > 0.f ? z : a * z; };
+                        float best = act(y00), zb = y00;
+                        int bi = 0;
+                        float v = act(y01);
+                        if (v > best) { best = v; bi = 1; zb = y01; }
+                        v = act(y10);
+                        if (v > best) { best = v; bi = 2; zb = y10; }
+                        v = act(y11);
+                        if (v > best) { best = v; bi = 3; zb = y11; }
+                        const size_t o = (((size_t)n * g.Cout + co) * g.tilesY + ty) * g.tilesX + txe;
+                        g.u[o] = best;
+                        g.idx[o] = (unsigned char)(bi | (zb <= 0.f ? 4 : 0));
+                    }
+                } else if (co < g.Cout && txe < g.tilesX) {
                     float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
                     const bool two = ox + 1 < g.cols;
                     if (two) {
@@ -311,16 +333,16 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     }
 }
 
-template <int MT, int NT>
-int launch_wino(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
+template <int MT, int NT, bool POOL>
+int launch_wino_t(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 16 * 32 * kTiles * sizeof(float);  // 128 KB: two epilogue images (V double buffer inside)
     static_assert(2 * 16 * kCh * kTiles * NT * sizeof(float) <= lds, "V double buffer fits the epilogue image");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, false>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, false, POOL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, true>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, true, POOL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd conv: %s", hipGetErrorString(e));
         attr = true;
@@ -333,13 +355,18 @@ int launch_wino(GW g, const float* x, const float* U, const float* bias, float* 
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: grid too large");
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino_conv_kernel<MT, NT, false>), dim3((unsigned)(rows * inner)), dim3(kThreads), lds,
+        hipLaunchKernelGGL((wino_conv_kernel<MT, NT, false, POOL>), dim3((unsigned)(rows * inner)), dim3(kThreads), lds,
                            s, g, x, U, bias, y);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino_conv_kernel<MT, NT, true>), dim3((unsigned)(rows * edge)), dim3(kThreads), lds, s,
+    hipLaunchKernelGGL((wino_conv_kernel<MT, NT, true, POOL>), dim3((unsigned)(rows * edge)), dim3(kThreads), lds, s,
                        g, x, U, bias, y);
     return afd::check_launch("wino_conv_kernel");
+}
+
+template <int MT, int NT>
+int launch_wino(const GW& g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
+    return g.u ? launch_wino_t<MT, NT, true>(g, x, U, bias, y, s) : launch_wino_t<MT, NT, false>(g, x, U, bias, y, s);
 }
 
 }  // namespace
@@ -361,7 +388,8 @@ size_t wino_workspace_bytes(int Cin, int Cout) {
 
 // same contract as conv3x3_run (conv3x3.hip)
 int wino_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
-             int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s) {
+             int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
+             const float* slope, float* u, unsigned char* idx) {
     if (!ws || ws_bytes < wino_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd conv: workspace too small");
     GW g{};
@@ -372,6 +400,9 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     g.tilesY = (g.rows + 1) / 2;
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     g.nchunks = Cin / kCh;
+    g.slope = slope; g.u = u; g.idx = idx;
+    if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx))
+        return afd::fail(AFD_ERR_ARG, "winograd conv + pool: bad arguments");
     const int MT = (Cout + 31) / 32;
     float* U = static_cast<float*>(ws);
     const int total = g.nchunks * 16 * MT * 4 * 64;

@@ -115,6 +115,18 @@ int afd_conv2d_backward_data(const float* dy, const float* w, float* dx, int N, 
                              int W, int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
                              afd_stream_t stream);
 
+/* Conv2d(k=3, padding=1) -> PReLU -> MaxPool2d(2, 2) in one launch (reference models.py:263-265 and
+ * :276-278, DCNN blocks 3 and 6): on the Winograd F(2x2,3x3) kernel the 2x2 output tile of a lane is
+ * the pooling window, so the pooled value u and the 3-bit code of afd_prelu_pool_forward (argmax |
+ * "winner <= 0") are written instead of the 4x larger convolution output, which never exists.
+ * u, idx [N][Cout][H/2][W/2].  afd_conv3x3_prelu_pool_applicable: 1 if the layer geometry is one the
+ * kernel takes (otherwise run afd_conv2d_forward_cropped + afd_prelu_pool_forward).  Backward is
+ * afd_prelu_pool_backward followed by the convolution's backward entry points. */
+int afd_conv3x3_prelu_pool_applicable(int Cin, int H, int W, int Cout);
+int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, const float* bias /* may be NULL */,
+                                   const float* slope, float* u, uint8_t* idx, int N, int Cin, int H, int W,
+                                   int Cout, void* ws, size_t ws_bytes, afd_stream_t stream);
+
 /* BatchNorm2d(affine=False) -> Conv2d(k=1, pad 0) pair (reference models.py:260-262, DCNN blocks 1-2).
  * Forward needs no kernel of its own: the normalisation is a per-input-channel scale and shift, so the
  * caller folds it into the weights (wf[co][ci] = w[co][ci] * invstd[ci], bf = b - wf . mean) and runs

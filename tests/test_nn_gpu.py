@@ -414,3 +414,32 @@ def test_winograd_class_is_what_runs():
         _native.timing_reset()
     assert n_w == 1 and n_d == 0
     assert work == 2.0 * 96 * 6 * 260 * 64 * 9
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 7, 1027, 96), (2, 32, 6, 1100, 64), (2, 64, 13, 257, 96)])
+def test_conv_prelu_pool_in_one_launch(shape):
+    """conv3x3_prelu_maxpool (the pool folded into the Winograd epilogue, reference models.py:263-265)
+    against conv -> PReLU -> MaxPool2d(2, 2) in float64, and bit-for-bit against the two-launch path."""
+    n, cin, h, w, cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    slope = torch.tensor([0.25])
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1)
+    assert ops.conv3x3_prelu_maxpool_applicable(x.cuda(), conv)
+    xr, wr, br, sr = (t.double().requires_grad_() for t in (x, wt, b, slope))
+    yr = F.max_pool2d(F.prelu(F.conv2d(xr, wr, br, padding=1), sr), 2, 2)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(dy.double())
+    xg, wg, bg, sg = (t.cuda().requires_grad_() for t in (x, wt, b, slope))
+    yg = ops.conv3x3_prelu_maxpool(xg, wg, bg, sg)
+    _close(yg, yr.detach(), 2e-5, "fused fwd")
+    yg.backward(dy.cuda())
+    _close(xg.grad, xr.grad, 2e-5, "dgrad")
+    _close(wg.grad, wr.grad, 3e-5, "wgrad")
+    _close(bg.grad, br.grad, 2e-5, "dbias")
+    _close(sg.grad, sr.grad, 1e-4, "dslope")
+    with torch.no_grad():
+        two = ops.prelu_maxpool2x2(ops.conv2d(xg, wg, bg, 1, 1, pooled=True), sg)
+    assert torch.equal(two, yg.detach())
