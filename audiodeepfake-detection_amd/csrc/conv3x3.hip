@@ -316,6 +316,8 @@ struct GW {
     int Hc, Wc;              // dz is zero outside [:Hc, :Wc]: tiles cover that extent only
     int tilesX, tilesY, S, nchunks;
     int ntiles;
+    // tile-column subset of this launch: tx = ncl ? cl[k] : col0 + k, k < ncols; slabs start at split0
+    int ncols, col0, ncl, cl[4], split0;
 };
 
 template <int MT, int CT, int TPW, int TW>
@@ -383,13 +385,14 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-    const int tpi = g.tilesX * g.tilesY;
+    const int tpi = g.ncols * g.tilesY;
     for (int tile = split; tile < g.ntiles; tile += g.S) {
         const int n = tile / tpi;
         const int t = tile - n * tpi;
-        const int ty = t / g.tilesX;
+        const int ty = t / g.ncols;
         const int oy = ty * TH;
-        const int ox0 = (t - ty * g.tilesX) * TW;
+        const int kx_ = t - ty * g.ncols;
+        const int ox0 = (g.ncl ? g.cl[kx_] : g.col0 + kx_) * TW;
         const int iy0 = oy - 1, ix0 = ox0 - 1;
         const float* dzn = dz + (size_t)n * g.Cout * plane + (size_t)oy * g.W + ox0;
         const float* xc = x + ((size_t)n * g.Cin + (size_t)chunk * CT) * plane;
@@ -499,7 +502,7 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
         }
     }
 
-    float* slab = part + ((size_t)split * g.nchunks + chunk) * CO_PAD * NCOL;
+    float* slab = part + ((size_t)(g.split0 + split) * g.nchunks + chunk) * CO_PAD * NCOL;
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int p = wave * TPW + q;
@@ -515,8 +518,204 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
     if (chunk == 0 && tid < CO_PAD) {
         float v = 0.f;
         for (int j = 0; j < 16; ++j) v += bsl[tid * 16 + j];  // fixed order
-        partb[(size_t)split * CO_PAD + tid] = v;
+        partb[(size_t)(g.split0 + split) * CO_PAD + tid] = v;
     }
+}
+
+// Second layout of the same GEMM for the interior tile columns of wide images (one row of 64 pixels per
+// tile): 8 waves with the (channel tile, column tile) pairs dealt round-robin (<= 5 per wave instead of
+// 7-9: no spills, 96 % balance per SIMD), and the NEXT tile's global loads issued before the k-loop
+// into registers (the single workgroup per CU covers its own load latency).  The load path has no
+// branch -- a join makes the compiler wait for the loads where they are issued: rows above / below
+// the image are read from the clamped row and zeroed when stored to LDS, and the first / last tile
+// columns (patches that cross the left / right edge) go to wgrad3x3_kernel as a second launch.
+template <int MT>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MT <= 2 ? 4 : 2, MT <= 2 ? 4 : 2)))
+wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dz,
+                 float* __restrict__ part, float* __restrict__ partb) {
+    constexpr int CT = 32, TW = 64, NTH = 512, NW = 8;
+    constexpr int CO_PAD = MT * 32;
+    constexpr int kPR = 3;
+    constexpr int kWPC = TW + 4;
+    constexpr int NTILES = CT * 9 / 32;  // 9
+    constexpr int PAIRS = MT * NTILES;
+    constexpr int TPW = (PAIRS + NW - 1) / NW;
+    constexpr int NCOL = NTILES * 32;
+    constexpr int DZF = CO_PAD * kWPitch;
+    constexpr int PF = CT * kPR * kWPC;
+    constexpr int G4 = kWPC / 4;                       // 17 groups of 4 per patch row
+    constexpr int DV = CO_PAD * 16 / NTH;              // = MT
+    constexpr int PGROUPS = CT * kPR * G4;             // 1632
+    constexpr int PV = (PGROUPS + NTH - 1) / NTH;      // 4
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // dz | patch | bias cells
+    float* patch = smem + DZF;
+    float* bsl = smem + DZF + PF;  // [CO_PAD][16]
+
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int chunk = blockIdx.y, split = blockIdx.x;
+    const size_t plane = (size_t)g.H * g.W;
+
+    for (int i = tid; i < CO_PAD * 16; i += NTH) bsl[i] = 0.f;
+
+    unsigned dzo[DV], xo[PV];
+    int xpr[PV];
+#pragma unroll
+    for (int u = 0; u < DV; ++u) {
+        const int item = tid + u * NTH;
+        const int co = item >> 4, px = (item & 15) << 2;
+        dzo[u] = co < g.Cout ? (unsigned)co * (unsigned)(g.H * g.W) + (unsigned)px : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < PV; ++u) {
+        const int item = tid + u * NTH;
+        const bool live = item < PGROUPS;
+        const int row = live ? item / G4 : 0, g4 = live ? item - row * G4 : 0;
+        const int ci_l = row / kPR, pr = row - ci_l * kPR;
+        xo[u] = (unsigned)ci_l * (unsigned)(g.H * g.W) + (unsigned)(4 * g4);
+        xpr[u] = pr;
+    }
+    const float* ap[TPW];
+    const float* bp[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int p = wave + NW * q;  // round-robin
+        const int pp = p < PAIRS ? p : 0;
+        const int m = pp / NTILES, nt = pp - m * NTILES;
+        const int c = nt * 32 + l31;
+        const int ci_l = c / 9, r = c - ci_l * 9, ky = r / 3, kx = r - ky * 3;
+        ap[q] = smem + (m * 32 + l31) * kWPitch + half;
+        bp[q] = patch + (ci_l * kPR + ky) * kWPC + kx + half;
+    }
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int q = 0; q < TPW; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    const int tpi = g.ncols * g.tilesY;
+    f32x4u dv[DV], pv[PV];
+    unsigned rowbad = 0;
+    auto load_tile = [&](int tile) {
+        const int n = tile / tpi;
+        const int t = tile - n * tpi;
+        const int ty = t / g.ncols;
+        const int ox0 = (g.col0 + (t - ty * g.ncols)) * TW;
+        const float* dzn = dz + (size_t)n * g.Cout * plane + (size_t)ty * g.W + ox0;
+        const float* xb = x + ((size_t)n * g.Cin + (size_t)chunk * CT) * plane + (ox0 - 1);
+        rowbad = 0;
+#pragma unroll
+        for (int u = 0; u < DV; ++u) dv[u] = *reinterpret_cast<const f32x4u*>(dzn + dzo[u]);
+#pragma unroll
+        for (int u = 0; u < PV; ++u) {
+            const int iy = ty - 1 + xpr[u];
+            const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+            rowbad |= (iy != iyc) ? (1u << u) : 0u;
+            pv[u] = *reinterpret_cast<const f32x4u*>(xb + xo[u] + (unsigned)(iyc * g.W));
+        }
+    };
+
+    int tile = split;
+    if (tile < g.ntiles) load_tile(tile);
+    for (; tile < g.ntiles; tile += g.S) {
+        __syncthreads();  // the previous tile's fragments have been read (first pass: bias cells are zero)
+#pragma unroll
+        for (int u = 0; u < DV; ++u) {
+            const int item = tid + u * NTH;
+            const int co = item >> 4, px = (item & 15) << 2;
+            float* d = smem + co * kWPitch + px;
+            const bool live = co < g.Cout;  // padded channel rows stay zero
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = live ? dv[u][j] : 0.f;
+            if (chunk == 0 && live) bsl[item] += (dv[u][0] + dv[u][1]) + (dv[u][2] + dv[u][3]);
+        }
+#pragma unroll
+        for (int u = 0; u < PV; ++u) {
+            const int item = tid + u * NTH;
+            const bool z = (rowbad >> u) & 1u;
+            if (item < PGROUPS)
+                *reinterpret_cast<float4*>(patch + 4 * item) =
+                    make_float4(z ? 0.f : pv[u][0], z ? 0.f : pv[u][1], z ? 0.f : pv[u][2], z ? 0.f : pv[u][3]);
+        }
+        __syncthreads();
+        if (tile + g.S < g.ntiles) load_tile(tile + g.S);  // in flight during the k-loop
+
+        float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
+#pragma unroll
+        for (int q = 0; q < TPW; ++q) {
+            a0[q] = ap[q][0];
+            b0[q] = bp[q][0];
+        }
+#pragma unroll
+        for (int ks = 0; ks < kWPix / 2; ks += 2) {
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                a1[q] = ap[q][2 * ks + 2];
+                b1[q] = bp[q][2 * ks + 2];
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[q], b0[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 2 < kWPix / 2) {
+#pragma unroll
+                for (int q = 0; q < TPW; ++q) {
+                    a0[q] = ap[q][2 * ks + 4];
+                    b0[q] = bp[q][2 * ks + 4];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < TPW; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[q], b1[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < TPW; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    float* slab = part + ((size_t)(g.split0 + split) * g.nchunks + chunk) * CO_PAD * NCOL;
+#pragma unroll
+    for (int q = 0; q < TPW; ++q) {
+        const int p = wave + NW * q;
+        if (p >= PAIRS) continue;
+        const int m = p / NTILES, nt = p - m * NTILES;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[(size_t)co * NCOL + nt * 32 + l31] = acc[q][r];
+        }
+    }
+    __syncthreads();  // the last tile's bias cells are written
+    if (chunk == 0 && tid < CO_PAD) {
+        float v = 0.f;
+        for (int j = 0; j < 16; ++j) v += bsl[tid * 16 + j];  // fixed order
+        partb[(size_t)(g.split0 + split) * CO_PAD + tid] = v;
+    }
+}
+
+template <int MT>
+int launchw_p(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
+    constexpr size_t lds = (size_t)(MT * 32 * kWPitch + 32 * 3 * 68 + MT * 32 * 16) * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3p_kernel<MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad3x3: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad3x3p_kernel<MT>), dim3(g.S, g.nchunks), dim3(512), lds, s, g, x, dz, part, partb);
+    return afd::check_launch("wgrad3x3p_kernel");
 }
 
 template <int MT, int CT, int TPW, int TW>
@@ -558,6 +757,62 @@ bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int di
     return (size_t)128 * H * W < 0x7fffffffULL;
 }
 
+// Tile columns of a wide image (64-pixel tiles): columns 1 .. last are interior (their patch and dz
+// loads stay inside the image rows), column 0 and the ones after `last` cross an edge.
+struct WgCols {
+    bool split;   // two launches: wgrad3x3p_kernel on the interior columns, wgrad3x3_kernel on the rest
+    int tilesX, ninner, nborder, border[4];
+};
+
+// mt = 32-channel tiles of Cout.  Measured at B = 32 (new vs general kernel): mt 4 1.70 vs 1.80 ms (the
+// general kernel spills 116 registers there), mt 3 3.73 vs 3.46, mt 2 0.34 vs 0.31, mt 1 0.87 vs 0.72 ms --
+// two workgroups of four waves cover each other's loads better than one of eight covers its own, so
+// only the 128-channel layer takes the split; AFD_WGRAD3X3P=1 forces it for every layer (A/B runs).
+WgCols wgrad_cols(int W, int wc, int mt) {
+    WgCols c{};
+    c.tilesX = (wc + 63) / 64;
+    if (W < 1024 || getenv("AFD_NO_WGRAD3X3P") || (mt != 4 && !getenv("AFD_WGRAD3X3P"))) return c;
+    int last = 0;
+    for (int tx = 1; tx < c.tilesX; ++tx)
+        if (tx * 64 + 64 + 3 <= W) last = tx;
+    c.ninner = last;
+    c.border[c.nborder++] = 0;
+    for (int tx = last + 1; tx < c.tilesX && c.nborder < 4; ++tx) c.border[c.nborder++] = tx;
+    c.split = c.ninner >= 8 && 1 + (c.tilesX - 1 - last) == c.nborder;
+    return c;
+}
+
+long coprime_splits(long s, long tx) {
+    // A split count that shares a factor with the tiles per row makes every workgroup walk down
+    // one tile column in lock step (measured 80 instead of 109 TF/s at 512 splits x 128 tiles per
+    // row): take the next smaller count coprime to it.
+    auto gcd = [](long a, long b) { while (b) { const long t = a % b; a = b; b = t; } return a; };
+    while (s > 1 && gcd(s, tx) != 1) --s;
+    return s;
+}
+
+// split counts of the two launches (S2 = 0: single launch of wgrad3x3_kernel over all columns)
+void wgrad_splits(int N, int tilesY, int nchunks, const WgCols& c, int* S1, int* S2) {
+    if (!c.split) {
+        const long tiles = (long)N * tilesY * c.tilesX;
+        long s = 1024 / nchunks;
+        if (s < 1) s = 1;
+        if (s > tiles) s = tiles;
+        *S1 = (int)coprime_splits(s, c.tilesX);
+        *S2 = 0;
+        return;
+    }
+    const long ti = (long)N * tilesY * c.ninner, tb = (long)N * tilesY * c.nborder;
+    long s = 1024 / nchunks;
+    if (s < 1) s = 1;
+    if (s > ti) s = ti;
+    *S1 = (int)coprime_splits(s, c.ninner);
+    long sb = 128 / nchunks;
+    if (sb < 1) sb = 1;
+    if (sb > tb) sb = tb;
+    *S2 = (int)sb;
+}
+
 // slab geometry for conv.hip's reduction: S splits x nchunks slabs of [CO_PAD][NCOL]
 void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int dz_cols, int* S,
                        int* nchunks, int* CI_T, int* CO_PAD, int* NCOL) {
@@ -569,17 +824,15 @@ void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int 
     *NCOL = ct * 9;
     const int hc = dz_rows < H ? dz_rows : H, wc = dz_cols < W ? dz_cols : W;
     const int tw = wgrad_tw(W), th = kWPix / tw;
-    const long tiles = (long)N * ((hc + th - 1) / th) * ((wc + tw - 1) / tw);
-    long s = 1024 / *nchunks;
-    if (s < 1) s = 1;
-    if (s > tiles) s = tiles;
-    // A split count that shares a factor with the tiles per row makes every workgroup walk down
-    // one tile column in lock step (measured 80 instead of 109 TF/s at 512 splits x 128 tiles per
-    // row): take the next smaller count coprime to it.
-    const long tx = (wc + tw - 1) / tw;
-    auto gcd = [](long a, long b) { while (b) { const long t = a % b; a = b; b = t; } return a; };
-    while (s > 1 && gcd(s, tx) != 1) --s;
-    *S = (int)s;
+    const int tilesY = (hc + th - 1) / th;
+    WgCols c = wgrad_cols(W, wc, mt);
+    if (tw != 64) {
+        c = WgCols{};
+        c.tilesX = (wc + tw - 1) / tw;
+    }
+    int s1, s2;
+    wgrad_splits(N, tilesY, *nchunks, c, &s1, &s2);
+    *S = s1 + s2;
 }
 
 int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, int N, int Cin, int H,
@@ -591,17 +844,43 @@ int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, 
     const int tw = wgrad_tw(W), th = kWPix / tw;
     g.tilesX = (g.Wc + tw - 1) / tw;
     g.tilesY = (g.Hc + th - 1) / th;
-    int ct, co_pad, ncol;
-    wgrad3x3_geometry(N, Cin, H, W, Cout, dz_rows, dz_cols, &g.S, &g.nchunks, &ct, &co_pad, &ncol);
+    int ct, co_pad, ncol, s_total;
+    wgrad3x3_geometry(N, Cin, H, W, Cout, dz_rows, dz_cols, &s_total, &g.nchunks, &ct, &co_pad, &ncol);
+    WgCols c = wgrad_cols(W, g.Wc, co_pad / 32);
+    if (tw != 64) {
+        c = WgCols{};
+        c.tilesX = g.tilesX;
+    }
+    int s1, s2;
+    wgrad_splits(N, g.tilesY, g.nchunks, c, &s1, &s2);
     const long tiles = (long)N * g.tilesY * g.tilesX;
     if (tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad3x3: too many tiles");
-    g.ntiles = (int)tiles;
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.Hc * g.Wc * Cin * 9, s);
     const int mt = co_pad / 32;
-    if (mt == 1) return launchw<1, 32, 3>(g, x, dz, part, partb, s);              //  9 pairs
-    if (mt == 2) return launchw<2, 32, 5>(g, x, dz, part, partb, s);              // 18 pairs
-    if (mt == 3) return launchw<3, 32, 7>(g, x, dz, part, partb, s);              // 27 pairs
-    return launchw<4, 32, 9>(g, x, dz, part, partb, s);                           // 36 pairs
+    auto run_all = [&](const GW& gg) {
+        if (mt == 1) return launchw<1, 32, 3>(gg, x, dz, part, partb, s);          //  9 pairs
+        if (mt == 2) return launchw<2, 32, 5>(gg, x, dz, part, partb, s);          // 18 pairs
+        if (mt == 3) return launchw<3, 32, 7>(gg, x, dz, part, partb, s);          // 27 pairs
+        return launchw<4, 32, 9>(gg, x, dz, part, partb, s);                       // 36 pairs
+    };
+    if (!c.split) {
+        g.S = s1; g.ncols = g.tilesX; g.col0 = 0; g.ncl = 0; g.split0 = 0;
+        g.ntiles = (int)tiles;
+        return run_all(g);
+    }
+    // interior columns: prefetching kernel; edge columns: the general kernel
+    g.S = s1; g.ncols = c.ninner; g.col0 = 1; g.ncl = 0; g.split0 = 0;
+    g.ntiles = N * g.tilesY * c.ninner;
+    int rc;
+    if (mt == 1) rc = launchw_p<1>(g, x, dz, part, partb, s);
+    else if (mt == 2) rc = launchw_p<2>(g, x, dz, part, partb, s);
+    else if (mt == 3) rc = launchw_p<3>(g, x, dz, part, partb, s);
+    else rc = launchw_p<4>(g, x, dz, part, partb, s);
+    if (rc) return rc;
+    g.S = s2; g.ncols = c.nborder; g.col0 = 0; g.ncl = c.nborder; g.split0 = s1;
+    for (int i = 0; i < c.nborder; ++i) g.cl[i] = c.border[i];
+    g.ntiles = N * g.tilesY * c.nborder;
+    return run_all(g);
 }
 
 }  // namespace afd
