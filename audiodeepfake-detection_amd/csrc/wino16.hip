@@ -91,7 +91,11 @@ wino16_conv_kernel(const GV g, const float* __restrict__ x, const float* __restr
     const int n = id / g.tilesY;
     const int tx0 = wx * kTiles;
 
-    // transform role: threads 0..255 own (channel ch, tile tl) of every chunk
+    // transform role: thread owns (channel ch [+ CHS], tile tl) of every chunk: with >= 4 waves the first
+    // 256 threads take one patch each, the 2-wave workgroup (Cout <= 32) two patches per thread
+    constexpr int PPT = NT >= kCh * kTiles ? 1 : 2;   // patches per thread
+    constexpr int CHS = NT >= kCh * kTiles ? 0 : 4;   // channel step between a thread's patches
+    static_assert(PPT == 1 || NT == 128, "two patches per thread: exactly two waves");
     const bool xf = tid < kCh * kTiles;
     const int tl = tid & 31, ch = (tid >> 5) & 7;
     const int txp = tx0 + tl;
@@ -108,40 +112,46 @@ wino16_conv_kernel(const GV g, const float* __restrict__ x, const float* __restr
             const bool ok = iy >= 0 && iy < g.H && (!BORDER || (tile_ok && ix >= 0 && ix < g.W));
             okmask |= ok ? (1u << (4 * r + j)) : 0u;
         }
-    float d[4][4];
+    float d[PPT][4][4];
     auto load_patch = [&](int c) {
-        const float* xc = xn + (size_t)(c * kCh + ch) * plane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int iy = iy0 + r;
-            const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
-            const float* row = xc + (size_t)iyc * g.W;
-            if (!BORDER) {
-                const f4u v = *reinterpret_cast<const f4u*>(row + ix0);
-                d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w;
-            } else {
+        for (int q = 0; q < PPT; ++q) {
+            const float* xc = xn + (size_t)(c * kCh + ch + q * CHS) * plane;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ix = ix0 + j;
-                    d[r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+            for (int r = 0; r < 4; ++r) {
+                const int iy = iy0 + r;
+                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+                const float* row = xc + (size_t)iyc * g.W;
+                if (!BORDER) {
+                    const f4u v = *reinterpret_cast<const f4u*>(row + ix0);
+                    d[q][r][0] = v.x; d[q][r][1] = v.y; d[q][r][2] = v.z; d[q][r][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int ix = ix0 + j;
+                        d[q][r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+                    }
                 }
             }
         }
     };
-    auto dv = [&](int r, int j) { return (okmask >> (4 * r + j)) & 1u ? d[r][j] : 0.f; };
     auto store_v = [&](int buf) {
-        float* vb = V + buf * VBUF + ch * kTiles + tl;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float t[4];
+        for (int p2 = 0; p2 < PPT; ++p2) {
+            auto dv = [&](int r, int j) { return (okmask >> (4 * r + j)) & 1u ? d[p2][r][j] : 0.f; };
+            float* vb = V + buf * VBUF + (ch + p2 * CHS) * kTiles + tl;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                t[j] = q == 0 ? dv(0, j) - dv(2, j) : q == 1 ? dv(1, j) + dv(2, j) : q == 2 ? dv(2, j) - dv(1, j) : dv(1, j) - dv(3, j);
-            float* o = vb + (q * 4) * (kCh * kTiles);
-            o[0 * kCh * kTiles] = t[0] - t[2];
-            o[1 * kCh * kTiles] = t[1] + t[2];
-            o[2 * kCh * kTiles] = t[2] - t[1];
-            o[3 * kCh * kTiles] = t[1] - t[3];
+            for (int q = 0; q < 4; ++q) {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    t[j] = q == 0 ? dv(0, j) - dv(2, j) : q == 1 ? dv(1, j) + dv(2, j) : q == 2 ? dv(2, j) - dv(1, j) : dv(1, j) - dv(3, j);
+                float* o = vb + (q * 4) * (kCh * kTiles);
+                o[0 * kCh * kTiles] = t[0] - t[2];
+                o[1 * kCh * kTiles] = t[1] + t[2];
+                o[2 * kCh * kTiles] = t[2] - t[1];
+                o[3 * kCh * kTiles] = t[1] - t[3];
+            }
         }
     };
 
@@ -269,8 +279,11 @@ bool wino16_applicable(int Cin, int H, int W, int Cout) {
     // measured against wino.hip: ahead with 8 waves (Cout 113..128: block 4 forward 1.06 -> 0.96 ms,
     // block 5 backward-data 0.43 -> 0.38 ms at B = 32), level or behind with 4, and 6 waves do not
     // fit three to a SIMD without spilling; AFD_WINO16=1 takes every Cout >= 49 (A/B runs)
-    if (Cin % kCh != 0 || Cin < kCh || Cout > 128 || Cout < 49) return false;
-    if (Cout <= 112 && !getenv("AFD_WINO16")) return false;
+    if (Cin % kCh != 0 || Cin < kCh || Cout > 128 || Cout < 17) return false;
+    if (Cout > 32 && Cout < 49) return false;  // three waves: no transform mapping built
+    // 2 waves (Cout 17..32: block 5 forward, block 6 backward-data, the layers wino.hip leaves to the
+    // direct kernel) and 8 waves take this kernel; the sizes in between stay on wino.hip
+    if (Cout > 32 && Cout <= 112 && !getenv("AFD_WINO16")) return false;
     if (W < 64 || H < 2) return false;
     return (size_t)H * W < 0x7fffffffULL;
 }
@@ -300,6 +313,7 @@ int wino16_run(const float* x, const float* w, const float* bias, float* y, int 
     if (rc) return rc;
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     switch (CG) {
+        case 2: return launch16<2, 2>(g, x, U, bias, y, s);
         case 4: return launch16<4, 2>(g, x, U, bias, y, s);
         case 5: return launch16<5, 2>(g, x, U, bias, y, s);
         case 6: return launch16<6, 2>(g, x, U, bias, y, s);
