@@ -549,7 +549,7 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
     constexpr int PV = (PGROUPS + NTH - 1) / NTH;      // 4
     extern __shared__ __attribute__((aligned(16))) float smem[];  // dz | patch | bias cells
     float* patch = smem + DZF;
-    float* bsl = smem + DZF + PF;  // [CO_PAD][16]
+    float* bsl = smem + 2 * (DZF + PF);  // [CO_PAD][16], after the two tile images
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
@@ -618,15 +618,15 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
         }
     };
 
-    int tile = split;
-    if (tile < g.ntiles) load_tile(tile);
-    for (; tile < g.ntiles; tile += g.S) {
-        __syncthreads();  // the previous tile's fragments have been read (first pass: bias cells are zero)
+    // LDS image of a tile: dz | patch, two of them used alternately; bias cells after both
+    constexpr int IMG = DZF + PF;
+    auto store_tile = [&](int buf) {
+        float* base = smem + buf * IMG;
 #pragma unroll
         for (int u = 0; u < DV; ++u) {
             const int item = tid + u * NTH;
             const int co = item >> 4, px = (item & 15) << 2;
-            float* d = smem + co * kWPitch + px;
+            float* d = base + co * kWPitch + px;
             const bool live = co < g.Cout;  // padded channel rows stay zero
 #pragma unroll
             for (int j = 0; j < 4; ++j) d[j] = live ? dv[u][j] : 0.f;
@@ -637,24 +637,24 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
             const int item = tid + u * NTH;
             const bool z = (rowbad >> u) & 1u;
             if (item < PGROUPS)
-                *reinterpret_cast<float4*>(patch + 4 * item) =
+                *reinterpret_cast<float4*>(base + DZF + 4 * item) =
                     make_float4(z ? 0.f : pv[u][0], z ? 0.f : pv[u][1], z ? 0.f : pv[u][2], z ? 0.f : pv[u][3]);
         }
-        __syncthreads();
-        if (tile + g.S < g.ntiles) load_tile(tile + g.S);  // in flight during the k-loop
-
+    };
+    auto k_loop = [&](int buf) {
+        const int bo = buf * IMG;
         float a0[TPW], a1[TPW], b0[TPW], b1[TPW];
 #pragma unroll
         for (int q = 0; q < TPW; ++q) {
-            a0[q] = ap[q][0];
-            b0[q] = bp[q][0];
+            a0[q] = ap[q][bo];
+            b0[q] = bp[q][bo];
         }
 #pragma unroll
         for (int ks = 0; ks < kWPix / 2; ks += 2) {
 #pragma unroll
             for (int q = 0; q < TPW; ++q) {
-                a1[q] = ap[q][2 * ks + 2];
-                b1[q] = bp[q][2 * ks + 2];
+                a1[q] = ap[q][bo + 2 * ks + 2];
+                b1[q] = bp[q][bo + 2 * ks + 2];
             }
 #pragma unroll
             for (int q = 0; q < TPW; ++q)
@@ -668,8 +668,8 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
             if (ks + 2 < kWPix / 2) {
 #pragma unroll
                 for (int q = 0; q < TPW; ++q) {
-                    a0[q] = ap[q][2 * ks + 4];
-                    b0[q] = bp[q][2 * ks + 4];
+                    a0[q] = ap[q][bo + 2 * ks + 4];
+                    b0[q] = bp[q][bo + 2 * ks + 4];
                 }
             }
 #pragma unroll
@@ -682,6 +682,33 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    // Iteration i works on tile t_i out of image i & 1 while tile t_{i+1} (in registers since the
+    // previous iteration) is stored into the other image and t_{i+2} is requested: one barrier per
+    // tile.  Waves 0-3 store first and then run their k-loop, waves 4-7 the other way round, so on
+    // every SIMD one wave is in its matrix phase while the other one stores.
+    const bool early = wave < 4;
+    __syncthreads();  // bias cells are zero
+    int tile = split;
+    if (tile < g.ntiles) {
+        load_tile(tile);
+        store_tile(0);
+        if (tile + g.S < g.ntiles) load_tile(tile + g.S);
+    }
+    __syncthreads();
+    for (int it = 0; tile < g.ntiles; tile += g.S, ++it) {
+        const bool more = tile + g.S < g.ntiles;
+        if (early && more) {
+            store_tile((it + 1) & 1);
+            if (tile + 2 * g.S < g.ntiles) load_tile(tile + 2 * g.S);
+        }
+        k_loop(it & 1);
+        if (!early && more) {
+            store_tile((it + 1) & 1);
+            if (tile + 2 * g.S < g.ntiles) load_tile(tile + 2 * g.S);
+        }
+        __syncthreads();
     }
 
     float* slab = part + ((size_t)(g.split0 + split) * g.nchunks + chunk) * CO_PAD * NCOL;
@@ -706,7 +733,7 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
 
 template <int MT>
 int launchw_p(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
-    constexpr size_t lds = (size_t)(MT * 32 * kWPitch + 32 * 3 * 68 + MT * 32 * 16) * 4;
+    constexpr size_t lds = (size_t)(2 * (MT * 32 * kWPitch + 32 * 3 * 68) + MT * 32 * 16) * 4;  // two tile images
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3p_kernel<MT>),
