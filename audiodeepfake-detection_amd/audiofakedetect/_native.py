@@ -37,7 +37,7 @@ _SIGNATURES = {
     "afd_wpt_out_len": (c_i, [c_i, c_i, c_i]),
     "afd_wpt_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "afd_wpt_forward": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i,
-                              c_u, c_f, c_f, c_f, c_f, c_p, c_p, c_sz, c_p]),
+                              c_u, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "afd_stft_dims": (c_i, [c_i, c_i, c_i] + [ctypes.POINTER(c_i)] * 4),
     "afd_stft_basis": (c_i, [c_i, c_p]),
     "afd_stft_forward": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_u, c_f, c_f, c_f, c_f, c_p, c_p]),
@@ -56,7 +56,7 @@ _SIGNATURES = {
     "afd_moments_accumulate": (c_i, [c_p, c_sz, c_p, c_p]),
     "afd_normalize_forward": (c_i, [c_p, c_p, c_sz, c_f, c_f, c_p]),
     "afd_packet_stats": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
-    "afd_packet_block_norm": (c_i, [c_p, c_i, c_i, c_i, c_p, c_u, c_f, c_f, c_f, c_f, c_p, c_p]),
+    "afd_packet_block_norm": (c_i, [c_p, c_i, c_i, c_i, c_p, c_u, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "afd_transpose_last2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_prelu_dropout_forward": (c_i, [c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),
     "afd_prelu_dropout_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),

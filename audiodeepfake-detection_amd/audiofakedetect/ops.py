@@ -20,6 +20,17 @@ from . import _native
 _ws_cache: dict = {}
 _seed_counter = itertools.count(1)
 
+# Tests only: when set to a list, every PReLU / max-pool forward appends (kind, tensor) --
+# ("pool", the uint8 argmax code tensor) or ("prelu", the pre-activation tensor) -- i.e. the
+# tensors whose signs / codes decide how the backward pass routes gradients.  They are the very
+# tensors saved for backward, so a test can compare them with another implementation's decisions.
+debug_taps: Optional[list] = None
+
+
+def _tap(kind: str, t: torch.Tensor) -> None:
+    if debug_taps is not None:
+        debug_taps.append((kind, t))
+
 
 def _lib():
     return _native.load()
@@ -125,6 +136,29 @@ def normalize_forward(t: torch.Tensor, mean: float, std: float) -> torch.Tensor:
     _native.check(_lib().afd_normalize_forward(_native.ptr(src), _native.ptr(out), src.numel(),
                                                float(mean), float(std), _native.stream_ptr()),
                   "afd_normalize_forward")
+    return out.permute(*perm) if perm else out
+
+
+def normalize_channels_forward(t: torch.Tensor, means, stds) -> torch.Tensor:
+    """(t[:, c] - means[c]) / stds[c] for [B, C, ...] features, out of place, memory order kept:
+    one `afd_normalize_forward` launch per (frame, channel) plane set of the dense buffer."""
+    _native.require_gpu()
+    src, perm = t, None
+    if not t.is_contiguous():
+        if t.dim() == 4 and t.permute(0, 1, 3, 2).is_contiguous():
+            src, perm = t.permute(0, 1, 3, 2), (0, 1, 3, 2)
+        else:
+            src = t.contiguous()
+    src = src if src.is_cuda else src.cuda()
+    out = torch.empty_like(src)
+    b, c = src.shape[0], src.shape[1]
+    plane = src.numel() // (b * c)
+    for i in range(b):
+        for ch in range(c):
+            off = (i * c + ch) * plane * 4
+            _native.check(_lib().afd_normalize_forward(
+                _native.c_p(src.data_ptr() + off), _native.c_p(out.data_ptr() + off), plane,
+                float(means[ch]), float(stds[ch]), _native.stream_ptr()), "afd_normalize_forward")
     return out.permute(*perm) if perm else out
 
 
@@ -262,6 +296,7 @@ class _PReLUPool(torch.autograd.Function):
                                                  _native.stream_ptr()), "afd_prelu_pool_forward")
         # backward needs only the pooled output and the 3-bit argmax code: the 4x larger
         # pre-pool tensor z is not kept alive
+        _tap("pool", idx)
         ctx.save_for_backward(u, idx, slope if slope is not None else torch.empty(0))
         ctx.has_slope = slope is not None
         ctx.zshape = (n, c, h, w)
@@ -298,6 +333,7 @@ class _Conv1PReLUPool(torch.autograd.Function):
         _native.check(lib.afd_conv1_pool_forward(
             _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
             _native.ptr(idx), n, h, wd, cout, pad, _native.stream_ptr()), "afd_conv1_pool_forward")
+        _tap("pool", idx)
         ctx.save_for_backward(x, u, idx, slope)
         ctx.cfg = (n, h, wd, cout, pad, b is not None, tuple(w.shape))
         return u
@@ -350,6 +386,7 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
             _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
             _native.ptr(idx), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
             "afd_conv3x3_prelu_pool_forward")
+        _tap("pool", idx)
         ctx.save_for_backward(x, w, u, idx, slope)
         ctx.geom = (n, cin, h, wd, cout, 3, 1, 1)
         ctx.crop = (2 * (h // 2), 2 * (wd // 2))
@@ -473,6 +510,8 @@ class _BatchNorm(torch.autograd.Function):
             _native.ptr(gamma), _native.ptr(beta), _native.ptr(y), n, c, hw, _native.stream_ptr()),
             "afd_bn_apply_forward")
         empty = torch.empty(0)
+        if slope is not None:
+            _tap("prelu", x)
         ctx.save_for_backward(x, slope if slope is not None else empty, mean, invstd,
                               gamma if gamma is not None else empty)
         ctx.flags = (slope is not None, gamma is not None, training, sync)
@@ -704,6 +743,7 @@ class _PReLUDropout(torch.autograd.Function):
                                                        _native.ptr(y), z.numel(), p, seed,
                                                        _native.stream_ptr()),
                       "afd_prelu_dropout_forward")
+        _tap("prelu", z)
         ctx.save_for_backward(z, slope)
         ctx.cfg = (p, seed)
         return y

@@ -4,7 +4,8 @@ Keeps the public surface of the reference's ``src/audiofakedetect/wavelet_math.p
 (``Packets`` :223-263, ``STFTLayer`` :25-68, ``compute_pytorch_packet_representation``
 :167-220, ``get_transforms`` :266-384, ``calc_normalization`` :387-452); the arithmetic is
 one HIP launch per batch in ``libafd_hip.so`` (``afd_wpt_forward`` / ``afd_stft_forward``).
-There is no CPU path: inputs are moved to the GPU, and a missing library or GPU raises.
+There is no CPU path: CPU inputs are computed on the GPU and the result is returned on the
+input's device; a missing library or GPU raises.
 """
 
 from __future__ import annotations
@@ -62,10 +63,12 @@ def wpt_forward(
     log_scale: bool = False,
     loss_less: bool = False,
     power: float = 2.0,
-    mean: Optional[float] = None,
-    std: Optional[float] = None,
+    mean=None,
+    std=None,
 ) -> torch.Tensor:
-    """Launch the fused packet transform; returns memory-order [B, C, T, P]."""
+    """Launch the fused packet transform; returns memory-order [B, C, T, P].
+
+    ``mean`` / ``std``: a scalar, or one value per channel (coefficients, sign)."""
     lib = _native.load()
     x = _as_frames(frames)
     b, n = x.shape
@@ -88,11 +91,25 @@ def wpt_forward(
     rc = lib.afd_wpt_forward(
         _native.ptr(x), b, n, _native.float_array(wavelet.dec_lo),
         _native.float_array(wavelet.dec_hi), length, max_lev, flags, float(power), 1e-12,
-        float(mean or 0.0), float(std if std is not None else 1.0), _native.ptr(out),
+        *_channel_stats(mean, std), _native.ptr(out),
         _native.ptr(ws), ws_bytes, _native.stream_ptr(),
     )
     _native.check(rc, "afd_wpt_forward")
     return out
+
+
+def _channel_stats(mean, std) -> Tuple[float, float, float, float]:
+    """(mean, std, sign_mean, sign_std) of the C-ABI from a scalar or per-channel pair."""
+    def two(v, default):
+        if v is None:
+            return default, default
+        if isinstance(v, (tuple, list)):
+            return float(v[0]), float(v[-1])
+        return float(v), float(v)
+
+    m0, m1 = two(mean, 0.0)
+    s0, s1 = two(std, 1.0)
+    return m0, s0, m1, s1
 
 
 def graycode_keys(level: int) -> list:
@@ -158,8 +175,8 @@ def packet_block_norm(
     power: float,
     block_norm: bool,
     estimators: Optional[PacketWelford],
-    mean: Optional[float] = None,
-    std: Optional[float] = None,
+    mean=None,
+    std=None,
 ) -> torch.Tensor:
     """Packet image with per-node statistics / max normalisation (wavelet_math.py:194-218).
 
@@ -192,7 +209,7 @@ def packet_block_norm(
     out = torch.empty((b, nch, t_len, npk), dtype=torch.float32, device=raw.device)
     _native.check(lib.afd_packet_block_norm(
         _native.ptr(raw), b, t_len, npk, _native.ptr(absmax) if block_norm else None, flags,
-        float(power), 1e-12, float(mean or 0.0), float(std if std is not None else 1.0),
+        float(power), 1e-12, *_channel_stats(mean, std),
         _native.ptr(out), _native.stream_ptr()), "afd_packet_block_norm")
     return out
 
@@ -223,7 +240,7 @@ def compute_pytorch_packet_representation(
                                 block_norm, estimators)
     else:
         out = wpt_forward(pt_data, wavelet, max_lev, log_scale, loss_less, power)
-    return out, block_norm_dict
+    return (out if pt_data.is_cuda else out.cpu()), block_norm_dict
 
 
 class Packets(torch.nn.Module):
@@ -250,7 +267,7 @@ class Packets(torch.nn.Module):
         self.compute_welford = compute_welford
         self.block_norm_dict = block_norm_dict
         # set by fuse_normalization(): (mean, std) applied in the kernel epilogue
-        self.fused_norm: Optional[Tuple[float, float]] = None
+        self.fused_norm: Optional[tuple] = None  # scalars, or (coefficients, sign) pairs
 
     def forward(self, pt_data: torch.Tensor) -> Tuple[torch.Tensor, dict]:
         mean, std = self.fused_norm if self.fused_norm is not None else (None, None)
@@ -264,6 +281,8 @@ class Packets(torch.nn.Module):
             packets = wpt_forward(pt_data, self.wavelet, self.max_lev, self.log_scale,
                                   self.loss_less, self.power, mean, std)
         bdict = self.block_norm_dict if self.block_norm_dict is not None else {}
+        if not pt_data.is_cuda:
+            packets = packets.cpu()  # the result lives where the input lives, as in the reference
         # logical [B, C, P, T]; memory stays [B, C, T, P] exactly like the reference's view
         return packets.permute(0, 1, 3, 2), bdict
 
@@ -288,26 +307,57 @@ class STFTLayer(torch.nn.Module):
 
         mean, std = self.fused_norm if self.fused_norm is not None else (None, None)
         spec = stft_forward(self, input, mean, std)
-        return spec, None
+        return (spec if input.is_cuda else spec.cpu()), None
 
 
 class Normalize(torch.nn.Module):
-    """``torchvision.transforms.Normalize`` with scalar statistics (wavelet_math.py:380-382)."""
+    """``torchvision.transforms.Normalize`` (wavelet_math.py:380-382): ``(t - mean[c]) / std[c]``.
+
+    The statistics are per channel, as ``calc_normalization``'s Welford produces them (one value
+    for the usual single-channel features, two with ``--loss-less True``: log-magnitude and sign);
+    a single value is applied to every channel, as torchvision broadcasts it."""
 
     def __init__(self, mean, std) -> None:
         super().__init__()
-        self.mean = float(mean.reshape(-1)[0]) if torch.is_tensor(mean) else float(mean)
-        self.std = float(std.reshape(-1)[0]) if torch.is_tensor(std) else float(std)
-        if self.std == 0.0:
+        self.means = [float(v) for v in torch.as_tensor(mean, dtype=torch.float64).reshape(-1).tolist()]
+        self.stds = [float(v) for v in torch.as_tensor(std, dtype=torch.float64).reshape(-1).tolist()]
+        if len(self.means) != len(self.stds) and 1 not in (len(self.means), len(self.stds)):
+            raise ValueError("mean and std must hold one value per channel")
+        if any(s == 0.0 for s in self.stds):
             raise ValueError("std evaluated to zero")
         self.identity = False  # True once the statistics are fused into the transform
+
+    @property
+    def mean(self) -> float:
+        return self.means[0]
+
+    @property
+    def std(self) -> float:
+        return self.stds[0]
+
+    def channel_stats(self, channels: int):
+        """([mean per channel], [std per channel]) for a `channels`-channel tensor."""
+        nstat = max(len(self.means), len(self.stds))
+        if nstat not in (1, channels):
+            raise ValueError(f"Normalize holds {nstat} channel statistics, the tensor has {channels} channels")
+        means = self.means * channels if len(self.means) == 1 else self.means
+        stds = self.stds * channels if len(self.stds) == 1 else self.stds
+        return means, stds
 
     def forward(self, t: torch.Tensor) -> torch.Tensor:
         if self.identity:
             return t
         from .ops import normalize_forward
 
-        return normalize_forward(t, self.mean, self.std)
+        means, stds = self.channel_stats(t.shape[1] if t.dim() >= 3 else 1)
+        if len(set(means)) == 1 and len(set(stds)) == 1:
+            out = normalize_forward(t, means[0], stds[0])
+        else:
+            # per-channel statistics (loss-less features) outside the fused epilogue
+            from .ops import normalize_channels_forward
+
+            out = normalize_channels_forward(t, means, stds)
+        return out if t.is_cuda else out.cpu()
 
 
 def fuse_normalization(transforms: torch.nn.Sequential, normalize: torch.nn.Sequential) -> bool:
@@ -321,7 +371,14 @@ def fuse_normalization(transforms: torch.nn.Sequential, normalize: torch.nn.Sequ
     tr, nm = transforms[0], normalize[0]
     if not isinstance(nm, Normalize) or not hasattr(tr, "fused_norm"):
         return False
-    tr.fused_norm = (nm.mean, nm.std)
+    if len(nm.means) == 1 and len(nm.stds) == 1:
+        tr.fused_norm = (nm.mean, nm.std)
+    else:
+        # per-channel statistics: the packet transform's epilogue takes (coefficients, sign) pairs
+        if not isinstance(tr, Packets) or max(len(nm.means), len(nm.stds)) != 2 or not tr.loss_less:
+            return False
+        means, stds = nm.channel_stats(2)
+        tr.fused_norm = (tuple(means), tuple(stds))
     nm.identity = True
     return True
 

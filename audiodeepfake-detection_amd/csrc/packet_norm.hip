@@ -108,7 +108,7 @@ __device__ __noinline__ float pow_log_precise(float v, float power, float eps) {
 
 struct BnParams {
     unsigned flags;
-    float power, eps, mean, std;
+    float power, eps, mean, std, sgn_neg, sgn_pos;
     long TP;       // T * P
     long chan;     // output channel stride = T * P
     int P, C;
@@ -143,8 +143,7 @@ __global__ __launch_bounds__(kT) void packet_block_norm_kernel(const float* __re
         for (int k = 0; k < VEC; ++k) {
             const float v = absmax ? f[k] / d[k] : f[k];
             r[k] = bn_value(v, p);
-            sg[k] = v < 0.f ? -1.f : 1.f;
-            if (p.flags & AFD_WPT_NORM) sg[k] = (sg[k] - p.mean) / p.std;
+            sg[k] = v < 0.f ? p.sgn_neg : p.sgn_pos;
         }
         float* o = out + b * p.C * p.chan + within;
         if constexpr (VEC == 4) {
@@ -186,12 +185,13 @@ extern "C" int afd_packet_stats(const float* x, long rows, int P, double* sums, 
 
 extern "C" int afd_packet_block_norm(const float* x, int B, int T, int P, const float* absmax,
                                      unsigned flags, float power, float eps, float mean, float std,
-                                     float* out, afd_stream_t stream) {
+                                     float sign_mean, float sign_std, float* out, afd_stream_t stream) {
     if (!x || !out) return afd::fail(AFD_ERR_ARG, "packet block norm: null pointer");
     if (B < 0 || T < 1 || P < 1) return afd::fail(AFD_ERR_ARG, "packet block norm: bad shape");
     if ((flags & AFD_WPT_SIGN) && !(flags & AFD_WPT_LOG))
         return afd::fail(AFD_ERR_ARG, "packet block norm: AFD_WPT_SIGN needs AFD_WPT_LOG");
-    if ((flags & AFD_WPT_NORM) && std == 0.f) return afd::fail(AFD_ERR_ARG, "packet block norm: std == 0");
+    if ((flags & AFD_WPT_NORM) && (std == 0.f || ((flags & AFD_WPT_SIGN) && sign_std == 0.f)))
+        return afd::fail(AFD_ERR_ARG, "packet block norm: std == 0");
     if (B == 0) return AFD_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     BnParams p;
@@ -200,6 +200,8 @@ extern "C" int afd_packet_block_norm(const float* x, int B, int T, int P, const 
     p.eps = eps;
     p.mean = mean;
     p.std = std;
+    p.sgn_neg = (flags & AFD_WPT_NORM) ? (-1.f - sign_mean) / sign_std : -1.f;
+    p.sgn_pos = (flags & AFD_WPT_NORM) ? (1.f - sign_mean) / sign_std : 1.f;
     p.TP = (long)T * P;
     p.chan = p.TP;
     p.P = P;

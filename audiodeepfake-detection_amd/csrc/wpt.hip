@@ -35,6 +35,7 @@ struct WptParams {
     int n[kMaxLevel + 1];
     unsigned flags;
     float power, eps, mean, std;
+    float sgn_neg, sgn_pos;  // the sign channel's two values, already normalised with its own statistics
     float lo[kMaxTaps], hi[kMaxTaps];
 };
 
@@ -136,12 +137,8 @@ __device__ __forceinline__ void final_step(const WptParams& p, const float* src,
         *reinterpret_cast<float2*>(outb + o) = r;
         if (C == 2) {
             float2 s;
-            s.x = v0 < 0.f ? -1.f : 1.f;
-            s.y = v1 < 0.f ? -1.f : 1.f;
-            if (p.flags & AFD_WPT_NORM) {
-                s.x = (s.x - p.mean) / p.std;
-                s.y = (s.y - p.mean) / p.std;
-            }
+            s.x = v0 < 0.f ? p.sgn_neg : p.sgn_pos;
+            s.y = v1 < 0.f ? p.sgn_neg : p.sgn_pos;
             *reinterpret_cast<float2*>(outb + (size_t)T * P + o) = s;
         }
     }
@@ -328,13 +325,13 @@ extern "C" int afd_wpt_out_len(int N, int L, int level) {
 
 namespace afd {
 int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L, int level,
-                       unsigned flags, float power, float eps, float mean, float std, float* out,
-                       hipStream_t stream);
+                       unsigned flags, float power, float eps, float mean, float std, float sign_mean,
+                       float sign_std, float* out, hipStream_t stream);
 size_t wpt2_workspace_bytes(int B, int N, int L, int level);
 bool wpt2_preferred(int L, int level);
 int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
-                 int level, unsigned flags, float power, float eps, float mean, float std, float* out,
-                 void* ws, size_t ws_bytes, hipStream_t stream);
+                 int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
+                 float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 }  // namespace afd
 
 extern "C" size_t afd_wpt_workspace_bytes(int B, int N, int L, int level) {
@@ -344,8 +341,8 @@ extern "C" size_t afd_wpt_workspace_bytes(int B, int N, int L, int level) {
 
 extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo,
                                const float* dec_hi, int L, int level, unsigned flags, float power,
-                               float eps, float mean, float std, float* out, void* ws,
-                               size_t ws_bytes, afd_stream_t stream) {
+                               float eps, float mean, float std, float sign_mean, float sign_std,
+                               float* out, void* ws, size_t ws_bytes, afd_stream_t stream) {
     if (!x || !out || !dec_lo || !dec_hi) return afd::fail(AFD_ERR_ARG, "wpt: null pointer");
     if (B < 1 || N < 2) return afd::fail(AFD_ERR_ARG, "wpt: bad shape B=%d N=%d", B, N);
     if (L < 2 || L > kMaxTaps || (L & 1))
@@ -353,13 +350,14 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
     if (level < 1 || level > kMaxLevel) return afd::fail(AFD_ERR_ARG, "wpt: level %d", level);
     if ((flags & AFD_WPT_SIGN) && !(flags & AFD_WPT_LOG))
         return afd::fail(AFD_ERR_ARG, "wpt: AFD_WPT_SIGN needs AFD_WPT_LOG");
-    if ((flags & AFD_WPT_NORM) && std == 0.f) return afd::fail(AFD_ERR_ARG, "wpt: std == 0");
+    if ((flags & AFD_WPT_NORM) && (std == 0.f || ((flags & AFD_WPT_SIGN) && sign_std == 0.f)))
+        return afd::fail(AFD_ERR_ARG, "wpt: std == 0");
     if ((long)B << (level >= 3 ? 2 : level - 1) > 0x7fffffffL)
         return afd::fail(AFD_ERR_ARG, "wpt: batch too large");
     if (!getenv("AFD_WPT_NO_HAAR")) {
         // Haar, level 14, 22 050-sample frames: dedicated add/subtract network (wpt_haar.hip)
         const int rch = afd::wpt_haar14_forward(x, B, N, dec_lo, L, level, flags, power, eps, mean, std,
-                                                out, static_cast<hipStream_t>(stream));
+                                                sign_mean, sign_std, out, static_cast<hipStream_t>(stream));
         if (rch != 1) return rch;
     }
     // Which generation: wpt2.hip (register window + packed FMAs, level-1 subtree per workgroup, MFMA
@@ -370,7 +368,8 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
     if (afd::wpt2_preferred(L, level)) {
         // 1 = geometry left to the kernel below
         const int rc2 = afd::wpt2_forward(x, B, N, dec_lo, dec_hi, L, level, flags, power, eps, mean,
-                                          std, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+                                          std, sign_mean, sign_std, out, ws, ws_bytes,
+                                          static_cast<hipStream_t>(stream));
         if (rc2 != 1) return rc2;
     }
     WptParams p{};
@@ -385,6 +384,8 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
     p.eps = eps;
     p.mean = mean;
     p.std = std;
+    p.sgn_neg = (flags & AFD_WPT_NORM) ? (-1.f - sign_mean) / sign_std : -1.f;
+    p.sgn_pos = (flags & AFD_WPT_NORM) ? (1.f - sign_mean) / sign_std : 1.f;
     for (int m = 0; m < L; ++m) {
         p.lo[m] = dec_lo[m];
         p.hi[m] = dec_hi[m];

@@ -50,6 +50,7 @@ struct W2Params {
     int n[kMaxLevel + 1];
     unsigned flags;
     float power, eps, mean, std, inv_std;
+    float sgn_neg, sgn_pos;  // the sign channel's two values, normalised with its own statistics
     float lo[kMaxTaps], hi[kMaxTaps];
     float rlo[kMaxTaps], rhi[kMaxTaps];  // taps reversed: rlo[t] = lo[L-1-t]
 };
@@ -124,12 +125,8 @@ __device__ __forceinline__ void emit(const W2Params& p, const Sink& s, int mode,
         *reinterpret_cast<f2*>(s.outb + o) = r;
         if (s.flags & AFD_WPT_SIGN) {
             f2 sg;
-            sg.x = v.x < 0.f ? -1.f : 1.f;
-            sg.y = v.y < 0.f ? -1.f : 1.f;
-            if (s.flags & AFD_WPT_NORM) {
-                sg.x = (sg.x - p.mean) * p.inv_std;
-                sg.y = (sg.y - p.mean) * p.inv_std;
-            }
+            sg.x = v.x < 0.f ? p.sgn_neg : p.sgn_pos;
+            sg.y = v.y < 0.f ? p.sgn_neg : p.sgn_pos;
             *reinterpret_cast<f2*>(s.outb + s.chan + o) = sg;
         }
     }
@@ -544,7 +541,7 @@ struct MfParams {
     short kst[6][kMfWaves];     // first k-step of each row tile's band
     int X, Y, C13, level;
     unsigned flags;
-    float power, eps, mean, inv_std;
+    float power, eps, mean, inv_std, sgn_neg, sgn_pos;
 };
 
 struct MfSink {
@@ -637,12 +634,8 @@ __device__ __forceinline__ void mfma_level(const MfParams& p, const float (&a)[L
                         *reinterpret_cast<f2*>(fs.outb + o) = q;
                         if (p.flags & AFD_WPT_SIGN) {
                             f2 sg;
-                            sg.x = v.x < 0.f ? -1.f : 1.f;
-                            sg.y = v.y < 0.f ? -1.f : 1.f;
-                            if (p.flags & AFD_WPT_NORM) {
-                                sg.x = (sg.x - p.mean) * p.inv_std;
-                                sg.y = (sg.y - p.mean) * p.inv_std;
-                            }
+                            sg.x = v.x < 0.f ? p.sgn_neg : p.sgn_pos;
+                            sg.y = v.y < 0.f ? p.sgn_neg : p.sgn_pos;
                             *reinterpret_cast<f2*>(fs.outb + fs.chan + o) = sg;
                         }
                     }
@@ -787,6 +780,7 @@ int launch_deep_mfma(const W2Params& p, hipStream_t stream) {
         q.ws = p.ws; q.tab = tab; q.out = p.out;
         q.X = p.mfX; q.Y = p.mfY; q.C13 = p.mfC13; q.level = p.level;
         q.flags = p.flags; q.power = p.power; q.eps = p.eps; q.mean = p.mean; q.inv_std = p.inv_std;
+        q.sgn_neg = p.sgn_neg; q.sgn_pos = p.sgn_pos;
         hipLaunchKernelGGL(wpt2_deep_mfma_kernel<MfShape<L>>, dim3((unsigned)p.B * (256 / kMfG)), dim3(kMfThreads),
                            (size_t)(p.mfX + p.mfY) * 4, stream, q);
     }
@@ -929,13 +923,15 @@ size_t wpt2_workspace_bytes(int B, int N, int L, int level) {
 
 // returns AFD_OK, an error, or 1 = "not handled here, use the first-generation kernel"
 int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
-                 int level, unsigned flags, float power, float eps, float mean, float std, float* out,
-                 void* ws, size_t ws_bytes, hipStream_t stream) {
+                 int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
+                 float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
     W2Params p{};
     p.x = x; p.out = out; p.ws = static_cast<float*>(ws);
     p.B = B; p.N = N; p.L = L; p.level = level;
     p.flags = flags; p.power = power; p.eps = eps; p.mean = mean; p.std = std;
     p.inv_std = (float)(1.0 / (double)(std == 0.f ? 1.f : std));
+    p.sgn_neg = (flags & AFD_WPT_NORM) ? (-1.f - sign_mean) / sign_std : -1.f;
+    p.sgn_pos = (flags & AFD_WPT_NORM) ? (1.f - sign_mean) / sign_std : 1.f;
     for (int m = 0; m < L; ++m) {
         p.lo[m] = dec_lo[m];
         p.hi[m] = dec_hi[m];

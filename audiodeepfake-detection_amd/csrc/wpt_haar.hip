@@ -43,7 +43,7 @@ struct HaarParams {
     float* out;
     int B;
     unsigned flags;
-    float eps, mean, inv_std, scale;
+    float eps, mean, inv_std, scale, sgn_neg, sgn_pos;
 };
 
 __device__ __forceinline__ float haar_epilogue(float v, const HaarParams& p) {
@@ -304,16 +304,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float4 sgn;
-                    sgn.x = out[t][4 * k] < 0.f ? -1.f : 1.f;
-                    sgn.y = out[t][4 * k + 1] < 0.f ? -1.f : 1.f;
-                    sgn.z = out[t][4 * k + 2] < 0.f ? -1.f : 1.f;
-                    sgn.w = out[t][4 * k + 3] < 0.f ? -1.f : 1.f;
-                    if (p.flags & AFD_WPT_NORM) {
-                        sgn.x = (sgn.x - p.mean) * p.inv_std;
-                        sgn.y = (sgn.y - p.mean) * p.inv_std;
-                        sgn.z = (sgn.z - p.mean) * p.inv_std;
-                        sgn.w = (sgn.w - p.mean) * p.inv_std;
-                    }
+                    sgn.x = out[t][4 * k] < 0.f ? p.sgn_neg : p.sgn_pos;
+                    sgn.y = out[t][4 * k + 1] < 0.f ? p.sgn_neg : p.sgn_pos;
+                    sgn.z = out[t][4 * k + 2] < 0.f ? p.sgn_neg : p.sgn_pos;
+                    sgn.w = out[t][4 * k + 3] < 0.f ? p.sgn_neg : p.sgn_pos;
                     *reinterpret_cast<float4*>(ob + (size_t)(2 + t) * P + 16 * k) = sgn;
                 }
             }
@@ -328,8 +322,8 @@ namespace afd {
 
 // 0 = launched, 1 = not this kernel's case
 int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L, int level,
-                       unsigned flags, float power, float eps, float mean, float std, float* out,
-                       hipStream_t stream) {
+                       unsigned flags, float power, float eps, float mean, float std, float sign_mean,
+                       float sign_std, float* out, hipStream_t stream) {
     if (L != 2 || level != 14 || N != kN || power != 2.0f) return 1;
     const float s = 0.70710678118654752f;
     if (fabsf(dec_lo[0] - s) > 1e-6f || fabsf(dec_lo[1] - s) > 1e-6f) return 1;
@@ -352,6 +346,8 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     p.eps = eps;
     p.mean = mean;
     p.inv_std = (float)(1.0 / (double)(std == 0.f ? 1.f : std));
+    p.sgn_neg = (flags & AFD_WPT_NORM) ? (-1.f - sign_mean) / sign_std : -1.f;
+    p.sgn_pos = (flags & AFD_WPT_NORM) ? (1.f - sign_mean) / sign_std : 1.f;
     p.scale = 1.0f / 128.0f;  // (1/sqrt 2)^14
     afd::ScopedTiming timing(AFD_K_WPT, 4.0 * B * ((double)N + ((flags & AFD_WPT_SIGN) ? 2.0 : 1.0) * 32768.0), stream);
     // two workgroups (frame halves) per CU, 16 per XCD pair up on a frame; the grid is a

@@ -61,7 +61,8 @@ int afd_timing_reset(void);
  * ---------------------------------------------------------------------------------- */
 #define AFD_WPT_LOG 1u  /* log(|x|^power + eps)                                       */
 #define AFD_WPT_SIGN 2u /* second channel = +1/-1 sign pattern (loss_less), needs LOG */
-#define AFD_WPT_NORM 4u /* (v - mean) / std on every channel                          */
+#define AFD_WPT_NORM 4u /* per-channel Normalize: (v - mean) / std on the coefficient
+                         * channel, (s - sign_mean) / sign_std on the sign channel    */
 
 /* Node length at `level` for frames of N samples and L-tap filters (reflect mode). */
 int afd_wpt_out_len(int N, int L, int level);
@@ -74,10 +75,14 @@ size_t afd_wpt_workspace_bytes(int B, int N, int L, int level);
  * out [dev]  [B][C][T][P], P = 2^level packets in frequency (Gray-code) order fastest,
  *            T = afd_wpt_out_len, C = 2 with AFD_WPT_SIGN else 1.  This is the memory
  *            order of the reference's returned view (logical [B][C][P][T]).
+ * mean, std / sign_mean, sign_std: the per-channel statistics torchvision Normalize applies
+ *            (calc_normalization's Welford runs per channel, wavelet_math.py:441); the sign
+ *            pair is read only with AFD_WPT_SIGN | AFD_WPT_NORM.
  */
 int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi,
                     int L, int level, unsigned flags, float power, float eps, float mean,
-                    float std, float* out, void* ws, size_t ws_bytes, afd_stream_t stream);
+                    float std, float sign_mean, float sign_std, float* out, void* ws, size_t ws_bytes,
+                    afd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * STFT power spectrogram front end.
@@ -194,8 +199,8 @@ int afd_moments_accumulate(const float* x, size_t n, double* acc, afd_stream_t s
 int afd_packet_stats(const float* x, long rows, int P, double* sums, float* absmax,
                      afd_stream_t stream);
 int afd_packet_block_norm(const float* x, int B, int T, int P, const float* absmax /* may be NULL */,
-                          unsigned flags, float power, float eps, float mean, float std, float* out,
-                          afd_stream_t stream);
+                          unsigned flags, float power, float eps, float mean, float std, float sign_mean,
+                          float sign_std, float* out, afd_stream_t stream);
 
 /* torchvision Normalize with scalar statistics (wavelet_math.py:380-382): y = (x-mean)/std */
 int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,

@@ -57,6 +57,48 @@ def dcnn_args(DotDict, input_dim, time_dim_add=0, flattend_size=320):
     )
 
 
+def record_routing(net):
+    """Hooks that record, for one forward of the reference DCNN, every piecewise-linear routing
+    decision the backward pass depends on, in forward order:
+
+    ("pool", uint8 [B,C,Hp,Wp])  PReLU followed by MaxPool2d(2, 2): bits 0-1 = position dy*2+dx of
+                                 the window's maximum, bit 2 = the winning pre-activation was <= 0;
+    ("prelu", packed bits)       any other PReLU: pre-activation <= 0, numpy.packbits of the
+                                 flattened mask, with the shape next to it.
+    Only these decisions are stored (no activations)."""
+    import torch.nn as nn
+
+    records = []
+    mods = []
+    for seq_name in ("cnn", "dil_conv"):
+        seq = getattr(net, seq_name)
+        for i, m in enumerate(seq):
+            if isinstance(m, nn.PReLU):
+                nxt = seq[i + 1] if i + 1 < len(seq) else None
+                mods.append((f"{seq_name}.{i}", m, isinstance(nxt, nn.MaxPool2d)))
+
+    def make_hook(name, pooled):
+        def hook(mod, inp, out):
+            z = inp[0].detach()
+            if pooled:
+                _, flat = torch.nn.functional.max_pool2d(out.detach(), 2, 2, return_indices=True)
+                w = z.shape[-1]
+                row, col = flat // w, flat % w
+                pos = (row % 2) * 2 + (col % 2)
+                zwin = z.flatten(2).gather(2, flat.flatten(2)).reshape(flat.shape)
+                code = (pos + 4 * (zwin <= 0)).to(torch.uint8)
+                records.append({"name": name, "kind": "pool", "code": code})
+            else:
+                mask = (z <= 0).flatten().numpy()
+                records.append({"name": name, "kind": "prelu", "shape": tuple(z.shape),
+                                "bits": torch.from_numpy(np.packbits(mask))})
+        return hook
+
+    for name, m, pooled in mods:
+        m.register_forward_hook(make_hook(name, pooled))
+    return records
+
+
 def main():
     models, DotDict = import_reference_models()
     torch.manual_seed(0)
@@ -111,11 +153,14 @@ def main():
     opt = torch.optim.Adam(net.parameters(), lr=4e-4, weight_decay=1e-3)
     net.train()
     opt.zero_grad()
+    routing = record_routing(net)
     out = net(x)
     loss = torch.nn.CrossEntropyLoss()(out, labels)
     loss.backward()
     grads = {k: p.grad.clone() for k, p in net.named_parameters()}
     opt.step()
+    # the reference run's routing decisions, in forward order (see record_routing)
+    torch.save({"routing": routing}, os.path.join(OUT, "dcnn_train_step_routing.pt"))
     gold["train_step"] = {
         "state_dict": sd0, "x": x, "labels": labels, "logits": out.detach(),
         "loss": loss.detach(), "grads": grads,

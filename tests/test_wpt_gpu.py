@@ -81,7 +81,8 @@ def test_input_forms_and_layout():
     assert isinstance(d, dict)
     assert a.shape == (2, 1, 256, 95) and not a.is_contiguous()
     assert a.permute(0, 1, 3, 2).is_contiguous()  # memory order [B, C, T, P]
-    assert torch.equal(a, b) and torch.equal(a[:1], c)
+    assert not c.is_cuda  # results live on the input's device, as in the reference
+    assert torch.equal(a, b) and torch.equal(a[:1].cpu(), c)
     raw, _ = compute_pytorch_packet_representation(x.cuda(), wavelets.Wavelet("sym5"), 8)
     assert raw.shape == (2, 1, 95, 256)
 
@@ -97,6 +98,64 @@ def test_reference_test_shapes():
     assert out.shape == (2, 2, 187, 128)
     out, _ = Packets("db8", max_lev=7, log_scale=True)(x)
     assert out.shape == (2, 1, 128, 187)
+
+
+def test_loss_less_per_channel_normalisation():
+    """--loss-less True: two channels (log magnitude, sign) with their own Welford statistics, applied
+    per channel by torchvision Normalize in the reference (wavelet_math.py:380-382, :441)."""
+    from audiofakedetect.wavelet_math import Normalize, fuse_normalization
+    from oracle import torch_ref
+
+    x = _parity_inputs(seed=2)[:3]
+    w = wavelets.Wavelet("sym5")
+    mean = torch.tensor([-11.5, 0.03])
+    std = torch.tensor([3.75, 0.98])
+    ref, _ = torch_ref.packets_torch(x.double(), w.dec_lo, 8, log_scale=True, loss_less=True)
+    ref = (ref - mean.double()[None, :, None, None]) / std.double()[None, :, None, None]
+    coef = wpt_oracle.packet_features(x.double().numpy(), w.dec_lo, 8)[:, 0]
+    d = COEF_RTOL * np.max(np.abs(coef))
+    sure = torch.from_numpy(np.abs(coef) > 50 * d)
+
+    def check(got):
+        got = got.cpu().double()
+        assert got.shape == ref.shape == (3, 2, 256, 95)
+        assert (got[:, 0] - ref[:, 0])[sure].abs().max().item() <= 1e-4
+        assert (got[:, 1] - ref[:, 1])[sure].abs().max().item() <= 1e-6
+        # the sign channel holds exactly the two normalised values
+        vals = torch.unique(got[:, 1].float())
+        want = torch.sort((torch.tensor([-1.0, 1.0]) - mean[1]) / std[1])[0]
+        assert torch.equal(vals, want)
+
+    for name, level in (("sym5", 8),):
+        tr = torch.nn.Sequential(Packets(name, max_lev=level, log_scale=True, loss_less=True))
+        # (a) unfused: transform, then the Normalize module
+        nm = torch.nn.Sequential(Normalize(mean, std))
+        feats, _ = tr(x.cuda())
+        check(nm(feats))
+        # (b) fused into the transform epilogue (what the Trainer does)
+        assert fuse_normalization(tr, nm) and nm[0].identity
+        feats, _ = tr(x.cuda())
+        check(nm(feats))
+    # the fused epilogue of every kernel generation carries the sign statistics
+    for name, level in (("coif4", 14), ("haar", 14), ("sym5", 14), ("coif4", 8)):
+        tr = Packets(name, max_lev=level, log_scale=True, loss_less=True)
+        plain, _ = tr(x.cuda())
+        tr.fused_norm = ((-11.5, 0.03), (3.75, 0.98))
+        fused, _ = tr(x.cuda())
+        assert torch.allclose(fused[:, 0], (plain[:, 0] + 11.5) / 3.75, atol=2e-6, rtol=1e-6)
+        assert torch.equal(fused[:, 1], (plain[:, 1] - 0.03) / 0.98)
+    # block-norm path (afd_packet_block_norm)
+    tr = Packets("sym5", max_lev=6, log_scale=True, loss_less=True, block_norm=True)
+    plain, _ = tr(x.cuda())
+    tr.fused_norm = ((-11.5, 0.03), (3.75, 0.98))
+    fused, _ = tr(x.cuda())
+    assert torch.allclose(fused[:, 0], (plain[:, 0] + 11.5) / 3.75, atol=2e-6, rtol=1e-6)
+    assert torch.equal(fused[:, 1], (plain[:, 1] - 0.03) / 0.98)
+    # a scalar statistic still applies to both channels, a wrong channel count raises
+    nm1 = Normalize(torch.tensor(0.5), torch.tensor(2.0))
+    assert torch.equal(nm1(plain), (plain - 0.5) / 2.0)
+    with pytest.raises(ValueError):
+        Normalize(torch.zeros(3), torch.ones(3))(plain)
 
 
 def test_fused_normalisation():
