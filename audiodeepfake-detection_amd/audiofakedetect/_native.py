@@ -31,8 +31,8 @@ _SIGNATURES = {
     "afd_last_error": (ctypes.c_char_p, []),
     "afd_version": (c_i, []),
     "afd_timing_enable": (c_i, [c_i]),
-    "afd_timing_collect": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_l),
-                                 ctypes.POINTER(ctypes.c_double)]),
+    "afd_timing_collect": (c_i, [c_i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_l)]
+                           + [ctypes.POINTER(ctypes.c_double)] * 3),
     "afd_timing_reset": (c_i, []),
     "afd_wpt_out_len": (c_i, [c_i, c_i, c_i]),
     "afd_wpt_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
@@ -138,12 +138,16 @@ def timing_enable(on: bool) -> None:
     load().afd_timing_enable(1 if on else 0)
 
 
-def timing_collect(name: str):
-    """(total_ms, launches, total_work) of one kernel class since the last reset."""
+def timing_collect(name: str) -> dict:
+    """Sums over one kernel class's launches since the last reset: total_ms, launches, work
+    (algorithmic bytes or direct-form flops), issued (matrix-core flops) and bytes (algorithmic)."""
     ms, n, work = ctypes.c_double(), c_l(), ctypes.c_double()
+    issued, nbytes = ctypes.c_double(), ctypes.c_double()
     check(load().afd_timing_collect(KERNEL_CLASSES[name], ctypes.byref(ms), ctypes.byref(n),
-                                    ctypes.byref(work)), "afd_timing_collect")
-    return ms.value, n.value, work.value
+                                    ctypes.byref(work), ctypes.byref(issued), ctypes.byref(nbytes)),
+          "afd_timing_collect")
+    return {"total_ms": ms.value, "launches": n.value, "work": work.value, "issued": issued.value,
+            "bytes": nbytes.value}
 
 
 def timing_reset() -> None:

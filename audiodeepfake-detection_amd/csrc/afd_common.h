@@ -24,9 +24,10 @@ inline int check_launch(const char* what) {
     return AFD_OK;
 }
 
-// per-kernel HIP-event timing (afd_timing_enable); `work` = algorithmic flops or bytes
+// per-kernel HIP-event timing (afd_timing_enable); `work` = algorithmic flops (direct form) or bytes
 bool timing_on();
 void timing_begin(int id, double work, hipStream_t s);
+void timing_annotate(double issued_flops, double algo_bytes);  // negative = leave as is
 void timing_end(hipStream_t s);
 
 struct ScopedTiming {
@@ -35,6 +36,10 @@ struct ScopedTiming {
     ScopedTiming(int id, double work, hipStream_t st) : s(st), on(timing_on()) {
         if (on) timing_begin(id, work, s);
     }
+    // flops the launch really issues on the matrix cores (tile padding included; Winograd: 16 GEMMs)
+    void issued(double flops) { if (on) timing_annotate(flops, -1.0); }
+    // bytes an ideal implementation moves: every input and output tensor once
+    void bytes(double b) { if (on) timing_annotate(-1.0, b); }
     ~ScopedTiming() {
         if (on) timing_end(s);
     }

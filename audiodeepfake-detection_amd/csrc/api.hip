@@ -24,7 +24,7 @@ namespace {
 struct Slot {
     hipEvent_t a, b;
     int id;
-    double work;
+    double work, issued, bytes;
 };
 std::vector<Slot>& slots() {
     static std::vector<Slot> v;
@@ -39,9 +39,17 @@ void timing_begin(int id, double work, hipStream_t s) {
     Slot sl;
     sl.id = id;
     sl.work = work;
+    sl.issued = 0.0;
+    sl.bytes = 0.0;
     if (hipEventCreate(&sl.a) != hipSuccess || hipEventCreate(&sl.b) != hipSuccess) return;
     (void)hipEventRecord(sl.a, s);
     slots().push_back(sl);
+}
+
+void timing_annotate(double issued_flops, double algo_bytes) {
+    if (slots().empty()) return;
+    if (issued_flops >= 0.0) slots().back().issued = issued_flops;
+    if (algo_bytes >= 0.0) slots().back().bytes = algo_bytes;
 }
 
 void timing_end(hipStream_t s) {
@@ -56,8 +64,9 @@ extern "C" int afd_timing_enable(int on) {
 }
 
 // Sums the recorded launches of kernel class `id` (AFD_K_*); synchronises on their events.
-extern "C" int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work) {
-    double ms = 0.0, work = 0.0;
+extern "C" int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work,
+                                  double* total_issued, double* total_bytes) {
+    double ms = 0.0, work = 0.0, issued = 0.0, bytes = 0.0;
     long long n = 0;
     for (auto& sl : afd::slots()) {
         if (sl.id != id) continue;
@@ -66,11 +75,15 @@ extern "C" int afd_timing_collect(int id, double* total_ms, long long* count, do
         if (hipEventElapsedTime(&t, sl.a, sl.b) != hipSuccess) return afd::fail(AFD_ERR_HIP, "timing: elapsed failed");
         ms += t;
         work += sl.work;
+        issued += sl.issued;
+        bytes += sl.bytes;
         ++n;
     }
     if (total_ms) *total_ms = ms;
     if (count) *count = n;
     if (total_work) *total_work = work;
+    if (total_issued) *total_issued = issued;
+    if (total_bytes) *total_bytes = bytes;
     return AFD_OK;
 }
 

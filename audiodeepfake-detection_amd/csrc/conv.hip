@@ -504,6 +504,9 @@ int launch_igemm(const ConvGeom& g, const float* x, const float* wp, const float
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv: grid too large");
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM,
                              2.0 * g.N * g.Cout * (double)g.Hout * g.Wout * g.Cin * g.K * g.K, s);
+    // lower bound of the issued matrix flops: channel-tile padding counted, pixel- and k-tile padding not
+    timing.issued(2.0 * g.N * g.CO_PAD * (double)g.Hout * g.Wout * g.Cin * g.K * g.K);
+    timing.bytes(4.0 * g.N * ((double)g.Cin * g.H * g.W + (double)g.Cout * g.Hout * g.Wout));
     const int key = g.MW * 10 + g.NW;
     switch (key) {
         case 12: launch_igemm_t<1, 2>(g, x, wp, bias, y, (unsigned)blocks, threads, s); break;
@@ -842,6 +845,8 @@ int launch_wgrad_t(const WgradGeom& wg, const float* x, const float* dz, float* 
     }
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * wg.c.N * wg.c.Cout * (double)wg.c.Hout *
                                                    wg.c.Wout * wg.c.Cin * wg.c.K * wg.c.K, s);
+    timing.issued(2.0 * wg.c.N * wg.c.CO_PAD * (double)wg.c.Hout * wg.c.Wout * wg.c.Cin * wg.c.K * wg.c.K);
+    timing.bytes(4.0 * wg.c.N * ((double)wg.c.Cin * wg.c.H * wg.c.W + (double)wg.c.Cout * wg.c.Hout * wg.c.Wout));
     hipLaunchKernelGGL(conv_wgrad_kernel<NTW>, dim3(wg.S, wg.c.nchunks), dim3(wg.MT * wg.NG * 64),
                        wgrad_lds_bytes(wg), s, wg, x, dz, part, partb);
     return afd::check_launch("conv_wgrad_kernel");
@@ -1233,6 +1238,8 @@ int launch_wgrad2_t(const Wgrad2Geom& w2, const float* x, const float* dz, float
     }
     const ConvGeom& g = w2.w.c;
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * g.N * g.Cout * (double)g.Hout * g.Wout * g.Cin * g.K * g.K, s);
+    timing.issued(2.0 * g.N * g.CO_PAD * (double)g.Hout * g.Wout * g.Cin * g.K * g.K);
+    timing.bytes(4.0 * g.N * ((double)g.Cin * g.H * g.W + (double)g.Cout * g.Hout * g.Wout));
     hipLaunchKernelGGL(conv_wgrad2_kernel<TPW>, dim3(w2.w.S, g.nchunks), dim3(kW2Threads),
                        ((size_t)2 * w2.bufFloats + (size_t)g.CO_PAD * 16) * 4, s, w2, x, dz, part, partb);
     return afd::check_launch("conv_wgrad2_kernel");

@@ -431,6 +431,8 @@ bool conv1x1_wgrad_applicable(int Cin, int Cout) {
     return a != 3 && b != 3 && a <= 4 && b <= 4;
 }
 
+static double pad32(int c) { return (double)((c + 31) / 32 * 32); }
+
 size_t conv1x1_workspace_bytes(int Cin, int Cout) {
     const size_t ci = (size_t)(Cin + 31) / 32 * 32, co = (size_t)(Cout + 31) / 32 * 32;
     return (size_t)num_cus() * kWgBlocksPerCu * (co * ci + co) * sizeof(float);
@@ -441,6 +443,8 @@ int conv1x1_forward(const float* x, const float* w, const float* bias, float* y,
     G1 g{};
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.HW = (int)HW; g.trans = 0;
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    timing.issued(2.0 * N * pad32(Cout) * (double)HW * Cin);
+    timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
     return run_gemm(g, x, w, bias, y, s);
 }
 
@@ -450,6 +454,8 @@ int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int
     G1 g{};
     g.N = N; g.Cin = Cout; g.Cout = Cin; g.HW = (int)HW; g.trans = 1;
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    timing.issued(2.0 * N * pad32(Cin) * (double)HW * Cout);
+    timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
     return run_gemm(g, dy, w, nullptr, dx, s);
 }
 
@@ -460,6 +466,8 @@ int conv1x1_backward_data_affine(const float* dy, const float* w, const float* r
     G1 g{};
     g.N = N; g.Cin = Cout; g.Cout = Cin; g.HW = (int)HW; g.trans = 1;
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    timing.issued(2.0 * N * pad32(Cin) * (double)HW * Cout);
+    timing.bytes(4.0 * N * (double)HW * (2.0 * Cin + Cout));
     return run_gemm(g, dy, w, beta, dx, s, res, alpha);
 }
 
@@ -469,6 +477,8 @@ int conv1x1_backward_weight(const float* x, const float* dy, float* dw, float* d
         return afd::fail(AFD_ERR_WORKSPACE, "conv1x1 wgrad: workspace too small");
     float* partial = static_cast<float*>(ws);
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD_1X1, 2.0 * N * Cout * (double)HW * Cin, s);
+    timing.issued(2.0 * N * pad32(Cout) * (double)HW * pad32(Cin));
+    timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
     const int cot = (Cout + 31) / 32, cit = (Cin + 31) / 32;
     const int key = (cot == 3 ? 0 : cot) * 10 + (cit == 3 ? 0 : cit);
     switch (key) {

@@ -883,6 +883,9 @@ int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, 
     const long tiles = (long)N * g.tilesY * g.tilesX;
     if (tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad3x3: too many tiles");
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.Hc * g.Wc * Cin * 9, s);
+    // GEMM M = padded Cout, N = the chunk's 9 ci columns (32-wide tiles), K = pixels in 64-pixel tiles
+    timing.issued(2.0 * co_pad * (double)((ncol + 31) / 32 * 32) * g.nchunks * (double)tiles * kWPix);
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.Hc * g.Wc));
     const int mt = co_pad / 32;
     auto run_all = [&](const GW& gg) {
         if (mt == 1) return launchw<1, 32, 3>(gg, x, dz, part, partb, s);          //  9 pairs
@@ -957,6 +960,8 @@ int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int
     int rc = afd::check_launch("repack3_kernel");
     if (rc) return rc;
     afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)g.Hc * g.Wc * Cin * 9, s);
+    timing.issued(2.0 * N * co_pad * (double)g.Hc * g.Wc * Cin * 9);  // lower bound: pixel-tile padding not counted
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.Hc * g.Wc));
     return run3(g, x, wp, bias, y, s);
 }
 

@@ -349,6 +349,8 @@ int launch_wino_t(GW g, const float* x, const float* U, const float* bias, float
     }
     g.wgX = (g.tilesX + kTiles * NT - 1) / (kTiles * NT);
     const long rows = (long)g.N * g.tilesY;
+    // 16 GEMMs [32 MT x Cin] x [Cin x 32 NT tiles] per workgroup, every tile computed in full
+    afd::timing_annotate(2.0 * 16 * (32.0 * MT) * ((double)kTiles * NT * g.wgX) * (double)rows * g.Cin, -1.0);
     const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
     const int edge = g.wgX >= 2 ? 2 : 1;
     if (rows * (inner > edge ? inner : edge) > 0x7fffffffL)
@@ -411,6 +413,7 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     int rc = afd::check_launch("wino_weights_kernel");
     if (rc) return rc;
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols / (u ? 4.0 : 1.0)));
     const bool wide = !getenv("AFD_WINO_NT1");
     switch (MT) {
         case 1: return wide ? launch_wino<1, 2>(g, x, U, bias, y, s) : launch_wino<1, 1>(g, x, U, bias, y, s);

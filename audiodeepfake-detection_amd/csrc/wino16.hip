@@ -255,6 +255,8 @@ template <int CG, int WPE>
 int launch16(GV g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     const long rows = (long)g.N * g.tilesY;
+    // 16 GEMMs [16 CG x Cin] x [Cin x kTiles tiles] per workgroup, every tile computed in full
+    afd::timing_annotate(2.0 * 16 * (16.0 * CG) * ((double)kTiles * g.wgX) * (double)rows * g.Cin, -1.0);
     const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
     const int edge = g.wgX >= 2 ? 2 : 1;
     if (rows * (inner > edge ? inner : edge) > 0x7fffffffL)
@@ -312,6 +314,7 @@ int wino16_run(const float* x, const float* w, const float* bias, float* y, int 
     int rc = afd::check_launch("wino16_weights_kernel");
     if (rc) return rc;
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
     switch (CG) {
         case 2: return launch16<2, 2>(g, x, U, bias, y, s);
         case 4: return launch16<4, 2>(g, x, U, bias, y, s);

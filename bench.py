@@ -1,28 +1,41 @@
 """Headline benchmark: 1 s @ 22 050 Hz frames/s of (wavelet-packet front end + DCNN train step).
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N > 1 launched by
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``, one rank per
-GPU over RCCL).  Rank 0 prints ONE JSON line.
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the driver launches it as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per GPU
+over RCCL); run directly with ``--gpus N`` and no WORLD_SIZE in the environment it starts that same
+launcher itself as a CHILD process, before anything touches the GPU, and relays the child's output
+and exit code.  Rank 0 prints ONE JSON line.
 
-A step is the reference's training step (train_classifier.py:945-995) on one synthetic batch
-that is already resident in HBM: zero_grad -> WPT (+log, +normalise) -> DCNN forward -> cross
-entropy -> backward -> gradient all-reduce (N > 1) -> Adam, plus the per-step loss/accuracy
-read-back the reference performs.  Default workload = BASELINE.json configs[1]:
-packets-coif4 level 14 + DCNN, batch 128 per GPU, fp32.
+A step is the reference's training step (train_classifier.py:945-995) on one synthetic batch that
+is already resident in HBM: zero_grad -> WPT (+log, +normalise) -> DCNN forward -> cross entropy ->
+backward -> gradient all-reduce (N > 1) -> Adam, plus the per-step loss/accuracy read-back the
+reference performs.  Default workload = BASELINE.json configs[1]: packets-coif4 level 14 + DCNN,
+batch 128 per GPU, fp32.  ``--workload haar-l14-frontend`` (BASELINE configs[3], B = 4096) and
+``coif4-l14-frontend`` / ``sym5-l14-frontend`` time the front end alone (a step = one transform of
+the batch); ``stft-lcnn-eval`` is configs[4]'s evaluation forward.
 
 Extra objects on the JSON line:
-  roofline      the kernel class with the largest share of the step, timed live with HIP
-                events on its launch stream (afd_timing_*), algorithmic flops (conv) or bytes
-                (front end) divided by the summed launch durations;
-  cpu_baseline  oracle/torch_ref.py (the reference's algorithm on torch CPU, per-node packet
-                recursion with Welford left on) timed on this host's cores on a bounded sample.
+  roofline      the kernel class with the largest share of the step AS TIMED (backward-weight
+                kernels on their second stream), from HIP events on each launch's own stream.
+                MFMA-bound classes: achieved = flops really issued on the matrix cores (tile padding
+                included, Winograd = its 16 GEMMs) / summed launch time, frac = achieved / 157.3 TF/s;
+                the layer's direct-form flops are reported beside it as algorithmic_TFLOPs.
+                HBM-bound front ends: achieved = algorithmic bytes 4 (N + C P T) per frame / launch
+                time over >= 20 timed launches.  traffic = HBM bytes per step of that class from the
+                committed rocprofv3 --pmc summary (profiles/), algorithmic_bytes beside it.
+  cpu_baseline  oracle/torch_ref.py (the reference's algorithm on torch CPU: per-node packet
+                recursion with Welford left on, full-width DCNN step) timed on this host's cores on a
+                bounded sample of the same workload.
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,31 +48,69 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 METRIC = "1s@22050Hz frames/sec (WPT-coif4 + DCNN train step) at 1/2/4/8 MI355X"
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
+PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured float4 copy)
 
 WORKLOADS = {
-    # name: (transform, wavelet, num_of_scales, time_dim_add, description)
-    "coif4-l14": ("packets", "coif4", 16384, 0, "packets-coif4 level-14 + DCNN train step"),
-    "coif4-l8": ("packets", "coif4", 256, 0, "packets-coif4 level-8 + DCNN train step"),
-    "sym5-l8": ("packets", "sym5", 256, 1, "packets-sym5 level-8 + DCNN train step"),
-    "sym5-l14": ("packets", "sym5", 16384, 0, "packets-sym5 level-14 + DCNN train step"),
-    "stft": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + DCNN train step"),
+    # name: (transform, wavelet, num_of_scales, time_dim_add, kind, description)
+    "coif4-l14": ("packets", "coif4", 16384, 0, "train", "packets-coif4 level-14 + DCNN train step"),
+    "coif4-l8": ("packets", "coif4", 256, 0, "train", "packets-coif4 level-8 + DCNN train step"),
+    "sym5-l8": ("packets", "sym5", 256, 1, "train", "packets-sym5 level-8 + DCNN train step"),
+    "sym5-l14": ("packets", "sym5", 16384, 0, "train", "packets-sym5 level-14 + DCNN train step"),
+    "stft": ("stft", "none", 256, 0, "train", "STFT(n_fft 511, hop 220) + DCNN train step"),
     # BASELINE configs[4]: evaluation (forward + argmax) of the LCNN head on STFT features
-    "stft-lcnn-eval": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + LCNN eval forward (fp32)"),
-    "stft-lcnn": ("stft", "none", 256, 0, "STFT(n_fft 511, hop 220) + LCNN train step (fp32)"),
+    "stft-lcnn-eval": ("stft", "none", 256, 0, "eval", "STFT(n_fft 511, hop 220) + LCNN eval forward (fp32)"),
+    "stft-lcnn": ("stft", "none", 256, 0, "train", "STFT(n_fft 511, hop 220) + LCNN train step (fp32)"),
+    # front end alone (BASELINE configs[3] is the Haar one at B = 4096)
+    "haar-l14-frontend": ("packets", "haar", 16384, 0, "frontend", "packets-haar level-14 front end only"),
+    "coif4-l14-frontend": ("packets", "coif4", 16384, 0, "frontend", "packets-coif4 level-14 front end only"),
+    "sym5-l14-frontend": ("packets", "sym5", 16384, 0, "frontend", "packets-sym5 level-14 front end only"),
+    "coif4-l8-frontend": ("packets", "coif4", 256, 0, "frontend", "packets-coif4 level-8 front end only"),
+}
+DEFAULT_BATCH = {"haar-l14-frontend": 4096}
+MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv_wgrad_1x1", "stft")
+# rocprof kernel names of each timing class (profiles/r*_pmc_traffic.json is keyed by kernel)
+CLASS_KERNELS = {
+    "conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
+    "conv_winograd": ("wino_conv_kernel", "wino16_conv_kernel"),
+    "conv_wgrad": ("wgrad3x3_kernel", "wgrad3x3p_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
+    "conv_wgrad_1x1": ("conv1x1_wgrad_kernel",),
+    "wpt": ("wpt2_deep_mfma_kernel", "wpt2_deep_kernel", "wpt2_top_kernel", "wpt_fused_kernel",
+            "wpt_haar14_kernel", "wpt3_kernel"),
+    "stft": ("stft_mfma_kernel",),
 }
 
 
-def build(workload: str, batch: int, ddp: bool, device):
-    from audiofakedetect import ops
-    from audiofakedetect.models import DCNN
-    from audiofakedetect.train_classifier import Trainer
-    from audiofakedetect.utils import DotDict
-    from audiofakedetect.wavelet_math import get_transforms
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    transform, wavelet, scales, add, _ = WORKLOADS[workload]
-    args = DotDict(
+
+def spawn_ranks(n: int, argv: list) -> int:
+    """Start `n` ranks as a child `torch.distributed.run` and wait for it.
+
+    Called before this process has made any HIP call (torch.cuda.device_count() does not
+    initialise the GPU on this image), so no GPU-holding process is ever replaced; the child's
+    stdout (rank 0's JSON line) and stderr go straight through."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL (see the task notes)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log("spawning: " + " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def make_args(workload: str, batch: int, ddp: bool):
+    from audiofakedetect.utils import DotDict
+
+    transform, wavelet, scales, add = WORKLOADS[workload][:4]
+    return DotDict(
         transform=transform, wavelet=wavelet, num_of_scales=scales, features="none", log_scale=True,
         loss_less="False", power=2.0, hop_length=220, sample_rate=22050, seconds=1, mean=0.0,
         std=1.0, block_norm=False, log_dir="/tmp/afd_bench", data_path=None, only_use=None,
@@ -67,10 +118,24 @@ def build(workload: str, batch: int, ddp: bool, device):
         ochannels5=32, kernel1=3, dropout_cnn=0.6, dropout_lstm=0.2, time_dim_add=add,
         learning_rate=4e-4, weight_decay=1e-3, synthetic=True,
     )
+
+
+def build(workload: str, batch: int, ddp: bool, device):
+    from audiofakedetect import ops
+    from audiofakedetect.models import DCNN
+    from audiofakedetect.train_classifier import Trainer
+    from audiofakedetect.wavelet_math import fuse_normalization, get_transforms
+
+    kind = WORKLOADS[workload][4]
+    scales = WORKLOADS[workload][2]
+    args = make_args(workload, batch, ddp)
     transforms, normalize = get_transforms(args, "none", str(device), False, verbose=False)
     with torch.no_grad():
         probe, _ = transforms(torch.zeros(1, 1, 22050, device=device))
     args.input_dim = [batch] + list(probe.shape[1:])
+    if kind == "frontend":
+        fuse_normalization(transforms, normalize)
+        return args, None, transforms
     # flattened size of the dil_conv output: [time_dim, 64-24=40, P/8-24]
     p8 = args.input_dim[2] // 8
     args.flattend_size = (64 - 24) * (p8 - 24)
@@ -83,7 +148,7 @@ def build(workload: str, batch: int, ddp: bool, device):
     opt = ops.FusedAdam(model.parameters(), lr=args.learning_rate, weight_decay=args.weight_decay)
     trainer = Trainer("/tmp/afd_bench/snap", args, normalize, transforms, None, model, None, None,
                       None, None, opt, ops.CrossEntropyLoss(), None)
-    return args, trainer
+    return args, trainer, transforms
 
 
 def synthetic_batch(batch: int, rank: int, device):
@@ -95,18 +160,31 @@ def synthetic_batch(batch: int, rank: int, device):
     return {"audio": audio.to(device), "label": labels.to(device)}
 
 
-def cpu_baseline(workload: str, frames: int, crop_packets: int = 4096):
-    """The reference's algorithm on torch CPU (oracle 'port'), on a bounded sample.
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
-    Front end: `frames` full frames (per-node pad+conv1d recursion, Welford on, as the
-    reference runs it).  DCNN train step: the same frames; for the level-14 workloads the
-    packet axis is cropped to `crop_packets` of P packets and the time scaled by P/crop (the
-    convolutions are translation invariant along that axis, cost is linear in it) -- one full
-    level-14 frame is 64 GFLOP of fp32 convolutions, minutes of CPU time.
+
+def cpu_baseline(workload: str, frames: int, steps: int = 2):
+    """The reference's algorithm on torch CPU (oracle 'port') on a bounded sample of the workload.
+
+    Front end: `frames` full frames through the per-node pad + conv1d recursion with the per-node
+    Welford updates left on, as the reference runs it (wavelet_math.py:182-206), + log + normalise.
+    Train workloads add the FULL-WIDTH DCNN step (forward, cross entropy, backward, Adam with coupled
+    L2) on those frames: one untimed step, then `steps` timed ones.  BASELINE.md section 3 asks for
+    B = 128 and >= 3 steps; one level-14 frame is 64 GFLOP of fp32 convolutions plus 16 384
+    pad/conv/Welford node updates (~2.5 s per frame on 16 threads), so the sample is cut to
+    `frames` frames to keep the default bench run within minutes -- the figure is frames/s either way.
     """
     from oracle import torch_ref, wpt_oracle
 
-    transform, wavelet, scales, add, _ = WORKLOADS[workload]
+    transform, wavelet, scales, add, kind = WORKLOADS[workload][:5]
     cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(99)
@@ -122,28 +200,91 @@ def cpu_baseline(workload: str, frames: int, crop_packets: int = 4096):
     feats = torch_ref.normalize_torch(feats, 0.0, 1.0)
     t_fe = time.perf_counter() - t0
     log(f"cpu baseline: front end {t_fe:.2f} s for {frames} frames ({cores} threads)")
-    packets = feats.shape[2]
-    crop = packets if packets <= 1024 else crop_packets
-    fc = feats[:, :, :crop, :].contiguous()
-    net = torch_ref.DCNNRef(fc.shape, time_dim_add=add, flattend_size=40 * (crop // 8 - 24))
-    opt = torch.optim.Adam(net.parameters(), lr=4e-4, weight_decay=1e-3)
-    net.train()
-    t1 = time.perf_counter()
-    torch_ref.train_step_torch(net, opt, fc, labels)
-    t_step = (time.perf_counter() - t1) * (packets / crop)
-    total = t_fe + t_step
-    crop_note = "" if crop == packets else f" measured on packets[0:{crop}] of {packets} and scaled x{packets // crop}"
-    return {
-        "value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port",
-        "sample": f"{frames} frame(s) of the same workload, one step: front end {t_fe:.2f} s "
-                  f"(per-node pad+conv1d recursion, Welford on) + DCNN fwd/bwd/Adam {t_step:.2f} s"
-                  f"{crop_note}; torch CPU, {cores} threads",
-    }
+    sample = (f"{frames} frame(s) of the same workload on {cpu_model()}, {cores} torch threads: front end "
+              f"{t_fe:.2f} s (per-node pad+conv1d recursion, Welford on)")
+    total = t_fe
+    if kind == "train" and "lcnn" not in workload:
+        packets = feats.shape[2]
+        net = torch_ref.DCNNRef(feats.shape, time_dim_add=add, flattend_size=40 * (packets // 8 - 24))
+        opt = torch.optim.Adam(net.parameters(), lr=4e-4, weight_decay=1e-3)
+        net.train()
+        fc = feats.contiguous()
+        torch_ref.train_step_torch(net, opt, fc, labels)  # untimed: allocator / oneDNN primitive warm-up
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            torch_ref.train_step_torch(net, opt, fc, labels)
+        t_step = (time.perf_counter() - t1) / steps
+        total += t_step
+        sample += (f" + full-width DCNN forward/backward/Adam {t_step:.2f} s per step "
+                   f"(mean of {steps} timed steps after 1 untimed)")
+    elif kind != "frontend":
+        sample += "; model step not timed on the CPU for this workload"
+    return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
 
 
-def log(msg: str) -> None:
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+def load_pmc(workload: str, batch: int):
+    """Newest committed rocprofv3 --pmc summary for this workload/batch, or None."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                pmc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if pmc.get("workload") == workload and pmc.get("batch") == batch and "steps_in_trace" in pmc:
+            pmc["_path"] = os.path.relpath(path, ROOT)
+            return pmc
+    return None
+
+
+def class_traffic(pmc, cls: str):
+    """HBM bytes per step of one timing class from the PMC summary (fetch corrected per the guide)."""
+    if not pmc:
+        return None
+    tot = 0.0
+    seen = False
+    for nm in CLASS_KERNELS.get(cls, ()):
+        kk = pmc["kernels"].get(nm)
+        if kk:
+            seen = True
+            tot += kk.get("fetch_bytes_total", 0.0) + kk.get("write_bytes_total", 0.0)
+    return tot / pmc["steps_in_trace"] if seen else None
+
+
+def collect(_native) -> dict:
+    out = {}
+    for name in _native.KERNEL_CLASSES:
+        c = _native.timing_collect(name)
+        if c["launches"]:
+            c["avg_ms"] = c["total_ms"] / c["launches"]
+            out[name] = c
+    return out
+
+
+def roofline_of(cls: str, k: dict, steps_timed: int, pmc) -> dict:
+    """The roofline object of one kernel class from its summed launch figures."""
+    sec = k["total_ms"] * 1e-3
+    if cls == "wpt" or (cls == "stft" and not k["issued"]):
+        ach = k["work"] / sec / 1e9
+        r = {"kernel": cls, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+             "frac": ach / PEAK_HBM_GBS}
+        algo_bytes = k["work"] / steps_timed
+    else:
+        ach = k["issued"] / sec / 1e12
+        r = {"kernel": cls, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+             "algorithmic_TFLOPs": k["work"] / sec / 1e12,
+             "note": "achieved = flops issued on the matrix cores (tile padding included; Winograd F(2x2,3x3) "
+                     "= 16 GEMMs per layer) / summed launch time; algorithmic_TFLOPs = the layers' "
+                     "direct-form flops over the same time"}
+        algo_bytes = k["bytes"] / steps_timed
+    r["traffic"] = class_traffic(pmc, cls)
+    r["algorithmic_bytes"] = algo_bytes
+    r["traffic_unit"] = "HBM bytes per step, all launches of the class"
+    if pmc:
+        r["traffic_source"] = pmc["_path"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    r["launches_per_step"] = k["launches"] / steps_timed
+    r["avg_launch_ms"] = k["avg_ms"]
+    return r
 
 
 def main() -> None:
@@ -151,27 +292,36 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=128, help="frames per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default 128; 4096 for haar-l14-frontend)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
     ap.add_argument("--cpu-frames", type=int, default=4, help="CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks through a child torch.distributed.run even for --gpus 1")
     a = ap.parse_args()
+    batch_size = a.batch if a.batch is not None else DEFAULT_BATCH.get(a.workload, 128)
+    kind = WORKLOADS[a.workload][4]
 
     if a.cpu_only:
         print(json.dumps(cpu_baseline(a.workload, max(1, a.cpu_frames))), flush=True)
         return
+    launched = "WORLD_SIZE" in os.environ  # under torch.distributed.run (the driver's N > 1 form)
+    if not launched and (a.gpus > 1 or a.spawn):
+        argv = [x for x in sys.argv[1:] if x != "--spawn"]
+        sys.exit(spawn_ranks(a.gpus, argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if a.gpus > 1 and world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with {a.gpus} ranks (WORLD_SIZE={world})")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    # AFD_FORCE_DDP=1: take the data-parallel path (RCCL process group, replica broadcast, SyncBN and
-    # gradient all-reduce) even with one rank -- lets a 1-GPU box exercise the collectives
-    ddp = world > 1 or bool(os.environ.get("AFD_FORCE_DDP"))
+    # a process group whenever the ranks come from the launcher (also for one rank: the RCCL path --
+    # replica broadcast, SyncBN statistics, gradient all-reduce -- is then what runs); AFD_FORCE_DDP=1
+    # does the same for a plain single-process run
+    ddp = launched or bool(os.environ.get("AFD_FORCE_DDP"))
     if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -184,35 +334,39 @@ def main() -> None:
 
     _native.load()
     torch.manual_seed(0)
-    args, trainer = build(a.workload, a.batch, ddp, device)
-    batch = synthetic_batch(a.batch, rank, device)
-    trainer.model.train()
+    args, trainer, transforms = build(a.workload, batch_size, ddp, device)
+    batch = synthetic_batch(batch_size, rank, device)
+    if trainer is not None:
+        trainer.model.train()
 
     def sync():
         if ddp:
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
-    log(f"built {a.workload}: features {args.input_dim}, batch/GPU {a.batch}, world {world}")
-    eval_only = a.workload.endswith("eval")
+    log(f"built {a.workload}: features {args.input_dim}, batch/GPU {batch_size}, world {world}")
     correct = torch.zeros((), dtype=torch.float64, device=device)
 
     def step():
-        if not eval_only:
+        if kind == "train":
             trainer._run_batch(0, batch)
-            return
-        # evaluation step (reference val_test_loop, train_classifier.py:365-497): features,
-        # forward, argmax, compare with the binarised label; counts stay on the device
-        with torch.no_grad():
-            out = trainer.model(trainer._features(batch["audio"]))
-            correct.add_((out.argmax(-1) == (batch["label"] != 0)).sum())
+        elif kind == "eval":
+            # evaluation step (reference val_test_loop, train_classifier.py:365-497): features,
+            # forward, argmax, compare with the binarised label; counts stay on the device
+            with torch.no_grad():
+                out = trainer.model(trainer._features(batch["audio"]))
+                correct.add_((out.argmax(-1) == (batch["label"] != 0)).sum())
+        else:
+            with torch.no_grad():
+                transforms(batch["audio"])
 
-    if eval_only:
+    if kind == "eval":
         trainer.model.eval()
     for i in range(a.warmup):
         step()
         torch.cuda.synchronize()
-        log(f"warmup step {i} done")
+        if kind != "frontend":
+            log(f"warmup step {i} done")
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -223,24 +377,25 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+    step_ms = 1e3 * elapsed / a.steps
+    log(f"timed {a.steps} steps: {step_ms:.3f} ms/step")
 
-    log(f"timed {a.steps} steps: {1e3 * elapsed / a.steps:.2f} ms/step")
-    # ---- per-kernel-class timing of one more step (HIP events on the launch stream) ----
-    kernels = {}
+    # ---- per-kernel-class timing (HIP events on each launch's own stream), after the timed region:
+    # the step as it is timed above (one step; >= 20 for the front-end workloads, whose class is one
+    # or two launches per step)
+    timed_steps = max(20, a.steps) if kind == "frontend" else 1
     _native.timing_reset()
     _native.timing_enable(True)
-    step()
+    for _ in range(timed_steps):
+        step()
     torch.cuda.synchronize()
     _native.timing_enable(False)
-    for name in ("wpt", "conv_igemm", "conv_wgrad", "stft", "conv_direct", "conv_winograd", "conv_wgrad_1x1"):
-        ms, n, work = _native.timing_collect(name)
-        if n:
-            kernels[name] = {"launches": n, "total_ms": ms, "avg_ms": ms / n, "work": work}
+    kernels = collect(_native)
     _native.timing_reset()
-    # the same once more with the backward-weight kernels on the main stream: launch durations
-    # without another stream's kernels sharing the CUs (reported as roofline["serial"])
+    # the same step once more with the backward-weight kernels on the main stream: each kernel's own
+    # time, with no other stream's kernels sharing the CUs (reported as roofline["serial"])
     serial = {}
-    if not eval_only:
+    if kind == "train":
         prev = os.environ.get("AFD_WGRAD_STREAM")
         os.environ["AFD_WGRAD_STREAM"] = "0"
         try:
@@ -248,103 +403,88 @@ def main() -> None:
             step()
             torch.cuda.synchronize()
             _native.timing_enable(False)
-            for name in kernels:
-                ms, n, work = _native.timing_collect(name)
-                if n:
-                    serial[name] = {"launches": n, "total_ms": ms, "avg_ms": ms / n, "work": work}
+            serial = collect(_native)
         finally:
             _native.timing_reset()
             if prev is None:
                 os.environ.pop("AFD_WGRAD_STREAM", None)
             else:
                 os.environ["AFD_WGRAD_STREAM"] = prev
-    step_ms = 1e3 * elapsed / a.steps
+
+    pmc = load_pmc(a.workload, batch_size)
     roofline = None
     if kernels:
-        # the roofline object is about an HBM- or MFMA-bound class (conv_direct is VALU work)
-        # launch durations of the pass without a second stream (a kernel's own time) where there
-        # is one; the two-stream step's figures go into roofline["two_streams"]
-        own = serial if serial else kernels
-        dom = max((k for k in own if k != "conv_direct"), key=lambda k: own[k]["total_ms"])
-        k = own[dom]
-        if dom in ("wpt", "stft"):
-            ach = k["work"] / (k["total_ms"] * 1e-3) / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        cand = [k for k in kernels if k == "wpt" or k in MFMA_CLASSES]
+        if kind == "frontend":
+            cand = [k for k in cand if k in ("wpt", "stft")]
+        dom = max(cand, key=lambda k: kernels[k]["total_ms"])
+        roofline = roofline_of(dom, kernels[dom], timed_steps, pmc)
+        roofline["share_of_step"] = kernels[dom]["total_ms"] / timed_steps / step_ms
+        roofline["timing"] = (f"HIP events around every launch of the class in {timed_steps} step(s) run as the "
+                              "timed steps are (backward-weight kernels on their second stream)")
+        if dom in serial:
+            s = roofline_of(dom, serial[dom], 1, None)
+            roofline["serial"] = {"achieved": s["achieved"], "frac": s["frac"], "avg_launch_ms": s["avg_launch_ms"],
+                                  "note": "the same launches with AFD_WGRAD_STREAM=0: no second stream's kernels "
+                                          "share the CUs (a kernel's own time)"}
+    classes = {}
+    for name, k in kernels.items():
+        c = {"launches_per_step": k["launches"] / timed_steps, "ms_per_step": k["total_ms"] / timed_steps,
+             "algorithmic_bytes_per_step": (k["work"] if name in ("wpt", "stft") and not k["bytes"] else k["bytes"]) / timed_steps,
+             "hbm_bytes_per_step_pmc": class_traffic(pmc, name)}
+        if k["issued"]:
+            c["issued_TFLOPs"] = k["issued"] / (k["total_ms"] * 1e-3) / 1e12
+            c["algorithmic_TFLOPs"] = k["work"] / (k["total_ms"] * 1e-3) / 1e12
+            c["mfma_frac"] = c["issued_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
         else:
-            ach = k["work"] / (k["total_ms"] * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": ach,
-                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None}
-            if dom == "conv_winograd":
-                # `achieved` counts the layer's direct-form flops (the algorithmic figure of the
-                # contract); the F(2x2,3x3) kernel issues 16 of every 36 of them on the matrix cores
-                roofline["mfma_issued"] = ach * 16.0 / 36.0
-                roofline["mfma_issued_frac"] = ach * 16.0 / 36.0 / PEAK_F32_MFMA_TFLOPS
-                roofline["note"] = ("achieved = direct-form flops / time; Winograd F(2x2,3x3) issues 16/36 "
-                                    "of them as exact-fp32 MFMAs (mfma_issued*)")
-        # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process):
-        # read back from the committed counter summary when it covers this workload
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                pmc = json.load(fh)
-            if pmc.get("workload") == a.workload and pmc.get("batch") == a.batch:
-                # the class's launches are spread over these kernels: launch-weighted mean
-                names = {"conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
-                         "conv_winograd": ("wino_conv_kernel", "wino16_conv_kernel"),
-                         "conv_wgrad": ("wgrad3x3_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
-                         "conv_wgrad_1x1": ("conv1x1_wgrad_kernel",),
-                         "wpt": ("wpt2_deep_kernel", "wpt2_top_kernel"), "stft": ("stft_mfma_kernel",)}[dom]
-                tot = cnt = 0.0
-                for nm in names:
-                    kk = pmc["kernels"].get(nm)
-                    if kk:
-                        tot += (kk.get("fetch_bytes_per_launch", 0.0) + kk.get("write_bytes_per_launch", 0.0)) * kk["launches_in_trace"]
-                        cnt += kk["launches_in_trace"]
-                if cnt:
-                    roofline["traffic"] = tot / cnt
-                    roofline["traffic_source"] = ("profiles/r01_pmc_traffic.json (FETCH_SIZE x2 for dwordx4 readers "
-                                                  "+ WRITE_SIZE, launch-weighted over the class's kernels)")
-        except (OSError, ValueError, KeyError):
-            pass
-        if serial and dom in kernels:
-            ko = kernels[dom]
-            div = 1e9 if dom in ("wpt", "stft") else 1e12
-            oa = ko["work"] / (ko["total_ms"] * 1e-3) / div
-            roofline["timing"] = ("launch durations from a step with the backward-weight stream off "
-                                  "(AFD_WGRAD_STREAM=0): no other stream's kernels share the CUs")
-            roofline["two_streams"] = {"achieved": oa, "frac": oa / roofline["peak"], "avg_launch_ms": ko["avg_ms"],
-                                       "note": "the same launches inside the normal step, where backward-weight "
-                                               "kernels run on a second stream next to the main stream's kernels"}
-        roofline["launches_per_step"] = k["launches"]
-        roofline["avg_launch_ms"] = k["avg_ms"]
-        roofline["share_of_step"] = k["total_ms"] / step_ms
+            c["achieved_GBps"] = c["algorithmic_bytes_per_step"] / (c["ms_per_step"] * 1e-3) / 1e9 if c["ms_per_step"] else None
+        if name in serial:
+            c["ms_per_step_serial"] = serial[name]["total_ms"]
+            if serial[name]["issued"]:
+                c["mfma_frac_serial"] = serial[name]["issued"] / (serial[name]["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
+        classes[name] = c
     frontend = None
     if "wpt" in kernels:
         k = kernels["wpt"]
         gbs = k["work"] / (k["total_ms"] * 1e-3) / 1e9
-        frontend = {"kernel": "wpt", "avg_launch_ms": k["avg_ms"], "achieved_GBps": gbs,
-                    "frac_of_hbm_peak": gbs / PEAK_HBM_GBS}
+        frontend = {"kernel": "wpt", "launches_timed": k["launches"], "ms_per_step": k["total_ms"] / timed_steps,
+                    "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_frame": k["work"] / timed_steps / batch_size,
+                    "hbm_bytes_per_step_pmc": class_traffic(pmc, "wpt")}
 
     cpu = None
-    log(f"kernel classes: { {k: round(v['total_ms'], 3) for k, v in kernels.items()} }")
-    if rank == 0 and world == 1 and a.cpu_frames > 0 and not eval_only:
+    log(f"kernel classes (ms/step): { {k: round(v['ms_per_step'], 3) for k, v in classes.items()} }")
+    if rank == 0 and world == 1 and a.cpu_frames > 0 and kind != "eval":
         cpu = cpu_baseline(a.workload, a.cpu_frames)
         log(f"cpu baseline: {cpu['value']:.4f} frames/s")
 
+    devices = [torch.cuda.get_device_name(device)]
+    rccl = None
+    if ddp:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank {rank}: cuda:{local_rank} {devices[0]}")
+        devices = gathered
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001 - version query only
+            rccl = "unknown"
     if rank == 0:
-        loss = trainer.loss_list[-1][2] if trainer.loss_list else None
+        loss = trainer.loss_list[-1][2] if (trainer is not None and trainer.loss_list) else None
         line = {
-            "metric": METRIC, "value": world * a.batch * a.steps / elapsed, "unit": "frames/s",
+            "metric": METRIC, "value": world * batch_size * a.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": WORKLOADS[a.workload][4], "batch_per_gpu": a.batch,
-                       "global_batch": a.batch * world, "frame": "1s@22050Hz mono f32",
-                       "features": list(args.input_dim[1:]), "flattend_size": args.flattend_size,
-                       "optimizer": "Adam lr 4e-4 wd 1e-3", "parallelism": f"dp{world}"},
+            "config": {"workload": WORKLOADS[a.workload][5], "batch_per_gpu": batch_size,
+                       "global_batch": batch_size * world, "frame": "1s@22050Hz mono f32",
+                       "features": list(args.input_dim[1:]), "flattend_size": args.get("flattend_size"),
+                       "optimizer": "Adam lr 4e-4 wd 1e-3" if kind == "train" else None,
+                       "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend,
-            "kernels": kernels, "kernels_serial": serial, "last_loss": loss,
+            "world": {"size": world, "backend": "rccl (torch.distributed nccl)" if ddp else None,
+                      "rccl_version": rccl, "devices": devices,
+                      "collectives": "gradient arena all-reduce + packed SyncBN statistics" if ddp and kind == "train" else None},
+            "classes": classes, "last_loss": loss,
         }
         print(json.dumps(line), flush=True)
     if ddp:

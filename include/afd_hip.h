@@ -36,9 +36,11 @@ const char* afd_last_error(void);
 int afd_version(void);
 
 /* Optional measurement hook (bench.py): when enabled, every launch of the kernel classes
- * below is bracketed by HIP events on its own stream; afd_timing_collect sums the durations,
- * launch count and algorithmic work (bytes for AFD_K_WPT / AFD_K_STFT, flops for the conv
- * classes) recorded since the last afd_timing_reset. */
+ * below is bracketed by HIP events on its own stream; afd_timing_collect sums, over the launches
+ * recorded since the last afd_timing_reset: the durations, the launch count, the algorithmic work
+ * (bytes for AFD_K_WPT / AFD_K_STFT, direct-form flops for the conv classes), the flops really
+ * issued on the matrix cores (tile padding included; Winograd: its 16 GEMMs; 0 for kernels without
+ * MFMAs) and the algorithmic bytes (every input and output tensor of the launch once). */
 #define AFD_K_WPT 0
 #define AFD_K_CONV_IGEMM 1 /* forward and backward-data launches of the implicit-GEMM kernel */
 #define AFD_K_CONV_WGRAD 2
@@ -48,7 +50,8 @@ int afd_version(void);
 #define AFD_K_CONV_WINOGRAD 5 /* 3x3 forward / backward-data launches on the Winograd F(2x2,3x3) kernel:
                                   work = direct-form flops, of which the kernel issues 16/36 as MFMAs */
 int afd_timing_enable(int on);
-int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work);
+int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work,
+                       double* total_issued_flops, double* total_algorithmic_bytes);
 int afd_timing_reset(void);
 
 /* ------------------------------------------------------------------------------------

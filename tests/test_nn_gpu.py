@@ -407,13 +407,18 @@ def test_winograd_class_is_what_runs():
     try:
         ops.conv2d(x, wt, None, 1, 1)
         torch.cuda.synchronize()
-        _, n_w, work = _native.timing_collect("conv_winograd")
-        _, n_d, _ = _native.timing_collect("conv_igemm")
+        cw = _native.timing_collect("conv_winograd")
+        n_w, work = cw["launches"], cw["work"]
+        n_d = _native.timing_collect("conv_igemm")["launches"]
     finally:
         _native.timing_enable(False)
         _native.timing_reset()
     assert n_w == 1 and n_d == 0
     assert work == 2.0 * 96 * 6 * 260 * 64 * 9
+    # issued on the matrix cores: 16 GEMMs of [96 x 64] x [64 x tiles], tiles padded to the workgroup's
+    # 64 (3 tile rows x 130 tiles -> 3 x 192), against 36/16 more in direct form
+    assert cw["issued"] == 2.0 * 16 * 96 * 64 * 3 * 192
+    assert cw["bytes"] == 4.0 * (64 + 96) * 6 * 260
 
 
 @pytest.mark.parametrize("shape", [(1, 64, 7, 1027, 96), (2, 32, 6, 1100, 64), (2, 64, 13, 257, 96)])
