@@ -37,6 +37,7 @@ constexpr int kTopThreads = 1024;
 constexpr int kDeepThreads = 256;
 constexpr int kTopLdsFloats = 40000;
 constexpr int kKsMax = 8;
+constexpr int kMinOut = 6;  // outputs per work unit, at least
 
 struct W2Params {
     const float* x;
@@ -169,6 +170,8 @@ struct Steps {
                                                int ps, int i, int i0, int i1, int q, int F,
                                                f2 (&w)[(L + 2 * kAhead) / 2]) {
         constexpr int W = L + 2 * kAhead;
+        // units are whole or half blocks of W/2 outputs: a unit that ends here skips the second half
+        if ((W / 2) % 2 == 0 && ST == W / 4 && i + ST >= i1) return;
         const f2 acc = window_dot<L, ST>(p, w);
         if (i + ST < i1) emit(p, s, mode, i + ST, q, 2 * M, F, acc);
         const int pn = ps + 2 * (i + ST - i0) + W;  // absolute position of the refill
@@ -304,13 +307,12 @@ __device__ __forceinline__ void level_units(const W2Params& p, const Sink& s, in
     const int nthreads = blockDim.x;
     int C = nthreads >> logM;  // chunks per parent so that every thread has a unit
     if (C < 1) C = 1;
-    const int maxC = (n_out + 7) >> 3;  // at least 8 outputs per unit (window fill amortised)
+    constexpr int blk = (L + 2 * kAhead) / 2;  // outputs come in blocks of W/2 (or half blocks)
+    constexpr int unit = (blk % 2 == 0 && blk >= 8) ? blk / 2 : blk;
+    const int maxC = (n_out + kMinOut - 1) / kMinOut;  // at least kMinOut outputs per unit (window fill amortised)
     if (C > maxC) C = maxC;
     int len = (n_out + C - 1) / C;
-    {
-        constexpr int blk = (L + 2 * kAhead) / 2;  // outputs come in blocks of W/2
-        len = ((len + blk - 1) / blk) * blk;
-    }
+    len = ((len + unit - 1) / unit) * unit;
     const int units = C << logM;
     for (int u = threadIdx.x; u < units; u += nthreads) {
         const int c = u >> logM;
