@@ -332,6 +332,9 @@ bool wpt2_preferred(int L, int level);
 int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
                  int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
                  float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
+                 int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
+                 float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 }  // namespace afd
 
 extern "C" size_t afd_wpt_workspace_bytes(int B, int N, int L, int level) {
@@ -359,6 +362,13 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
         const int rch = afd::wpt_haar14_forward(x, B, N, dec_lo, L, level, flags, power, eps, mean, std,
                                                 sign_mean, sign_std, out, static_cast<hipStream_t>(stream));
         if (rch != 1) return rch;
+    }
+    // third generation (wpt3.hip): padded-node vector kernel for levels <= 8, matrix-core composite for the
+    // level-14 transforms of 1 s frames; 1 = not its case
+    {
+        const int rc3 = afd::wpt3_forward(x, B, N, dec_lo, dec_hi, L, level, flags, power, eps, mean, std,
+                                          sign_mean, sign_std, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
+        if (rc3 != 1) return rc3;
     }
     // Which generation: wpt2.hip (register window + packed FMAs, level-1 subtree per workgroup, MFMA
     // deep levels) for every level >= 11 and, up to level 10, for the long and the 2-tap filters
