@@ -52,15 +52,27 @@ __device__ __noinline__ float pow_log_slow3(float v, float power, float eps) {
     return logf(powf(fabsf(v), power) + eps);
 }
 
-// log(|v|^power + eps) and (x - mean) / std.  power == 2: v*v + eps >= 1e-12 is a normal float, the bare
-// v_log_f32 (log2, ~1 ulp) needs no denormal pre-scaling; ln 2, 1/std and -mean/std are folded into one FMA.
+// log(|v|^power + eps) and (x - mean) / std.  The kernels are compiled per epilogue mode, so that an
+// element costs three vector instructions and no branch (the f32 matrix instructions and the vector ALU
+// share the SIMD's FMA lanes: every vector instruction is time the matrix stream does not get):
+//   EPI_RAW   v * k1 + k0                      (k1 = 1/std, k0 = -mean/std; 1, 0 without AFD_WPT_NORM)
+//   EPI_LOG2  log2(v*v + eps) * k1 + k0        (power == 2: v*v + eps >= 1e-12 is a normal float, the bare
+//             v_log_f32 needs no denormal pre-scaling; k1 = ln 2 / std)
+//   EPI_SLOW  any other power, library pow / log
+enum { EPI_RAW = 0, EPI_LOG2 = 1, EPI_SLOW = 2 };
+
+template <int MODE>
 __device__ __forceinline__ float epi_value(float v, const Epi& e) {
-    if (e.flags & AFD_WPT_LOG) {
-        if (e.power == 2.0f) return fmaf(__builtin_amdgcn_logf(fmaf(v, v, e.eps)), e.k1, e.k0);
-        v = pow_log_slow3(v, e.power, e.eps);
-    }
+    if (MODE == EPI_RAW) return fmaf(v, e.k1, e.k0);
+    if (MODE == EPI_LOG2) return fmaf(__builtin_amdgcn_logf(fmaf(v, v, e.eps)), e.k1, e.k0);
+    v = pow_log_slow3(v, e.power, e.eps);
     if (e.flags & AFD_WPT_NORM) v = (v - e.mean) * e.inv_std;
     return v;
+}
+
+inline int epi_mode(unsigned flags, float power) {
+    if (!(flags & AFD_WPT_LOG)) return EPI_RAW;
+    return power == 2.0f ? EPI_LOG2 : EPI_SLOW;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -69,7 +81,7 @@ __device__ __forceinline__ float epi_value(float v, const Epi& e) {
 struct T3Params {
     const float* x;
     float* dst;  // features (final) or the level-Ks hand-off image
-    int B, N, Ks, final_;
+    int B, N, Ks;
     int n[kKsMax + 1];
     int off[kKsMax + 1];    // LDS offset (floats) of level k's image; sample 0 of node 0 at off + L - 2
     int pitch[kKsMax + 1];  // node pitch (floats): even, pitch / 2 odd
@@ -116,7 +128,8 @@ __device__ __forceinline__ float dot_one(const T3Params& p, const float* __restr
     return acc.x + acc.y;
 }
 
-template <int L>
+// FIN: -1 = the level-Ks image is a hand-off to the deep kernel (no epilogue), else the epilogue mode
+template <int L, int FIN>
 __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PAD = L - 2;
@@ -177,6 +190,7 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         float* dst0 = lds + p.off[k] + PAD;
         const int pin = p.pitch[k - 1], pout = p.pitch[k];
         const unsigned magic = p.magic[k];
+        const int padr = PAD + (nk & 1);
         for (int idx = tid; idx < total; idx += kTopThreads) {
             const int q = (int)__umulhi((unsigned)idx, magic);
             const int i = idx - q * nk;
@@ -184,8 +198,19 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
             dot_both<L>(p, src0 + q * pin + 2 * i, ca, cd);
             // odd-frequency parents list their children (d, a)
             const int par = (k == 2) ? h : (q & 1);
-            put<L>(dst0 + (2 * q + par) * pout, i, nk, ca);
-            put<L>(dst0 + (2 * q + 1 - par) * pout, i, nk, cd);
+            float* na = dst0 + (2 * q + par) * pout;
+            float* nd = dst0 + (2 * q + 1 - par) * pout;
+            na[i] = ca;
+            nd[i] = cd;
+            // the L-2 coefficients next to a border also fill the pad slots that mirror them
+            if ((unsigned)(i - 1) < (unsigned)PAD) {
+                na[-i] = ca;
+                nd[-i] = cd;
+            }
+            if ((unsigned)(nk - 2 - i) < (unsigned)padr) {
+                na[2 * (nk - 1) - i] = ca;
+                nd[2 * (nk - 1) - i] = cd;
+            }
         }
         __syncthreads();
     }
@@ -201,7 +226,7 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         const int pin = p.pitch[k - 1];
         const size_t P = (size_t)1 << k;
         const size_t chan = (size_t)nk * P;
-        const int nch = (p.final_ && (p.e.flags & AFD_WPT_SIGN)) ? 2 : 1;
+        const int nch = (FIN >= 0 && (p.e.flags & AFD_WPT_SIGN)) ? 2 : 1;
         float* outb = p.dst + (size_t)b * nch * chan;
         for (int idx = tid; idx < total; idx += kTopThreads) {
             const int q = idx & (Mp - 1);
@@ -213,12 +238,12 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
             v.x = par ? cd : ca;
             v.y = par ? ca : cd;
             const size_t o = (size_t)i * P + 2 * ((size_t)(h << logM) + q);
-            if (!p.final_) {
+            if (FIN < 0) {
                 *reinterpret_cast<f2*>(outb + o) = v;
             } else {
                 f2 r;
-                r.x = epi_value(v.x, p.e);
-                r.y = epi_value(v.y, p.e);
+                r.x = epi_value<(FIN < 0 ? 0 : FIN)>(v.x, p.e);
+                r.y = epi_value<(FIN < 0 ? 0 : FIN)>(v.y, p.e);
                 *reinterpret_cast<f2*>(outb + o) = r;
                 if (p.e.flags & AFD_WPT_SIGN) {
                     f2 sg;
@@ -293,62 +318,77 @@ template <class SH> struct Deep3 {
     static constexpr int R8 = 2 * P1::KS, R9 = 2 * P2::KS, R10 = 2 * KS3;
     static constexpr int A_FLOATS = (R8 * 32 > R10 * 128) ? R8 * 32 : R10 * 128;
     static constexpr int B_FLOATS = R9 * 64;
+    // fragment tables: four k-steps of a lane are one 16-byte element and the 64 lanes of a load are
+    // consecutive (1 KB per load instruction).  Inside a stream of f32 matrix instructions a vector-memory
+    // instruction costs by the cache lines it touches, not by its bytes (measured, tools/micro): the same
+    // 4 KB per wave cost 1 345 cycles as lane-strided 16-byte pieces and 231 as whole lines
+    static constexpr int pad4(int v) { return (v + 3) / 4 * 4; }
+    static constexpr int KP1 = pad4(P1::KSB), KP2 = pad4(P2::KSB), KP3 = pad4(KS3);
     static constexpr int off1 = 0;
-    static constexpr int off2 = off1 + P1::T * P1::KSB * 64;
-    static constexpr int off3 = off2 + P2::T * P2::KSB * 64;
-    static constexpr int tab_floats = off3 + T3 * KS3 * 64;
+    static constexpr int off2 = off1 + P1::T * KP1 * 64;
+    static constexpr int off3 = off2 + P2::T * KP2 * 64;
+    static constexpr int tab_floats = off3 + T3 * KP3 * 64;
 };
 
 struct D3Params {
     const float* ws;
     const float* tab;
     float* out;
+    int groups;  // B * 8 work items (frame, 32 level-8 nodes)
     short kst1[kDeepWaves], kst2[kDeepWaves];
     Epi e;
 };
 
 // stepwise level for one wave: row tile mt of A (fragments a[]) times the 32 columns [32 nt, 32 nt + 32) of
-// src (row stride 1 << LOGS); children written position-major to dst (row stride 1 << LOGD)
-template <class LV, int LOGS, int LOGD>
-__device__ __forceinline__ void step_tile(const float (&a)[LV::KSB], int mt, int kst, int nt,
+// src (row stride 1 << LOGS); children written position-major to dst (row stride 1 << LOGD).  The B
+// fragments are all requested before the first matrix instruction (one LDS round trip per tile).
+template <class LV, int KP, int LOGS, int LOGD>
+__device__ __forceinline__ void step_tile(const float (&a)[KP], int mt, int kst, int nt,
                                           const float* __restrict__ src, float* __restrict__ dst, int lane) {
     constexpr int S = 1 << LOGS;
     const int half = lane >> 5, col = lane & 31;
     const float* bp = src + ((size_t)kst * 2 + half) * S + nt * 32 + col;
+    float bv[LV::KSB];
+#pragma unroll
+    for (int st = 0; st < LV::KSB; ++st) bv[st] = bp[st * 2 * S];
     f16v acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int st = 0; st < LV::KSB; ++st)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], bp[st * 2 * S], acc, 0, 0, 0);
+    for (int st = 0; st < LV::KSB; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], bv[st], acc, 0, 0, 0);
     // D: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); rows (2i, 2i+1) = (cA[i], cD[i])
     const int n = nt * 32 + col;
-    int i0 = mt * 16 + half * 2;
-    asm volatile("" : "+v"(i0));
+    const int i0 = mt * 16 + half * 2;
+    const bool odd = col & 1;  // odd-frequency parents list their children (d, a)
+    float* dp = dst + ((size_t)i0 << LOGD) + 2 * n;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const int i = i0 + (r >> 2) * 4 + ((r & 3) >> 1);
-        if (i < LV::n_out) {
-            // odd-frequency parents list their children (d, a); values pinned so that the select is
-            // not turned into a dynamic vector index
-            float e0 = acc[r], e1 = acc[r + 1];
-            asm volatile("" : "+v"(e0), "+v"(e1));
-            f2 v;
-            v.x = (col & 1) ? e1 : e0;
-            v.y = (col & 1) ? e0 : e1;
-            *reinterpret_cast<f2*>(dst + ((size_t)i << LOGD) + 2 * n) = v;
-        }
+        const int di = (r >> 2) * 4 + ((r & 3) >> 1);  // i - i0: compile-time
+        float e0 = acc[r], e1 = acc[r + 1];
+        asm volatile("" : "+v"(e0), "+v"(e1));  // pinned: the select must not become a dynamic vector index
+        f2 v;
+        v.x = odd ? e1 : e0;
+        v.y = odd ? e0 : e1;
+        if (i0 + di < LV::n_out) *reinterpret_cast<f2*>(dp + ((size_t)di << LOGD)) = v;
     }
 }
 
-template <int KS>
-__device__ __forceinline__ void load_frags(float (&a)[KS], const float* tab, int mt, int lane) {
-    const float* t = tab + (size_t)mt * KS * 64 + lane;
+// fragments of row tile mt: KP floats per lane, KP % 4 == 0; table [mt][KP / 4][lane][4]
+template <int KP>
+__device__ __forceinline__ void load_frags(float (&a)[KP], const float* tab, int mt, int lane) {
+    const f4* t = reinterpret_cast<const f4*>(tab) + (size_t)mt * (KP / 4) * 64 + lane;
 #pragma unroll
-    for (int st = 0; st < KS; ++st) a[st] = t[st * 64];
+    for (int j = 0; j < KP / 4; ++j) {
+        const f4 v = t[j * 64];
+        a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w;
+    }
 }
 
-template <class SH>
+// Persistent workgroups (two per CU): each walks the (frame, group of 32 level-8 nodes) items with a
+// stride of the grid.  The fragments of the two stepwise phases stay in registers for the whole kernel,
+// the next item's level-8 nodes travel from the hand-off image into registers while the current item is
+// in the composite phase.
+template <class SH, int MODE, bool SIGN>
 __global__ void __launch_bounds__(kDeepThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 wpt3_deep_kernel(const D3Params p) {
     using D = Deep3<SH>;
@@ -359,102 +399,110 @@ wpt3_deep_kernel(const D3Params p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int groups = 256 / kGroup;
-    const int b = blockIdx.x / groups;
-    const int grp = blockIdx.x - b * groups;
+    constexpr int n8 = SH::n[0];
+    constexpr int NLD = (n8 * kGroup + kDeepThreads - 1) / kDeepThreads;  // hand-off floats per thread
+    static_assert(NLD * kDeepThreads >= D::R8 * kGroup, "the zero row of the level-8 image comes with the load");
+    static_assert(D::R9 == SH::n[1] && D::R10 == SH::n[2], "even node lengths at levels 9 and 10: no pad rows");
     float* XA = lds;
     float* XB = lds + D::A_FLOATS;
-    // rows past a node's length meet zero matrix columns but must hold finite numbers
-    for (int e = tid; e < D::A_FLOATS + D::B_FLOATS; e += kDeepThreads) lds[e] = 0.f;
-    // fragments of the first phase are on their way while the level-8 nodes arrive
-    float a1[P1::KSB];
+
+    int item = blockIdx.x;
+    if (item >= p.groups) return;
+    float xr[NLD];
+#define AFD_FETCH_X8(it)                                                                      \
+    {                                                                                         \
+        const int fb = (it) / groups, fg = (it) - fb * groups;                                \
+        const float* wsb = p.ws + (size_t)fb * n8 * 256 + fg * kGroup;                        \
+        _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                     \
+            const int e = u * kDeepThreads + tid;                                             \
+            xr[u] = e < n8 * kGroup ? wsb[(size_t)(e >> 5) * 256 + (e & 31)] : 0.f;           \
+        }                                                                                     \
+    }
+    AFD_FETCH_X8(item);
     const int mt1 = wave < P1::T ? wave : 0;
-    load_frags<P1::KSB>(a1, p.tab + D::off1, mt1, lane);
-    __syncthreads();
-    {
-        constexpr int n8 = SH::n[0];
-        const float* wsb = p.ws + (size_t)b * n8 * 256 + grp * kGroup;
-        for (int e = tid; e < n8 * kGroup; e += kDeepThreads) {
-            const int pos = e >> 5, j = e & 31;
-            XA[e] = wsb[(size_t)pos * 256 + j];
-        }
-    }
-    float a2[P2::KSB];
     const int mt2 = wave % P2::T;
-    load_frags<P2::KSB>(a2, p.tab + D::off2, mt2, lane);
-    __syncthreads();
-    // 8 -> 9: one row tile per wave, 32 columns -> 64
-    if (wave < P1::T) step_tile<P1, 5, 6>(a1, mt1, p.kst1[mt1], 0, XA, XB, lane);
-    __syncthreads();
-    // X8 is dead: clear what the level-10 image leaves untouched but the composite's k-loop reads
-    if (D::R10 > SH::n[2]) {
-        for (int e = tid; e < 128; e += kDeepThreads) XA[(D::R10 - 1) * 128 + e] = 0.f;
-    }
-    // 9 -> 10: (row tile, column tile) per wave, 64 columns -> 128
-    if (wave < 2 * P2::T) step_tile<P2, 6, 7>(a2, mt2, p.kst2[mt2], wave / P2::T, XB, XA, lane);
-    __syncthreads();
-    // 10 -> 14: wave = (column tile, half of the composite's row tiles); B fragments stay in registers
-    {
-        constexpr int KS3 = D::KS3, T3 = D::T3, TH = (T3 + 1) / 2;
-        const int ct = wave & 3, part = wave >> 2;
-        const int half = lane >> 5, col = lane & 31;
+    const int kst1 = p.kst1[mt1], kst2 = p.kst2[mt2];
+
+    // composite phase: wave = (half of the row tiles, 32 consecutive level-10 columns).  The node image is
+    // the A operand and the matrix fragment the B operand, i.e. the wave computes the TRANSPOSED tile
+    // D[node][row]: a lane then owns one composite row (time, packet offset) and its 16 registers are 16
+    // nodes, so one store instruction writes, for a fixed register, 16 consecutive packets of a node from
+    // 16 consecutive lanes -- whole 64-byte lines (four per instruction) instead of 64 quarter lines.
+    constexpr int KS3 = D::KS3, T3 = D::T3, TH = (T3 + 1) / 2;
+    const int part = wave >> 2, ct = wave & 3;
+    const int half = lane >> 5, col = lane & 31;
+    const int rt0 = part * TH;
+    const size_t P = 16384;
+    const size_t chan = (size_t)D::n14 * P;
+    // this lane's composite row inside a tile: time col >> 4, packet offset f = col & 15 of an even-frequency
+    // node (an odd-frequency node's 16 descendants come out in reversed order: 15 - f)
+    const int lane_t = col >> 4, lane_f = col & 15;
+
+    for (; item < p.groups; item += (int)gridDim.x) {
+        const int b = item / groups, grp = item - b * groups;
+        // the table pointer is made opaque once per item: hoisted out of the item loop, the (loop-invariant)
+        // fragment loads of all phases would be kept live across it -- 200 registers of spills
+        const float* tab = p.tab;
+        asm volatile("" : "+s"(tab));
+        // fragments of the 8 -> 9 tile: on their way (L1 / L2 hits) while the level-8 nodes go to LDS
+        float a1[D::KP1];
+        load_frags<D::KP1>(a1, tab + D::off1, mt1, lane);
+        // level-8 nodes -> LDS; rows past the node length meet zero matrix columns but must be finite
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int e = u * kDeepThreads + tid;
+            if (e < D::R8 * kGroup) XA[e] = xr[u];
+        }
+        __syncthreads();
+        if (item + (int)gridDim.x < p.groups) AFD_FETCH_X8(item + (int)gridDim.x);
+        float a2[D::KP2];
+        load_frags<D::KP2>(a2, tab + D::off2, mt2, lane);
+        // 8 -> 9: one row tile per wave, 32 columns -> 64
+        if (wave < P1::T) step_tile<P1, D::KP1, 5, 6>(a1, mt1, kst1, 0, XA, XB, lane);
+        __syncthreads();
+        // 9 -> 10: (row tile, column tile) per wave, 64 columns -> 128
+        if (wave < 2 * P2::T) step_tile<P2, D::KP2, 6, 7>(a2, mt2, kst2, wave / P2::T, XB, XA, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // the composite's first fragments are requested before the barrier
+        float fa[2][D::KP3];
+        load_frags<D::KP3>(fa[0], tab + D::off3, rt0, lane);
+        __syncthreads();
+        // 10 -> 14
         float bf[KS3];
 #pragma unroll
-        for (int s = 0; s < KS3; ++s) bf[s] = XA[(2 * s + half) * 128 + ct * 32 + col];
-        const int rt0 = part * TH;
-        const float* tb = p.tab + D::off3 + lane;
-        const size_t P = 16384;
-        const size_t chan = (size_t)D::n14 * P;
-        const int nch = (p.e.flags & AFD_WPT_SIGN) ? 2 : 1;
-        const int n = ct * 32 + col;           // level-10 node inside the group
-        const bool odd = n & 1;                // its frequency index is odd: packets come out reversed
-        float* outc = p.out + (size_t)b * nch * chan + (size_t)16 * (grp * 128 + n);
-        float a[KS3];
-#pragma unroll
-        for (int s = 0; s < KS3; ++s) a[s] = tb[((size_t)rt0 * KS3 + s) * 64];
+        for (int s = 0; s < KS3; ++s) bf[s] = XA[(2 * s + half) * 128 + 32 * ct + col];
+        __syncthreads();  // XA may be overwritten by the next item's level-8 nodes from here on
+        // registers r = 4 (r >> 2) + (r & 3) of this lane are nodes 8 (r >> 2) + 4 half + (r & 3) of the column tile
+        float* oute = p.out + (size_t)b * (SIGN ? 2 : 1) * chan + (size_t)16 * (grp * 128 + 32 * ct + 4 * half) +
+                      (size_t)lane_t * P;
+        float* outo = oute + (15 - lane_f);
+        oute += lane_f;
 #pragma unroll
         for (int r = 0; r < TH; ++r) {
             const int rt = rt0 + r;
             if (rt < T3) {
-                float an[KS3];
-                if (r + 1 < TH && rt + 1 < T3) {
-#pragma unroll
-                    for (int s = 0; s < KS3; ++s) an[s] = tb[((size_t)(rt + 1) * KS3 + s) * 64];
-                }
+                // next tile's fragments into the other register set while this tile multiplies
+                if (r + 1 < TH && rt + 1 < T3) load_frags<D::KP3>(fa[(r + 1) & 1], tab + D::off3, rt + 1, lane);
                 f16v acc;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-                for (int s = 0; s < KS3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bf[s], acc, 0, 0, 0);
-                // tile rows = (time 2 rt + {0, 1}) x (packet offset 0..15); this lane: register group g
-                // holds time 2 rt + (g >> 1), packets 8 (g & 1) + 4 half + {0..3}
+                for (int s = 0; s < KS3; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], fa[r & 1][s], acc, 0, 0, 0);
+                const size_t trow = (size_t)(2 * rt) * P;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int t = 2 * rt + (g >> 1);
-                    const int f0 = 8 * (g & 1) + 4 * half;
-                    const float v0 = acc[4 * g], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
-                    float* o = outc + (size_t)t * P + (odd ? 12 - f0 : f0);
-                    f4 w;
-                    w.x = epi_value(odd ? v3 : v0, p.e);
-                    w.y = epi_value(odd ? v2 : v1, p.e);
-                    w.z = epi_value(odd ? v1 : v2, p.e);
-                    w.w = epi_value(odd ? v0 : v3, p.e);
-                    *reinterpret_cast<f4*>(o) = w;
-                    if (p.e.flags & AFD_WPT_SIGN) {
-                        f4 sg;
-                        sg.x = (odd ? v3 : v0) < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
-                        sg.y = (odd ? v2 : v1) < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
-                        sg.z = (odd ? v1 : v2) < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
-                        sg.w = (odd ? v0 : v3) < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
-                        *reinterpret_cast<f4*>(o + chan) = sg;
-                    }
+                for (int q = 0; q < 16; ++q) {
+                    const int node = 8 * (q >> 2) + (q & 3);  // + 4 half: inside oute / outo
+                    const float v = acc[q];
+                    float* o = ((q & 1) ? outo : oute) + trow + 16 * node;
+                    *o = epi_value<MODE>(v, p.e);
+                    if (SIGN) o[chan] = v < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
                 }
-                if (r + 1 < TH && rt + 1 < T3) {
-#pragma unroll
-                    for (int s = 0; s < KS3; ++s) a[s] = an[s];
-                }
+                __builtin_amdgcn_sched_barrier(0);  // one tile's fragments in flight, not all of them
             }
         }
     }
+#undef AFD_FETCH_X8
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,14 +559,15 @@ Mat matmul(const Mat& x, const Mat& y) {
     return z;
 }
 
-// fragment (row tile rt, k-step s, lane l) = A[32 rt + (l & 31)][2 (kst + s) + (l >> 5)]
-void put_fragments(std::vector<float>& tab, int off, const Mat& a, int tiles, int ksb, const int* kst) {
+// fragment (row tile rt, lane l, k-step s) = A[32 rt + (l & 31)][2 (kst + s) + (l >> 5)]; kp floats per lane,
+// stored [rt][kp / 4][lane][4]
+void put_fragments(std::vector<float>& tab, int off, const Mat& a, int tiles, int ksb, int kp, const int* kst) {
     for (int rt = 0; rt < tiles; ++rt)
-        for (int s = 0; s < ksb; ++s)
-            for (int l = 0; l < 64; ++l) {
+        for (int l = 0; l < 64; ++l)
+            for (int s = 0; s < ksb; ++s) {
                 const int row = 32 * rt + (l & 31), col = 2 * ((kst ? kst[rt] : 0) + s) + (l >> 5);
                 const double v = (row < a.rows && col < a.cols) ? a.at(row, col) : 0.0;
-                tab[(size_t)off + ((size_t)rt * ksb + s) * 64 + l] = (float)v;
+                tab[(size_t)off + (((size_t)rt * (kp / 4) + s / 4) * 64 + l) * 4 + (s & 3)] = (float)v;
             }
 }
 
@@ -558,8 +607,8 @@ int get_tables(const float* lo, const float* hi, hipStream_t stream, const float
         if (lv[j].rows != 2 * SH::n[j + 1]) return afd::fail(AFD_ERR_ARG, "wpt: node length table mismatch");
     }
     std::vector<float> tab((size_t)D::tab_floats, 0.f);
-    put_fragments(tab, D::off1, lv[0], D::P1::T, D::P1::KSB, kst1i);
-    put_fragments(tab, D::off2, lv[1], D::P2::T, D::P2::KSB, kst2i);
+    put_fragments(tab, D::off1, lv[0], D::P1::T, D::P1::KSB, D::KP1, kst1i);
+    put_fragments(tab, D::off2, lv[1], D::P2::T, D::P2::KSB, D::KP2, kst2i);
     // composite 10 -> 14: packet offset f (for an even-frequency level-10 node) has Gray-ordered path bits
     // b11..b14 (MSB first); the filter taken at a level is c = b ^ (bit of the level above), c11 = b11
     Mat comp;
@@ -573,7 +622,7 @@ int get_tables(const float* lo, const float* hi, hipStream_t stream, const float
         for (int t = 0; t < SH::n[6]; ++t)
             for (int k = 0; k < comp.cols; ++k) comp.at(16 * t + f, k) = m.at(t, k);
     }
-    put_fragments(tab, D::off3, comp, D::T3, D::KS3, nullptr);
+    put_fragments(tab, D::off3, comp, D::T3, D::KS3, D::KP3, nullptr);
     float* dptr = nullptr;
     hipError_t e = hipMalloc(&dptr, tab.size() * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(dptr, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, stream);
@@ -612,48 +661,68 @@ bool plan_top(T3Params& p, int L) {
     return true;
 }
 
-template <int L>
-int launch3(T3Params& p, const float* dec_lo, const float* dec_hi, float* out, void* ws, int level, int t_len,
-            hipStream_t stream) {
+template <int L, int FIN>
+int launch_top(const T3Params& p, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L, FIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTopLdsFloats * 4);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
+    hipLaunchKernelGGL((wpt3_top_kernel<L, FIN>), dim3((unsigned)p.B * 2), dim3(kTopThreads),
+                       (size_t)kTopLdsFloats * 4, stream, p);
+    return afd::check_launch("wpt3_top_kernel");
+}
+
+template <class SH, int MODE, bool SIGN>
+int launch_deep(const D3Params& q, hipStream_t stream) {
+    using D = Deep3<SH>;
+    constexpr size_t lds = (size_t)(D::A_FLOATS + D::B_FLOATS) * 4;
+    static int grid = 0;
+    if (!grid) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_deep_kernel<SH, MODE, SIGN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, cus = 0;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: %s", hipGetErrorString(e));
+        grid = 2 * (cus > 0 ? cus : 256);  // two persistent workgroups per CU (128 VGPRs x 8 waves each)
+    }
+    const int g = q.groups < grid ? q.groups : grid;
+    hipLaunchKernelGGL((wpt3_deep_kernel<SH, MODE, SIGN>), dim3((unsigned)g), dim3(kDeepThreads), lds, stream, q);
+    return afd::check_launch("wpt3_deep_kernel");
+}
+
+template <int L>
+int launch3(T3Params& p, const float* dec_lo, const float* dec_hi, float* out, void* ws, int level, int t_len,
+            hipStream_t stream) {
     const int C = (p.e.flags & AFD_WPT_SIGN) ? 2 : 1;
     afd::ScopedTiming timing(AFD_K_WPT, 4.0 * p.B * ((double)p.N + (double)C * t_len * (double)(1L << level)), stream);
+    const int mode = epi_mode(p.e.flags, p.e.power);
+    const bool sign = p.e.flags & AFD_WPT_SIGN;
     if (level <= kKsMax) {
         p.dst = out;
-        p.final_ = 1;
-        hipLaunchKernelGGL(wpt3_top_kernel<L>, dim3((unsigned)p.B * 2), dim3(kTopThreads), (size_t)kTopLdsFloats * 4,
-                           stream, p);
-        return afd::check_launch("wpt3_top_kernel");
+        // the sign channel and the slow powers take the generic instance (flags read at run time there)
+        if (mode == EPI_LOG2) return launch_top<L, EPI_LOG2>(p, stream);
+        if (mode == EPI_RAW) return launch_top<L, EPI_RAW>(p, stream);
+        return launch_top<L, EPI_SLOW>(p, stream);
     }
     if constexpr (HasShape3<L>::value) {
         using SH = Shape3<L>;
-        using D = Deep3<SH>;
-        static bool dattr = false;
-        constexpr size_t lds = (size_t)(D::A_FLOATS + D::B_FLOATS) * 4;
-        if (!dattr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_deep_kernel<SH>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
-            dattr = true;
-        }
         D3Params q{};
         int rc = get_tables<SH>(dec_lo, dec_hi, stream, &q.tab, q.kst1, q.kst2);
         if (rc != AFD_OK) return rc;
         p.dst = static_cast<float*>(ws);
-        p.final_ = 0;
-        hipLaunchKernelGGL(wpt3_top_kernel<L>, dim3((unsigned)p.B * 2), dim3(kTopThreads), (size_t)kTopLdsFloats * 4,
-                           stream, p);
+        rc = launch_top<L, -1>(p, stream);
+        if (rc != AFD_OK) return rc;
         q.ws = static_cast<const float*>(ws);
         q.out = out;
         q.e = p.e;
-        hipLaunchKernelGGL(wpt3_deep_kernel<SH>, dim3((unsigned)p.B * (256 / kGroup)), dim3(kDeepThreads), lds, stream, q);
-        return afd::check_launch("wpt3 kernels");
+        q.groups = p.B * (256 / kGroup);
+        if (mode == EPI_LOG2) return sign ? launch_deep<SH, EPI_LOG2, true>(q, stream) : launch_deep<SH, EPI_LOG2, false>(q, stream);
+        if (mode == EPI_RAW) return sign ? launch_deep<SH, EPI_RAW, true>(q, stream) : launch_deep<SH, EPI_RAW, false>(q, stream);
+        return sign ? launch_deep<SH, EPI_SLOW, true>(q, stream) : launch_deep<SH, EPI_SLOW, false>(q, stream);
     }
     return 1;
 }
@@ -711,7 +780,8 @@ int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float*
     e.mean = mean;
     e.inv_std = (float)(1.0 / (double)(std == 0.f ? 1.f : std));
     const bool norm = flags & AFD_WPT_NORM;
-    e.k1 = (float)(0.6931471805599453 * (norm ? 1.0 / (double)std : 1.0));
+    const double scale = norm ? 1.0 / (double)std : 1.0;
+    e.k1 = (float)((flags & AFD_WPT_LOG) ? 0.6931471805599453 * scale : scale);
     e.k0 = norm ? (float)(-(double)mean / (double)std) : 0.f;
     e.sgn_neg = norm ? (-1.f - sign_mean) / sign_std : -1.f;
     e.sgn_pos = norm ? (1.f - sign_mean) / sign_std : 1.f;
