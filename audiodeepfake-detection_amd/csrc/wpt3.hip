@@ -15,14 +15,17 @@
 //   wpt3_deep_kernel  levels 9..14 of the level-14 transform of 1 s frames on the matrix cores
 //       (v_mfma_f32_32x32x2_f32: exact fp32 products).  An analysis step is the same linear map for
 //       every node of a level, children = A_k parent, so a level is the GEMM Y = A_k X with the nodes
-//       as columns.  Three phases per workgroup (32 level-8 nodes of one frame, 8 waves):
-//         8 -> 9   A [2 n9 x n8], banded row tiles, 32 columns
-//         9 -> 10  A [2 n10 x n9], 64 columns
+//       as columns.  Three phases per work item (64 level-8 nodes of one frame; persistent 8-wave workgroups):
+//         8 -> 9   A [2 n9 x n8], banded row tiles, 64 columns
+//         9 -> 10  A [2 n10 x n9], 128 columns
 //         10 -> 14 ONE composite matrix C [16 n14 x n10] = the product of the four level matrices along
 //                  each of the 16 filter paths (deep nodes are 24..44 samples long: the composite has
 //                  fewer entries than the four steps it replaces, 16 896 against 21 800 products per
-//                  level-10 node for coif4), 128 columns, rows ordered (time, packet) so that a lane's
-//                  four consecutive accumulator registers are four neighbouring packets -> float4 stores.
+//                  level-10 node for coif4), 256 columns.  Its fragments stay in registers for the whole
+//                  kernel (a wave owns half of the row tiles and two of the eight column tiles): inside a
+//                  stream of f32 matrix instructions every operand register filled from LDS or memory costs
+//                  about as much as a matrix instruction (tools/micro), so operands are loaded once and
+//                  reused across as many instructions as the register file allows (2 waves per SIMD).
 //       Matrices are built on the host in double precision from the taps, once per wavelet and device.
 #include "afd_common.h"
 #include "../../include/afd_hip.h"
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
 // ------------------------------------------------------------------------------------------------
 constexpr int kDeepWaves = 8;
 constexpr int kDeepThreads = kDeepWaves * 64;
-constexpr int kGroup = 32;  // level-8 nodes per workgroup
+constexpr int kGroup = 64;  // level-8 nodes per work item
 
 constexpr int refl_c(int j, int n) {
     j = j < 0 ? -j : j;
@@ -313,11 +316,10 @@ template <class SH> struct Deep3 {
     static constexpr int KS3 = (n10 + 1) / 2;
     static constexpr int T3 = 16 * n14 / 32;
     static_assert((16 * n14) % 32 == 0, "composite rows fill whole tiles");
-    static_assert(P1::T <= kDeepWaves && 2 * P2::T <= kDeepWaves, "one task per wave in the stepwise phases");
-    // LDS images, position-major: X8 [R8][32] and X10 [R10][128] share region A, X9 [R9][64] is region B
+    // LDS images, position-major: X8 [R8][64] and X10 [R10][256] share region A, X9 [R9][128] is region B
     static constexpr int R8 = 2 * P1::KS, R9 = 2 * P2::KS, R10 = 2 * KS3;
-    static constexpr int A_FLOATS = (R8 * 32 > R10 * 128) ? R8 * 32 : R10 * 128;
-    static constexpr int B_FLOATS = R9 * 64;
+    static constexpr int A_FLOATS = (R8 * 64 > R10 * 256) ? R8 * 64 : R10 * 256;
+    static constexpr int B_FLOATS = R9 * 128;
     // fragment tables: four k-steps of a lane are one 16-byte element and the 64 lanes of a load are
     // consecutive (1 KB per load instruction).  Inside a stream of f32 matrix instructions a vector-memory
     // instruction costs by the cache lines it touches, not by its bytes (measured, tools/micro): the same
@@ -384,12 +386,11 @@ __device__ __forceinline__ void load_frags(float (&a)[KP], const float* tab, int
     }
 }
 
-// Persistent workgroups (two per CU): each walks the (frame, group of 32 level-8 nodes) items with a
-// stride of the grid.  The fragments of the two stepwise phases stay in registers for the whole kernel,
-// the next item's level-8 nodes travel from the hand-off image into registers while the current item is
-// in the composite phase.
+// Persistent workgroups (one per CU, 2 waves per SIMD, up to 256 registers each): a workgroup walks the
+// (frame, 64 level-8 nodes) items with a stride of the grid.  The composite's fragments are loaded once per
+// kernel; the next item's level-8 nodes travel from the hand-off image into registers during the current item.
 template <class SH, int MODE, bool SIGN>
-__global__ void __launch_bounds__(kDeepThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(kDeepThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wpt3_deep_kernel(const D3Params p) {
     using D = Deep3<SH>;
     using P1 = typename D::P1;
@@ -415,38 +416,36 @@ wpt3_deep_kernel(const D3Params p) {
         const float* wsb = p.ws + (size_t)fb * n8 * 256 + fg * kGroup;                        \
         _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                     \
             const int e = u * kDeepThreads + tid;                                             \
-            xr[u] = e < n8 * kGroup ? wsb[(size_t)(e >> 5) * 256 + (e & 31)] : 0.f;           \
+            xr[u] = e < n8 * kGroup ? wsb[(size_t)(e >> 6) * 256 + (e & 63)] : 0.f;           \
         }                                                                                     \
     }
     AFD_FETCH_X8(item);
-    const int mt1 = wave < P1::T ? wave : 0;
-    const int mt2 = wave % P2::T;
-    const int kst1 = p.kst1[mt1], kst2 = p.kst2[mt2];
 
-    // composite phase: wave = (half of the row tiles, 32 consecutive level-10 columns).  The node image is
+    // composite phase: wave = (half of the row tiles, two of the eight 32-column tiles).  The node image is
     // the A operand and the matrix fragment the B operand, i.e. the wave computes the TRANSPOSED tile
     // D[node][row]: a lane then owns one composite row (time, packet offset) and its 16 registers are 16
     // nodes, so one store instruction writes, for a fixed register, 16 consecutive packets of a node from
     // 16 consecutive lanes -- whole 64-byte lines (four per instruction) instead of 64 quarter lines.
     constexpr int KS3 = D::KS3, T3 = D::T3, TH = (T3 + 1) / 2;
-    const int part = wave >> 2, ct = wave & 3;
+    const int rh = wave & 1, cp = wave >> 1;
     const int half = lane >> 5, col = lane & 31;
-    const int rt0 = part * TH;
+    const int rt0 = rh * TH;
     const size_t P = 16384;
     const size_t chan = (size_t)D::n14 * P;
     // this lane's composite row inside a tile: time col >> 4, packet offset f = col & 15 of an even-frequency
     // node (an odd-frequency node's 16 descendants come out in reversed order: 15 - f)
     const int lane_t = col >> 4, lane_f = col & 15;
+    float fa[TH][D::KP3];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+        if (rt0 + r < T3) load_frags<D::KP3>(fa[r], p.tab + D::off3, rt0 + r, lane);
 
     for (; item < p.groups; item += (int)gridDim.x) {
         const int b = item / groups, grp = item - b * groups;
         // the table pointer is made opaque once per item: hoisted out of the item loop, the (loop-invariant)
-        // fragment loads of all phases would be kept live across it -- 200 registers of spills
+        // fragment loads of the stepwise phases would be kept live across it
         const float* tab = p.tab;
         asm volatile("" : "+s"(tab));
-        // fragments of the 8 -> 9 tile: on their way (L1 / L2 hits) while the level-8 nodes go to LDS
-        float a1[D::KP1];
-        load_frags<D::KP1>(a1, tab + D::off1, mt1, lane);
         // level-8 nodes -> LDS; rows past the node length meet zero matrix columns but must be finite
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
@@ -455,50 +454,56 @@ wpt3_deep_kernel(const D3Params p) {
         }
         __syncthreads();
         if (item + (int)gridDim.x < p.groups) AFD_FETCH_X8(item + (int)gridDim.x);
-        float a2[D::KP2];
-        load_frags<D::KP2>(a2, tab + D::off2, mt2, lane);
-        // 8 -> 9: one row tile per wave, 32 columns -> 64
-        if (wave < P1::T) step_tile<P1, D::KP1, 5, 6>(a1, mt1, kst1, 0, XA, XB, lane);
+        // 8 -> 9: (row tile, column tile) tasks, 64 columns -> 128
+        for (int task = wave; task < 2 * P1::T; task += kDeepWaves) {
+            const int mt = task % P1::T, nt = task / P1::T;
+            float a1[D::KP1];
+            load_frags<D::KP1>(a1, tab + D::off1, mt, lane);
+            step_tile<P1, D::KP1, 6, 7>(a1, mt, p.kst1[mt], nt, XA, XB, lane);
+        }
         __syncthreads();
-        // 9 -> 10: (row tile, column tile) per wave, 64 columns -> 128
-        if (wave < 2 * P2::T) step_tile<P2, D::KP2, 6, 7>(a2, mt2, kst2, wave / P2::T, XB, XA, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        // the composite's first fragments are requested before the barrier
-        float fa[2][D::KP3];
-        load_frags<D::KP3>(fa[0], tab + D::off3, rt0, lane);
+        // 9 -> 10: 128 columns -> 256
+        for (int task = wave; task < 4 * P2::T; task += kDeepWaves) {
+            const int mt = task % P2::T, nt = task / P2::T;
+            float a2[D::KP2];
+            load_frags<D::KP2>(a2, tab + D::off2, mt, lane);
+            step_tile<P2, D::KP2, 7, 8>(a2, mt, p.kst2[mt], nt, XB, XA, lane);
+        }
         __syncthreads();
-        // 10 -> 14
-        float bf[KS3];
+        // 10 -> 14: both column tiles' node fragments are requested up front
+        float bf[2][KS3];
 #pragma unroll
-        for (int s = 0; s < KS3; ++s) bf[s] = XA[(2 * s + half) * 128 + 32 * ct + col];
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int s = 0; s < KS3; ++s) bf[c][s] = XA[(2 * s + half) * 256 + 32 * (2 * cp + c) + col];
         __syncthreads();  // XA may be overwritten by the next item's level-8 nodes from here on
-        // registers r = 4 (r >> 2) + (r & 3) of this lane are nodes 8 (r >> 2) + 4 half + (r & 3) of the column tile
-        float* oute = p.out + (size_t)b * (SIGN ? 2 : 1) * chan + (size_t)16 * (grp * 128 + 32 * ct + 4 * half) +
-                      (size_t)lane_t * P;
-        float* outo = oute + (15 - lane_f);
-        oute += lane_f;
 #pragma unroll
-        for (int r = 0; r < TH; ++r) {
-            const int rt = rt0 + r;
-            if (rt < T3) {
-                // next tile's fragments into the other register set while this tile multiplies
-                if (r + 1 < TH && rt + 1 < T3) load_frags<D::KP3>(fa[(r + 1) & 1], tab + D::off3, rt + 1, lane);
-                f16v acc;
+        for (int c = 0; c < 2; ++c) {
+            // registers q of this lane are nodes 8 (q >> 2) + 4 half + (q & 3) of the column tile
+            float* oute = p.out + (size_t)b * (SIGN ? 2 : 1) * chan +
+                          (size_t)16 * (grp * 256 + 32 * (2 * cp + c) + 4 * half) + (size_t)lane_t * P;
+            float* outo = oute + (15 - lane_f);
+            oute += lane_f;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            for (int r = 0; r < TH; ++r) {
+                const int rt = rt0 + r;
+                if (rt < T3) {
+                    f16v acc;
 #pragma unroll
-                for (int s = 0; s < KS3; ++s)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s], fa[r & 1][s], acc, 0, 0, 0);
-                const size_t trow = (size_t)(2 * rt) * P;
+                    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int node = 8 * (q >> 2) + (q & 3);  // + 4 half: inside oute / outo
-                    const float v = acc[q];
-                    float* o = ((q & 1) ? outo : oute) + trow + 16 * node;
-                    *o = epi_value<MODE>(v, p.e);
-                    if (SIGN) o[chan] = v < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                    for (int s = 0; s < KS3; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][s], fa[r][s], acc, 0, 0, 0);
+                    const size_t trow = (size_t)(2 * rt) * P;
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int node = 8 * (q >> 2) + (q & 3);  // + 4 half: inside oute / outo
+                        const float v = acc[q];
+                        float* o = ((q & 1) ? outo : oute) + trow + 16 * node;
+                        *o = epi_value<MODE>(v, p.e);
+                        if (SIGN) o[chan] = v < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);  // one tile's fragments in flight, not all of them
             }
         }
     }
@@ -687,7 +692,7 @@ int launch_deep(const D3Params& q, hipStream_t stream) {
         if (e == hipSuccess) e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: %s", hipGetErrorString(e));
-        grid = 2 * (cus > 0 ? cus : 256);  // two persistent workgroups per CU (128 VGPRs x 8 waves each)
+        grid = cus > 0 ? cus : 256;  // one persistent workgroup per CU (8 waves, 2 per SIMD)
     }
     const int g = q.groups < grid ? q.groups : grid;
     hipLaunchKernelGGL((wpt3_deep_kernel<SH, MODE, SIGN>), dim3((unsigned)g), dim3(kDeepThreads), lds, stream, q);

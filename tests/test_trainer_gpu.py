@@ -47,7 +47,7 @@ def test_trainer_train_eval_snapshot_roundtrip(tmp_path):
     from torch.utils.data import DataLoader
 
     torch.manual_seed(0)
-    args, trainer = bench.build("sym5-l8", 8, False, torch.device("cuda", 0))
+    args, trainer, _ = bench.build("sym5-l8", 8, False, torch.device("cuda", 0))
     args.validation_interval = 1
     args.ckpt_every = 0
     loader = DataLoader(SyntheticFrames(16, 22050, num_labels=3), batch_size=8, drop_last=True)
@@ -82,7 +82,7 @@ def test_integrated_gradients_match_cpu_restatement(tmp_path):
     from torch.utils.data import DataLoader
 
     torch.manual_seed(1)
-    args, trainer = bench.build("sym5-l8", 4, False, torch.device("cuda", 0))
+    args, trainer, _ = bench.build("sym5-l8", 4, False, torch.device("cuda", 0))
     net = trainer.model
     net.eval()
     ref = torch_ref.DCNNRef(args.input_dim, time_dim_add=1).double()
