@@ -74,12 +74,39 @@ def _join_side(device_index: int) -> None:
     torch.cuda.current_stream(device_index).wait_stream(_side_streams[device_index])
 
 
+def join_side_stream(device=None) -> None:
+    """Make the current stream wait for everything queued on the weight-gradient stream.  Idempotent and
+    unconditional: called by everything that reads or rewrites the gradient arena (the gradient
+    all-reduce, FusedAdam.step / zero_grad), so a backward pass that raised before its end-of-backward
+    callback ran cannot leave later steps racing the side stream."""
+    idx = device.index if isinstance(device, torch.device) else (torch.cuda.current_device() if device is None else device)
+    st = _side_streams.get(idx)
+    if st is not None:
+        _side_pending.discard(idx)
+        torch.cuda.current_stream(idx).wait_stream(st)
+
+
 def _queue_join(device) -> None:
     if device.index in _side_pending:
         return
     _side_pending.add(device.index)
     idx = device.index
     torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(idx))
+
+
+# One-shot hook run by the autograd engine at the very end of the next backward pass (after the weight-
+# gradient stream has been joined): the data-parallel step starts its gradient all-reduce from here, without
+# a trip back through the Python step code (train_classifier.sync_gradients then only waits for it).
+_end_of_backward: list = []
+
+
+def at_end_of_backward(fn) -> None:
+    _end_of_backward.append(fn)
+
+
+def _run_end_of_backward() -> None:
+    while _end_of_backward:
+        _end_of_backward.pop(0)()
 
 
 def next_seed() -> int:
@@ -234,6 +261,12 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
     nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
     ws = _ws(nbytes, x.device)
     dx = dw = db = None
+    # the weight-gradient kernel only needs dy (and the zeroed arena): the side stream waits for an event
+    # recorded BEFORE this layer's backward-data launch, so the two kernels can overlap
+    ready = None
+    if (need_dw or need_db) and _side_enabled() and x.is_cuda:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(x.device))
     if need_dx:
         dx = torch.empty_like(x)
         _native.check(lib.afd_conv2d_backward_data(
@@ -248,9 +281,8 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
                 and (not has_bias or (b is not None and b.grad is not None
                                       and getattr(b, "_afd_arena", False))))
         if side:
-            main = torch.cuda.current_stream(x.device)
             st = _side_stream(x.device)
-            st.wait_stream(main)  # dy (and the zeroed arena) are ready
+            st.wait_event(ready)  # dy (and the zeroed arena) are ready
             with torch.cuda.stream(st):
                 dwt = torch.empty_like(w)
                 dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
@@ -822,6 +854,10 @@ class _CrossEntropy(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dout):
         (dl,) = ctx.saved_tensors
+        if _end_of_backward:
+            # the loss is the first node of every backward pass: callbacks queued here run once the
+            # engine has finished the whole graph, after those queued by the layers (side-stream join)
+            torch.autograd.Variable._execution_engine.queue_callback(_run_end_of_backward)
         return dl * dloss, None
 
 
@@ -872,6 +908,8 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False):  # keep the arena views alive
+        if self.flat_grad.is_cuda:
+            join_side_stream(self.flat_grad.device)
         self.flat_grad.zero_()
         self._relink()
 
@@ -885,6 +923,8 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         g = self.param_groups[0]
+        if self.flat_grad.is_cuda:
+            join_side_stream(self.flat_grad.device)
         self.step_count += 1
         _native.check(_lib().afd_adam_step(
             _native.ptr(self.flat), _native.ptr(self.flat_grad), _native.ptr(self.m),

@@ -76,6 +76,14 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
         return 1.0
     world = dist.get_world_size()
     if isinstance(optimizer, ops.FusedAdam):
+        work = getattr(optimizer, "_pending_allreduce", None)
+        if work is not None:  # started by the end-of-backward hook (start_gradient_allreduce)
+            optimizer._pending_allreduce = None
+            work.wait()
+            return 1.0 / world
+        ops._end_of_backward.clear()  # a hook whose backward never reached the loss node (foreign loss function)
+        if optimizer.flat_grad.is_cuda:
+            ops.join_side_stream(optimizer.flat_grad.device)
         dist.all_reduce(optimizer.flat_grad)
         return 1.0 / world
     for p in model.parameters():
@@ -85,24 +93,64 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
     return 1.0
 
 
+def _loader(args: DotDict, ds, train: bool) -> DataLoader:
+    """Only the training split drops its ragged tail (sampler and loader); validation / test see every
+    sample, the DistributedSampler padding a shard by wrapping around (reference :118-158)."""
+    sampler = None
+    if args.ddp:
+        sampler = DistributedSampler(ds, shuffle=train, seed=args.seed or 0, drop_last=train)
+    workers = int(args.num_workers or 0)
+    return DataLoader(ds, batch_size=args.batch_size, shuffle=(sampler is None and train), sampler=sampler,
+                      drop_last=train, pin_memory=True, num_workers=workers,
+                      persistent_workers=workers > 0)
+
+
+def start_gradient_allreduce(optimizer) -> None:
+    """Arrange for the arena all-reduce to be issued by the autograd engine itself when the coming backward
+    pass ends (ops.at_end_of_backward): RCCL gets the collective the moment the last gradient kernel has been
+    queued; `sync_gradients` picks the handle up."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1 and isinstance(optimizer, ops.FusedAdam)):
+        return
+
+    def fire() -> None:
+        if optimizer.flat_grad.is_cuda:
+            ops.join_side_stream(optimizer.flat_grad.device)
+        optimizer._pending_allreduce = dist.all_reduce(optimizer.flat_grad, async_op=True)
+
+    ops.at_end_of_backward(fire)
+
+
 def create_data_loaders(args: DotDict, limit: Optional[int] = None):
-    """Train / val / test loaders with DistributedSampler semantics (reference :50-229)."""
+    """(train, val, test, cross val, cross test) loaders (reference :50-229).
+
+    ``limit`` caps the synthetic splits only; real datasets are cut by ``limit_train`` / ``cross_limit``
+    from the config, as in the reference."""
+    synthetic = bool(args.synthetic) or args.data_path is None
     loaders = []
-    for split, lim in (("train", args.limit_train[0] if args.limit_train else limit),
-                       ("val", args.limit_train[1] if args.limit_train else limit),
-                       ("test", args.limit_train[2] if args.limit_train else limit)):
+    for i, split in enumerate(("train", "val", "test")):
+        lim = args.limit_train[i] if args.limit_train else (limit if synthetic else None)
+        kw = dict(limit=lim) if lim is not None else {}
         ds = get_costum_dataset(data_path=args.data_path, ds_type=split, only_use=args.only_use,
-                                save_path=args.save_path, limit=lim, file_type=args.file_type,
+                                save_path=args.save_path, file_type=args.file_type,
                                 resample_rate=args.sample_rate, seconds=args.seconds,
-                                synthetic=bool(args.synthetic))
-        sampler = None
-        if args.ddp:
-            sampler = DistributedSampler(ds, shuffle=(split == "train"), seed=args.seed or 0,
-                                         drop_last=True)
-        loaders.append(DataLoader(ds, batch_size=args.batch_size, shuffle=(sampler is None and split == "train"),
-                                  sampler=sampler, drop_last=True, pin_memory=True,
-                                  num_workers=args.num_workers or 0))
-    return loaders
+                                synthetic=synthetic, **kw)
+        loaders.append(_loader(args, ds, split == "train"))
+    cross_val = cross_test = None
+    if args.unknown_prefix is not None or args.cross_data_path is not None:
+        if args.cross_data_path is None:
+            raise NotImplementedError("--unknown-prefix needs cross_data_path in the config (reference :187-189)")
+        for split in ("val", "test"):
+            i = 1 if split == "val" else 2
+            kw = dict(limit=args.cross_limit[i]) if args.cross_limit else {}
+            ds = get_costum_dataset(data_path=args.cross_data_path, ds_type=split,
+                                    only_test_folders=args.only_test_folders, only_use=args.cross_sources,
+                                    save_path=args.save_path, file_type=args.file_type,
+                                    resample_rate=args.sample_rate, seconds=args.seconds, **kw)
+            if split == "val":
+                cross_val = _loader(args, ds, False)
+            else:
+                cross_test = _loader(args, ds, False)
+    return loaders[0], loaders[1], loaders[2], cross_val, cross_test
 
 
 class Trainer:
@@ -181,6 +229,7 @@ class Trainer:
         feats = self._features(audio)
         out = self.model(feats)
         loss = self.loss_fun(out, labels)
+        start_gradient_allreduce(self.optimizer)
         loss.backward()
         scale = sync_gradients(self.model, self.optimizer)
         if isinstance(self.optimizer, ops.FusedAdam):
@@ -387,10 +436,24 @@ class Trainer:
             np.save(path + "_mean_images.npy", mean_img.finalize().squeeze().cpu().numpy())
             np.save(path + "_last_image.npy", image.squeeze().detach().cpu().numpy())
 
-    def testing(self):
-        acc, eer = self.val_test_loop(self.test_data_loader, name="test")
-        self.test_results = (acc, eer)
+    def testing(self, only_unknown: bool = False):
+        """(test acc, test EER, cross-source acc, cross-source EER) (reference :1055-1065, :846-885);
+        ``only_unknown`` evaluates the cross-source loader alone."""
+        self._check_model_init()
+        acc = eer = cross_acc = cross_eer = 0.0
+        if not only_unknown and self.test_data_loader is not None:
+            acc, eer = self.val_test_loop(self.test_data_loader, name="test known")
+        if self.cross_loader_test is not None:
+            cross_acc, cross_eer = self.val_test_loop(self.cross_loader_test, name="test unknown")
+        self.test_results = (acc, eer, cross_acc, cross_eer)
         return self.test_results
+
+    def _run_validation(self, epoch: int) -> None:
+        acc, eer = self.val_test_loop(self.val_data_loader, name="val known")
+        entry = [self.step_total, epoch, acc, eer]
+        if self.cross_loader_val is not None:
+            entry += list(self.val_test_loop(self.cross_loader_val, name="val unknown"))
+        self.validation_list.append(entry)
 
     # -- snapshots ------------------------------------------------------------------------
     def _save_snapshot(self, epoch: int) -> None:
@@ -404,17 +467,32 @@ class Trainer:
         self.epochs_run = snapshot["EPOCHS_RUN"]
 
     def train(self, max_epochs: int) -> None:
+        """Epoch loop with the reference's snapshot / validation cadence (:1021-1053)."""
         self._check_model_init()
+        ckpt = self.args.ckpt_every or 0
+        val = self.args.validation_interval or 0
         for epoch in range(self.epochs_run, max_epochs):
             self._run_epoch(epoch)
-            if self.global_rank == 0 and self.args.ckpt_every and epoch % self.args.ckpt_every == 0 and epoch > 0:
+            if self.global_rank == 0 and ckpt and ((epoch > 0 and epoch % ckpt == 0) or (epoch == 0 and ckpt == 1)):
                 self._save_snapshot(epoch)
-            if self.val_data_loader is not None and self.args.validation_interval and \
-                    (epoch + 1) % self.args.validation_interval == 0:
-                acc, eer = self.val_test_loop(self.val_data_loader, name="val")
-                self.validation_list.append([self.step_total, epoch, acc, eer])
-        if self.test_data_loader is not None:
-            self.testing()
+            if self.val_data_loader is not None and val and \
+                    ((epoch > 0 and epoch % val == 0) or (epoch == 0 and val == 1)):
+                self._run_validation(epoch)
+            if epoch == max_epochs - 1 and (self.test_data_loader is not None or self.cross_loader_test is not None):
+                self.testing()
+
+
+def snapshot_name(args: DotDict, model) -> str:
+    """Snapshot file stem with the reference's fields (:1222-1271): transform, wavelet, features, STFT /
+    packet geometry, optimiser settings, model name, sign channel, power, source, frame length, seed."""
+    tr = "stft" if args.transform == "stft" else "packets" + str(args.wavelet)
+    name = model.get_name() if hasattr(model, "get_name") else "customModel"
+    src = (args.only_use or ["all"])[-1]
+    return (f"fake_{tr}_{args.features}_{args.hop_length}_{args.sample_rate}_{args.window_size}_"
+            f"{args.num_of_scales}_{int(args.f_min or 0)}-{int(args.f_max or 0)}_{args.learning_rate}_"
+            f"{args.weight_decay}_{args.batch_size}_{args.nclasses}_{args.epochs}e_{name}_"
+            f"signs{args.loss_less == 'True'}_augc{bool(args.aug_contrast)}_augn{bool(args.aug_noise)}_"
+            f"power{args.power}_{src}_{args.seconds}secs_{args.seed}")
 
 
 def _parse_args():
@@ -426,7 +504,9 @@ def main() -> None:
     """CLI / experiment loop (reference train_classifier.py:1084-1368)."""
     parsed = _parse_args()
     args = DotDict(vars(parsed))
-    args.num_workers = 0
+    if args.num_workers is None:
+        # the reference hard-codes 10 loader workers (:1106); here: what this process may use
+        args.num_workers = 0 if args.synthetic else min(10, max(1, (os.cpu_count() or 2) - 1))
     if args.ddp:
         ddp_setup()
     if args.config:
@@ -436,11 +516,13 @@ def main() -> None:
         config = ns["get_config"]()
     else:
         config = {}
-    for k in ("data_path", "save_path", "only_use", "limit_train", "file_type", "seconds"):
+    for k in ("data_path", "save_path", "only_use", "limit_train", "file_type", "seconds", "cross_data_path",
+              "cross_limit", "only_test_folders"):
         args.setdefault(k, None)
     args.seconds = args.seconds or 1
     griderator = build_new_grid(config, random_seeds=args.random_seeds, seeds=args.init_seeds)
     num_exp = griderator.get_len()
+    exp_results: dict = {}
     for _ in range(num_exp):
         args, _step = griderator.update_step(args)
         set_seed(args.seed)
@@ -450,19 +532,42 @@ def main() -> None:
         args.input_dim = get_input_dims(args, transforms)
         in_channels = 2 if args.loss_less == "True" else 1
         model = get_model(args, args.model, args.nclasses, in_channels, is_lead(args))
-        train_loader, val_loader, test_loader = create_data_loaders(args, limit=args.batch_size * (args.synthetic_steps or 8))
+        train_loader, val_loader, test_loader, cross_val, cross_test = create_data_loaders(
+            args, limit=args.batch_size * (args.synthetic_steps or 8))
         model.to(device)
         optimizer = ops.FusedAdam(model.parameters(), lr=args.learning_rate, weight_decay=args.weight_decay)
         loss_fun = ops.CrossEntropyLoss()
         os.makedirs(os.path.join(args.log_dir, "models"), exist_ok=True)
-        snap = os.path.join(args.log_dir, "models", f"model_{args.transform}_{args.wavelet}_{args.seed}")
+        snap = os.path.join(args.log_dir, "models", snapshot_name(args, model))
         trainer = Trainer(snap, args, normalize, transforms, test_loader, model, train_loader,
-                          val_loader, None, None, optimizer, loss_fun, None)
-        trainer.train(args.epochs)
+                          val_loader, cross_val, cross_test, optimizer, loss_fun, None)
+        if args.only_testing:
+            # evaluate an existing snapshot on the cross-source test set (reference :1313-1316)
+            trainer._check_model_init()
+            trainer.load_snapshot(trainer.snapshot_path)
+            trainer.testing(only_unknown=cross_test is not None)
+        elif args.only_ig:
+            # attribution of an existing snapshot (reference :1317-1323)
+            trainer._check_model_init()
+            trainer.load_snapshot(trainer.snapshot_path)
+            tag = (f"{args.transform}_{args.sample_rate}_{args.seconds}_{args.seed}_"
+                   f"{(args.only_use or ['all'])[-1]}_{args.wavelet}_{args.power}_{args.loss_less == 'True'}")
+            trainer.integrated_gradients(tag)
+        else:
+            trainer.train(args.epochs)
+        exp_results.setdefault(args.seed, []).append(trainer.test_results)
         if is_lead(args):
             last = trainer.loss_list[-1][2] if trainer.loss_list else float("nan")
+            res = trainer.test_results
             print(f"seed {args.seed}: steps {trainer.step_total}, last loss {last:.6f}, "
-                  f"test acc {trainer.test_results[0] if trainer.test_results else float('nan'):.4f}")
+                  f"test acc {res[0] if res else float('nan'):.4f}, eer {res[1] if res else float('nan'):.4f}")
+    if is_lead(args) and exp_results:
+        # per-seed summary (the reference's print_results, :1360): mean / std over the runs of each seed
+        for seed, runs in exp_results.items():
+            arr = np.asarray([r for r in runs if r], dtype=np.float64)
+            if arr.size:
+                print(f"results seed {seed}: mean {np.round(arr.mean(0), 4).tolist()} std {np.round(arr.std(0), 4).tolist()} "
+                      f"over {arr.shape[0]} run(s) [acc, eer, cross acc, cross eer]")
     if args.ddp:
         dist.destroy_process_group()
 

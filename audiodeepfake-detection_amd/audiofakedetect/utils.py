@@ -92,6 +92,7 @@ def add_default_parser_args(parser: ArgumentParser) -> ArgumentParser:
     # MI355X build only: run on synthetic frames (no dataset on disk)
     f("--synthetic", action="store_true")
     f("--synthetic-steps", type=int, default=8)
+    f("--num-workers", type=int, default=None)  # loader workers; default: CPU share (the reference hard-codes 10)
     return parser
 
 

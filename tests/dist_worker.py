@@ -75,10 +75,10 @@ def gpu_dcnn(rank, world):
     BatchNorm statistics and the flat gradient all-reduce == single-process full-batch step."""
     from audiofakedetect import ops
     from audiofakedetect.models import DCNN
-    from audiofakedetect.train_classifier import DataParallelRCCL, sync_gradients
+    from audiofakedetect.train_classifier import DataParallelRCCL, start_gradient_allreduce, sync_gradients
     from audiofakedetect.utils import DotDict
 
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
 
     def make(ddp):
         torch.manual_seed(3)
@@ -95,7 +95,10 @@ def gpu_dcnn(rank, world):
     opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=1e-3)
     opt.zero_grad()
     out = wrapped(x[rank * 4:(rank + 1) * 4])
-    ops.CrossEntropyLoss()(out, y[rank * 4:(rank + 1) * 4]).backward()
+    loss = ops.CrossEntropyLoss()(out, y[rank * 4:(rank + 1) * 4])
+    start_gradient_allreduce(opt)  # the all-reduce is issued by the end-of-backward hook
+    loss.backward()
+    assert getattr(opt, "_pending_allreduce", None) is not None
     scale = sync_gradients(wrapped, opt)
     grads = (opt.flat_grad * scale).clone()
     bn_rm = net.cnn[3].running_mean.clone()
@@ -119,9 +122,13 @@ def gpu_dcnn(rank, world):
 if __name__ == "__main__":
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # "gpu_dcnn_rccl": one rank per GPU over RCCL (backend "nccl" is RCCL on ROCm); the others over gloo
+    backend = "nccl" if mode.endswith("_rccl") else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
     try:
-        {"cpu_sync": cpu_sync, "gpu_dcnn": gpu_dcnn}[mode](rank, world)
+        {"cpu_sync": cpu_sync, "gpu_dcnn": gpu_dcnn, "gpu_dcnn_rccl": gpu_dcnn}[mode](rank, world)
     finally:
         dist.destroy_process_group()
     print(f"rank {rank} ok")

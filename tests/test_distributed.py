@@ -20,12 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world2(mode, timeout=300):
+def _run_world2(mode, timeout=300, one_gpu_per_rank=False):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                   WORLD_SIZE="2", LOCAL_RANK="0", OMP_NUM_THREADS="2",
+                   WORLD_SIZE="2", LOCAL_RANK=str(rank if one_gpu_per_rank else 0), OMP_NUM_THREADS="2",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -50,3 +50,34 @@ def test_world2_gloo_cpu_gradient_allreduce_bn_stats_sampler():
 @pytest.mark.gpu
 def test_world2_sharded_dcnn_step_equals_full_batch_step():
     _run_world2("gpu_dcnn")
+
+
+def _gpu_count():
+    import torch
+
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two MI355X: one RCCL rank per GPU")
+def test_world2_rccl_sharded_dcnn_step_equals_full_batch_step():
+    """The same check over RCCL (backend "nccl"), one rank per GPU: replica broadcast, packed SyncBN
+    statistics and the flat gradient all-reduce travel over xGMI."""
+    _run_world2("gpu_dcnn_rccl", one_gpu_per_rank=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two MI355X")
+def test_bench_two_gpus_spawns_ranks_and_reports_the_world():
+    """`python bench.py --gpus 2` (no launcher): two RCCL ranks, weak scaling, one JSON line."""
+    import json
+
+    root = os.path.dirname(HERE)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "sym5-l8",
+                          "--steps", "3", "--warmup", "2", "--cpu-frames", "0"], cwd=root, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["world"]["size"] == 2 and len(d["world"]["devices"]) == 2
+    assert d["config"]["global_batch"] == 2 * d["config"]["batch_per_gpu"] and d["scaling"] == "weak"

@@ -15,11 +15,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_entry_point_runs_like_train_sh(tmp_path):
     cmd = [sys.executable, "-m", "src.audiofakedetect.train_classifier", "--log-dir", str(tmp_path),
            "--transform", "packets", "--wavelet", "sym5", "--num-of-scales", "256", "--log-scale",
-           "--model", "modules", "--init-seeds", "0", "--synthetic",
+           "--model", "modules", "--init-seeds", "0", "--synthetic", "--ckpt-every", "1",
            "--config", os.path.join(ROOT, "tests", "synthetic_config.py")]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "seed 0: steps 2" in out.stdout, out.stdout[-2000:]
+    # --ckpt-every 1 saved a snapshot after epoch 0; --only-testing evaluates it and must not train
+    # (reference train_classifier.py:1313-1316)
+    snaps = [f for f in os.listdir(tmp_path / "models") if f.endswith(".pt")]
+    assert len(snaps) == 1 and snaps[0].startswith("fake_packetssym5_none_220_22050_") and "_DCNN_signsFalse_" in snaps[0]
+    out2 = subprocess.run(cmd + ["--only-testing"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stdout[-2000:] + out2.stderr[-2000:]
+    assert "seed 0: steps 0" in out2.stdout and "results seed 0" in out2.stdout, out2.stdout[-2000:]
 
 
 def test_entry_point_with_block_norm_statistics(tmp_path):
@@ -56,8 +63,9 @@ def test_trainer_train_eval_snapshot_roundtrip(tmp_path):
     trainer.train(1)
     assert trainer.step_total == 2 and len(trainer.loss_list) == 2
     assert all(torch.isfinite(torch.tensor(l[2])) for l in trainer.loss_list)
-    acc, eer = trainer.test_results
-    assert 0.0 <= acc <= 1.0 and 0.0 <= eer <= 1.0
+    acc, eer, cross_acc, cross_eer = trainer.test_results  # (test, test EER, cross-source, cross-source EER)
+    assert 0.0 <= acc <= 1.0 and 0.0 <= eer <= 1.0 and cross_acc == 0.0 and cross_eer == 0.0
+    assert len(trainer.validation_list) == 1  # validation_interval 1 validates epoch 0, as the reference does
     assert set(trainer.last_eval["per_label"]) <= {0, 1, 2}
     # class labels are bit-exact between two evaluations of the same snapshot
     before = trainer.last_eval["pred"].clone()
