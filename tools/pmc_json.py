@@ -1,17 +1,28 @@
-"""Turns the two rocprofv3 --pmc passes of tools/pmc_bench.sh into profiles/r01_pmc_traffic.json.
+"""Turns the two rocprofv3 --pmc passes of tools/pmc_traffic.sh into profiles/<name>.json.
 
-FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE
-counts 64 B per 128-B request of wide (16 B/lane) coalesced reads, so it is doubled for the kernels
-whose staging loads are dwordx4; other widths are uncalibrated and recorded raw.
+usage: pmc_json.py <workload> <batch> <out.json>
+
+FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts
+64 B per 128-B request of wide (16 B/lane) coalesced reads, so it is doubled for the kernels whose streaming
+loads are dwordx4 (WIDE below); other widths are uncalibrated and recorded raw.  WRITE_SIZE is exact for
+16-byte-per-lane streaming stores.  Totals are over every dispatch of a kernel in the trace; `steps_in_trace`
+= the number of bench steps the trace covers (warm-up, timed and the instrumented extra steps), so that
+bytes per step = total / steps_in_trace (bench.py's roofline.traffic).
 """
 import collections, csv, glob, json, os, re, sys
 
-WIDE = ("wino_conv_kernel", "wino16_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "conv1x1_kernel", "wpt_haar14_kernel", "conv_wgrad2_kernel",
-        "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel", "bn_bwd_apply_kernel",
-        "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
-out = {"note": __doc__.strip(), "workload": "coif4-l14", "batch": 128, "kernels": {}}
+workload, batch, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+WIDE = ("wino_conv_kernel", "wino16_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "wgrad3x3p_kernel", "conv1x1_kernel",
+        "wpt_haar14_kernel", "conv_wgrad2_kernel", "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel",
+        "bn_bwd_apply_kernel", "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
+out = {"note": __doc__.strip(), "workload": workload, "batch": batch, "kernels": {}}
+line = None
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     f = max(glob.glob(f"gpurun_out/pmc_{counter}/*/*counter_collection.csv"), key=os.path.getmtime)
+    try:
+        line = json.loads(open(f"gpurun_out/pmc_{counter}/bench.json").read().strip().splitlines()[-1])
+    except Exception:
+        pass
     agg = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
@@ -20,14 +31,20 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         agg[k] += float(r["Counter_Value"]) * 1024.0; n[k] += 1
     for k in agg:
         e = out["kernels"].setdefault(k, {})
-        raw = agg[k] / n[k]
         if counter == "FETCH_SIZE":
-            e["fetch_raw_bytes_per_launch"] = raw
-            e["fetch_bytes_per_launch"] = raw * (2.0 if k in WIDE else 1.0)
+            e["fetch_raw_bytes_total"] = agg[k]
+            e["fetch_bytes_total"] = agg[k] * (2.0 if k in WIDE else 1.0)
             e["fetch_corrected_x2"] = k in WIDE
         else:
-            e["write_bytes_per_launch"] = raw
+            e["write_bytes_total"] = agg[k]
         e["launches_in_trace"] = n[k]
-json.dump(out, open("profiles/r01_pmc_traffic.json", "w"), indent=1, sort_keys=True)
-for k, e in sorted(out["kernels"].items(), key=lambda kv: -(kv[1].get("fetch_bytes_per_launch", 0) + kv[1].get("write_bytes_per_launch", 0)) * kv[1]["launches_in_trace"])[:12]:
-    print(f"{k:28s} launches {e['launches_in_trace']:3d}  fetch {e.get('fetch_bytes_per_launch', 0)/1e9:7.3f} GB  write {e.get('write_bytes_per_launch', 0)/1e9:7.3f} GB per launch")
+# steps the trace covers: warm-up + timed + the instrumented ones bench.py adds after the timed region
+steps = None
+if line:
+    kind_extra = 20 if "front end only" in line["config"]["workload"] else (1 if "eval" in line["config"]["workload"] else 2)
+    steps = line["warmup"] + line["steps"] + max(kind_extra, line["steps"] if kind_extra == 20 else 0)
+    out["bench_line"] = {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}
+out["steps_in_trace"] = steps
+json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+for k, e in sorted(out["kernels"].items(), key=lambda kv: -(kv[1].get("fetch_bytes_total", 0) + kv[1].get("write_bytes_total", 0)))[:14]:
+    print(f"{k:28s} launches {e['launches_in_trace']:4d}  fetch {e.get('fetch_bytes_total', 0)/1e9/max(steps or 1,1):8.3f} GB  write {e.get('write_bytes_total', 0)/1e9/max(steps or 1,1):8.3f} GB per step")
