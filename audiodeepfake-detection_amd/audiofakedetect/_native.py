@@ -74,6 +74,9 @@ _SIGNATURES = {
     "afd_mfm_forward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_mfm_backward": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_gemm_nt": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
+    "afd_gemm_nt_bf16": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
+    "afd_conv2d_bf16_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "afd_conv2d_forward_bf16": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     "afd_lstm_cell": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_lstm_cell_backward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "afd_cross_entropy": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -59,17 +59,61 @@ def max_feature_map(x: torch.Tensor) -> torch.Tensor:
     return _MFM.apply(x)
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate: bool = False):
-    """out[M,N] (+)= a[M,K] @ b[N,K].T + bias; `a`/`out` may be row-strided views."""
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, bias=None, out=None, accumulate: bool = False,
+            bf16: bool = False):
+    """out[M,N] (+)= a[M,K] @ b[N,K].T + bias; `a`/`out` may be row-strided views.  ``bf16``: operands
+    rounded to bf16, fp32 accumulation (``afd_gemm_nt_bf16``)."""
     m, k = a.shape
     n = b.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.stride(1) == 1
-    _native.check(_native.load().afd_gemm_nt(
+    fn = _native.load().afd_gemm_nt_bf16 if bf16 else _native.load().afd_gemm_nt
+    _native.check(fn(
         _native.ptr(a), _native.ptr(b), _native.ptr(bias), _native.ptr(out), m, n, k, a.stride(0),
         b.stride(0), out.stride(0), 1 if accumulate else 0, _native.stream_ptr()), "afd_gemm_nt")
     return out
+
+
+def conv2d_bf16(x: torch.Tensor, w: torch.Tensor, b, padding: int, mfm: bool = False) -> torch.Tensor:
+    """conv2d(x, w, b, padding) with bf16 operands on the matrix cores (inference only: no autograd node);
+    ``mfm``: max-feature-map over the two channel halves applied in the epilogue (Cout / 2 channels out)."""
+    lib = _native.load()
+    x = ops._f32c(x)
+    w = ops._f32c(w)
+    n, cin, h, wd = x.shape
+    cout, _, k, _ = w.shape
+    ho, wo = h + 2 * padding - (k - 1), wd + 2 * padding - (k - 1)
+    y = torch.empty((n, cout // 2 if mfm else cout, ho, wo), dtype=torch.float32, device=x.device)
+    nbytes = lib.afd_conv2d_bf16_workspace_bytes(cin, cout, k)
+    ws = ops._ws(nbytes, x.device)
+    _native.check(lib.afd_conv2d_forward_bf16(
+        _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(y), n, cin, h, wd, cout, k, int(padding),
+        1 if mfm else 0, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_forward_bf16")
+    return y
+
+
+def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM) -> torch.Tensor:
+    """Inference forward of a bidirectional LSTM layer with bf16 projections (cell update in fp32)."""
+    lib = _native.load()
+    bsz, steps, d = x.shape
+    h = m.weight_hh_l0.shape[1]
+    xt = x.permute(1, 0, 2).contiguous().view(steps * bsz, d)
+    out = torch.empty((steps, bsz, 2 * h), dtype=torch.float32, device=x.device)
+    for direction, sfx in enumerate(("", "_reverse")):
+        wi, wh = getattr(m, "weight_ih_l0" + sfx), getattr(m, "weight_hh_l0" + sfx)
+        bias = getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)
+        pre = gemm_nt(xt, ops._f32c(wi), bias, bf16=True).view(steps, bsz, 4 * h)
+        hs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+        cs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+        whc = ops._f32c(wh)
+        for t in (range(steps) if direction == 0 else range(steps - 1, -1, -1)):
+            gates = pre[t]
+            gemm_nt(hs, whc, None, out=gates, accumulate=True, bf16=True)
+            hout = out[t, :, direction * h:(direction + 1) * h]
+            _native.check(lib.afd_lstm_cell(_native.ptr(gates), _native.ptr(cs), _native.ptr(hout),
+                                            _native.ptr(hs), bsz, h, 2 * h, _native.stream_ptr()), "afd_lstm_cell")
+    return out.permute(1, 0, 2).contiguous()
 
 
 class _BLSTM(torch.autograd.Function):
@@ -172,8 +216,14 @@ class BLSTMLayer(nn.Module):
 class LCNN(nn.Module):
     """Light CNN + 2 x BLSTM + Linear (reference models.py:68-131)."""
 
-    def __init__(self, classes: int = 2, in_channels: int = 1, lstm_channels: int = 256) -> None:
+    def __init__(self, classes: int = 2, in_channels: int = 1, lstm_channels: int = 256,
+                 precision: str = "fp32") -> None:
         super().__init__()
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        # "bf16": matrix products of the evaluation forward on the bf16 matrix cores (BASELINE configs[4]);
+        # parameters, BatchNorm, max-feature-map, the LSTM cell and training stay fp32
+        self.precision = precision
         # (cin, cout, k, pad, pooled, bn channels or 0)
         spec = ((in_channels, 64, 5, 2, True, 0), (32, 64, 1, 0, False, 32), (32, 96, 3, 1, True, 48),
                 (48, 96, 1, 0, False, 48), (48, 128, 3, 1, True, 0), (64, 128, 1, 0, False, 64),
@@ -202,10 +252,18 @@ class LCNN(nn.Module):
         if not h.is_contiguous():
             h = ops.transpose_contiguous(x.contiguous())
         net = self.lcnn
+        bf16 = self.precision == "bf16"
+        if bf16 and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("LCNN(precision='bf16') is the evaluation path: call it under torch.no_grad() "
+                               "(training runs in fp32)")
         for conv_i, pooled, bn_i in self._plan:
             conv = net[conv_i]
-            h = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
-            h = max_feature_map(h)
+            if bf16:
+                # convolution + max-feature-map in one launch: the full-width output is never written
+                h = conv2d_bf16(h, conv.weight, conv.bias, conv.padding[0], mfm=True)
+            else:
+                h = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0])
+                h = max_feature_map(h)
             if pooled:
                 h = ops.prelu_maxpool2x2(h, None)
             if bn_i is not None:
@@ -213,7 +271,7 @@ class LCNN(nn.Module):
         h = ops.dropout_permute(h, net[-1].p, self.training)  # [B, T', C, W']
         h = h.reshape(h.shape[0], h.shape[1], -1)
         for layer in self.lstm:
-            h = layer(h)
+            h = blstm_forward_bf16(ops._f32c(h), layer.l_blstm) if bf16 else layer(h)
         return ops.linear_mean(h, self.fc.weight, self.fc.bias)
 
     def get_name(self) -> str:

@@ -61,6 +61,8 @@ WORKLOADS = {
     # BASELINE configs[4]: evaluation (forward + argmax) of the LCNN head on STFT features
     "stft-lcnn-eval": ("stft", "none", 256, 0, "eval", "STFT(n_fft 511, hop 220) + LCNN eval forward (fp32)"),
     "stft-lcnn": ("stft", "none", 256, 0, "train", "STFT(n_fft 511, hop 220) + LCNN train step (fp32)"),
+    # BASELINE configs[4] at its stated precision: matrix products of the evaluation forward on the bf16 cores
+    "stft-lcnn-eval-bf16": ("stft", "none", 256, 0, "eval", "STFT(n_fft 511, hop 220) + LCNN eval forward (bf16 matrix products)"),
     # front end alone (BASELINE configs[3] is the Haar one at B = 4096)
     "haar-l14-frontend": ("packets", "haar", 16384, 0, "frontend", "packets-haar level-14 front end only"),
     "coif4-l14-frontend": ("packets", "coif4", 16384, 0, "frontend", "packets-coif4 level-14 front end only"),
@@ -142,7 +144,8 @@ def build(workload: str, batch: int, ddp: bool, device):
     if "lcnn" in workload:
         from audiofakedetect.lcnn import LCNN
 
-        model = LCNN(classes=2, in_channels=1, lstm_channels=scales).to(device)
+        model = LCNN(classes=2, in_channels=1, lstm_channels=scales,
+                     precision="bf16" if workload.endswith("bf16") else "fp32").to(device)
     else:
         model = DCNN(args).to(device)
     opt = ops.FusedAdam(model.parameters(), lr=args.learning_rate, weight_decay=args.weight_decay)
@@ -473,7 +476,8 @@ def main() -> None:
         line = {
             "metric": METRIC, "value": world * batch_size * a.steps / elapsed, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if a.workload.endswith("bf16") else "f32",
             "data": "synthetic",
             "config": {"workload": WORKLOADS[a.workload][5], "batch_per_gpu": batch_size,
                        "global_batch": batch_size * world, "frame": "1s@22050Hz mono f32",

@@ -288,6 +288,20 @@ int afd_gemm_nt(const float* A, const float* B, const float* bias, float* C, int
                 int lda, int ldb, int ldc, int accumulate, afd_stream_t stream);
 int afd_lstm_cell(const float* gates, float* c, float* hout, float* hstate, int B, int H, int ldh,
                   afd_stream_t stream);
+/* bf16 matrix-core path of the LCNN evaluation forward (BASELINE.json configs[4]; the reference runs the same
+ * layers of models.py:68-131 under autocast): operands rounded to bf16, fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, fp32 tensors in memory.
+ * afd_conv2d_forward_bf16: y = conv2d(x, w) + bias, stride 1, dilation 1, K in {1, 3, 5}, Cout <= 128;
+ *                          mfm != 0 fuses MaxFeatureMap2D (models.py:203-209): y [N][Cout/2][Ho][Wo] =
+ *                          max over the two channel halves; ws (afd_conv2d_bf16_workspace_bytes)
+ *                          receives the bf16 weight image.
+ * afd_gemm_nt_bf16       : afd_gemm_nt with bf16 operands. */
+size_t afd_conv2d_bf16_workspace_bytes(int Cin, int Cout, int K);
+int afd_conv2d_forward_bf16(const float* x, const float* w, const float* bias /* may be NULL */, float* y,
+                            int N, int Cin, int H, int W, int Cout, int K, int pad, int mfm, void* ws,
+                            size_t ws_bytes, afd_stream_t stream);
+int afd_gemm_nt_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
+                     int lda, int ldb, int ldc, int accumulate, afd_stream_t stream);
 /* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):
  * gates = saved pre-activation sums [B][4H] of the step, c / cprev = cell state after / before it
  * (cprev NULL = zero), dh = gradient reaching h_t (row stride lddh), dc = running cell-state

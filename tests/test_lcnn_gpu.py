@@ -50,6 +50,85 @@ def test_lcnn_eval_logits_match_reference():
     assert torch.equal(y.argmax(-1).cpu(), g["labels"])
 
 
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,h,w", [(1, 64, 5, 2, 21, 70), (32, 96, 3, 1, 13, 37), (48, 128, 3, 1, 9, 64),
+                                                (64, 128, 1, 0, 12, 32), (32, 64, 3, 1, 12, 32)])
+def test_conv2d_bf16_matches_bf16_rounded_reference(cin, cout, k, pad, h, w):
+    """afd_conv2d_forward_bf16: operands rounded to bf16 (RNE), fp32 accumulation.  Against float64 on the
+    SAME rounded operands the only error is the accumulation order (1e-5 of the largest output); against
+    the unrounded fp32 convolution it is the bf16 rounding itself (stated bar 2e-2 of the largest output)."""
+    from audiofakedetect.lcnn import conv2d_bf16
+
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    x = torch.randn(3, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    got = conv2d_bf16(x.cuda(), wt.cuda(), b.cuda(), pad).cpu().double()
+    ref_r = torch.nn.functional.conv2d(_bf16_round(x), _bf16_round(wt), b.double(), padding=pad)
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), padding=pad)
+    assert got.shape == ref.shape
+    scale = ref.abs().max().item()
+    assert (got - ref_r).abs().max().item() <= 1e-5 * scale
+    assert (got - ref).abs().max().item() <= 2e-2 * scale
+    # max-feature-map fused into the epilogue (reference models.py:203-209)
+    fused = conv2d_bf16(x.cuda(), wt.cuda(), b.cuda(), pad, mfm=True).cpu().double()
+    want = ref_r.reshape(3, 2, cout // 2, *ref_r.shape[2:]).max(1)[0]
+    assert fused.shape == want.shape and (fused - want).abs().max().item() <= 1e-5 * scale
+
+
+def test_gemm_nt_bf16():
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(200, 300, generator=g)
+    b = torch.randn(130, 300, generator=g)
+    bias = torch.randn(130, generator=g)
+    ref_r = _bf16_round(a) @ _bf16_round(b).t() + bias.double()
+    got = gemm_nt(a.cuda(), b.cuda(), bias.cuda(), bf16=True)
+    assert (got.cpu().double() - ref_r).abs().max().item() <= 1e-5 * ref_r.abs().max().item()
+    got2 = gemm_nt(a.cuda(), b.cuda(), None, out=got.clone(), accumulate=True, bf16=True)
+    assert (got2.cpu().double() - (2 * ref_r - bias.double())).abs().max().item() <= 2e-5 * ref_r.abs().max().item()
+
+
+def test_lcnn_bf16_eval_labels_and_logits():
+    """BASELINE configs[4] precision: LCNN(precision="bf16") evaluation forward.  Bars (stated up front):
+    class labels bit-exact on the reference fixture; logits within 3e-2 of the largest fp32 logit magnitude
+    of the fixture (bf16 has 8 significant bits; nine convolutions, two BLSTM layers); the fp32 path of the
+    same module stays within 1e-4."""
+    from recipes import fill_state_dict
+
+    g = torch.load(os.path.join(GOLD, "dcnn_lcnn_eval.pt"), map_location="cpu")
+    net = LCNN(precision="bf16")
+    net.load_state_dict(fill_state_dict(g["shapes"]), strict=True)
+    net.cuda().eval()
+    with torch.no_grad():
+        y = net(g["x"].cuda())
+        net.precision = "fp32"
+        y32 = net(g["x"].cuda())
+    assert (y32.cpu() - g["logits"]).abs().max().item() <= 1e-4
+    err = (y.cpu() - g["logits"]).abs().max().item()
+    assert err <= 3e-2 * g["logits"].abs().max().item(), err
+    assert torch.equal(y.argmax(-1).cpu(), g["labels"])
+    # training in bf16 is not built: the module says so instead of silently running fp32
+    net.precision = "bf16"
+    net.train()
+    with pytest.raises(RuntimeError):
+        net(g["x"].cuda())
+    # a batch of 128 random frames: labels of the bf16 and fp32 paths agree wherever the fp32 margin is
+    # larger than the bf16 error bar
+    net.eval()
+    x = torch.randn(128, 1, 256, 101, generator=torch.Generator().manual_seed(9)).cuda()
+    with torch.no_grad():
+        yb = net(x)
+        net.precision = "fp32"
+        yf = net(x)
+    bar = 3e-2 * yf.abs().max().item()
+    assert (yb - yf).abs().max().item() <= bar
+    sure = (yf[:, 0] - yf[:, 1]).abs() > 2 * bar
+    assert torch.equal(yb.argmax(-1)[sure], yf.argmax(-1)[sure])
+
+
 def test_blstm_layer_forward_backward_matches_nn_lstm():
     # BLSTMLayer (reference models.py:212-237) = bidirectional nn.LSTM over [T, B, D] seen as
     # [B, T, D]; float64 torch on the CPU is the reference
