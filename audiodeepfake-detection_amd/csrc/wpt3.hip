@@ -87,8 +87,8 @@ struct T3Params {
     int B, N, Ks;
     int n[kKsMax + 1];
     int off[kKsMax + 1];    // LDS offset (floats) of level k's image; sample 0 of node 0 at off + L - 2
-    int pitch[kKsMax + 1];  // node pitch (floats): even, pitch / 2 odd
-    unsigned magic[kKsMax + 1];  // floor(2^32 / n[k]) + 1
+    int pitch[kKsMax + 1];  // node pitch (floats): pitch / 4 odd (16-byte aligned nodes, node-strided reads conflict-free)
+    unsigned magic[kKsMax + 1];  // floor(2^32 / m) + 1, m = (n[k] + 1) / 2 output pairs per node
     Epi e;
     float rlo[kMaxTaps], rhi[kMaxTaps];  // taps reversed: rlo[t] = dec_lo[L - 1 - t]
 };
@@ -98,38 +98,38 @@ template <int L>
 __device__ __forceinline__ void put(float* node, int i, int n, float v) {
     constexpr int PAD = L - 2;
     node[i] = v;
-    if (i >= 1 && i <= PAD) node[-i] = v;
-    const int j = n - 1 - i;
-    if (j >= 1 && j <= PAD + (n & 1)) node[n - 1 + j] = v;
+    if ((unsigned)(i - 1) < (unsigned)PAD) node[-i] = v;
+    if ((unsigned)(n - 2 - i) < (unsigned)(PAD + (n & 1))) node[2 * (n - 1) - i] = v;
 }
 
+// A work item is a PAIR of neighbouring outputs (i, i + 1), i even: their windows share L - 2 of L samples,
+// so the item reads L + 2 samples as 16-byte vectors (7 ds_read_b128 for 24 taps, lanes 16 bytes apart:
+// conflict-free) and both filters run over registers.
 template <int L>
-__device__ __forceinline__ void dot_both(const T3Params& p, const float* __restrict__ src, float& ca, float& cd) {
-    const f2* s2 = reinterpret_cast<const f2*>(src);
-    f2 accA = {0.f, 0.f}, accD = {0.f, 0.f};
+struct Window {
+    static constexpr int NV = (L + 2 + 3) / 4;
+    float w[4 * NV];
+    __device__ __forceinline__ void load(const float* __restrict__ src) {
+        const f4* s4 = reinterpret_cast<const f4*>(src);
 #pragma unroll
-    for (int t = 0; t < L / 2; ++t) {
-        const f2 xv = s2[t];
-        const f2 tl = {p.rlo[2 * t], p.rlo[2 * t + 1]};
-        const f2 th = {p.rhi[2 * t], p.rhi[2 * t + 1]};
-        accA = __builtin_elementwise_fma(tl, xv, accA);
-        accD = __builtin_elementwise_fma(th, xv, accD);
+        for (int v = 0; v < NV; ++v) {
+            const f4 x = s4[v];
+            w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+        }
     }
-    ca = accA.x + accA.y;
-    cd = accD.x + accD.y;
-}
-
-template <int L, bool HI>
-__device__ __forceinline__ float dot_one(const T3Params& p, const float* __restrict__ src) {
-    const f2* s2 = reinterpret_cast<const f2*>(src);
-    f2 acc = {0.f, 0.f};
+    // filter `taps` (reversed) at output i (O = 0) or i + 1 (O = 1)
+    template <int O>
+    __device__ __forceinline__ float dot(const float* taps) const {
+        f2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < L / 2; ++t) {
-        const f2 tp = {HI ? p.rhi[2 * t] : p.rlo[2 * t], HI ? p.rhi[2 * t + 1] : p.rlo[2 * t + 1]};
-        acc = __builtin_elementwise_fma(tp, s2[t], acc);
+        for (int t = 0; t < L / 2; ++t) {
+            const f2 tp = {taps[2 * t], taps[2 * t + 1]};
+            const f2 xv = {w[2 * t + 2 * O], w[2 * t + 1 + 2 * O]};
+            acc = __builtin_elementwise_fma(tp, xv, acc);
+        }
+        return acc.x + acc.y;
     }
-    return acc.x + acc.y;
-}
+};
 
 // FIN: -1 = the level-Ks image is a hand-off to the deep kernel (no epilogue), else the epilogue mode
 template <int L, int FIN>
@@ -148,15 +148,17 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         if ((p.N & 1) == 0) {
             const float2* xv = reinterpret_cast<const float2*>(xg);  // frames are 8-byte aligned
             const int n2 = p.N >> 1;
-            for (int base = 0; base < n2; base += kTopThreads * 8) {
-                float2 v[8];
+            // 11 loads in flight per thread: the 22 050-sample frame arrives in ONE round of memory latency
+            constexpr int UN = 11;
+            for (int base = 0; base < n2; base += kTopThreads * UN) {
+                float2 v[UN];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     const int i = base + u * kTopThreads + tid;
                     v[u] = i < n2 ? xv[i] : make_float2(0.f, 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < UN; ++u) {
                     const int i = base + u * kTopThreads + tid;
                     if (i < n2) *reinterpret_cast<float2*>(X0 + 2 * i) = v[u];
                 }
@@ -176,10 +178,12 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         const float* src = lds + p.off[0];
         float* node = lds + p.off[1] + PAD;
         const int n1 = p.n[1];
-        if (h) {
-            for (int i = tid; i < n1; i += kTopThreads) put<L>(node, i, n1, dot_one<L, true>(p, src + 2 * i));
-        } else {
-            for (int i = tid; i < n1; i += kTopThreads) put<L>(node, i, n1, dot_one<L, false>(p, src + 2 * i));
+        const float* taps = h ? p.rhi : p.rlo;
+        for (int j = tid; 2 * j < n1; j += kTopThreads) {
+            Window<L> win;
+            win.load(src + 4 * j);
+            put<L>(node, 2 * j, n1, win.template dot<0>(taps));
+            if (2 * j + 1 < n1) put<L>(node, 2 * j + 1, n1, win.template dot<1>(taps));
         }
     }
     __syncthreads();
@@ -188,7 +192,8 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
     for (int k = 2; k < p.Ks; ++k) {
         const int Mp = 1 << (k - 2);  // parents (nodes of level k-1 in this half)
         const int nk = p.n[k];
-        const int total = Mp * nk;
+        const int mk = (nk + 1) >> 1;  // items (output pairs) per node
+        const int total = Mp * mk;
         const float* src0 = lds + p.off[k - 1];
         float* dst0 = lds + p.off[k] + PAD;
         const int pin = p.pitch[k - 1], pout = p.pitch[k];
@@ -196,23 +201,31 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         const int padr = PAD + (nk & 1);
         for (int idx = tid; idx < total; idx += kTopThreads) {
             const int q = (int)__umulhi((unsigned)idx, magic);
-            const int i = idx - q * nk;
-            float ca, cd;
-            dot_both<L>(p, src0 + q * pin + 2 * i, ca, cd);
+            const int i = 2 * (idx - q * mk);
+            Window<L> win;
+            win.load(src0 + q * pin + 2 * i);
+            const float ca0 = win.template dot<0>(p.rlo), cd0 = win.template dot<0>(p.rhi);
+            const float ca1 = win.template dot<1>(p.rlo), cd1 = win.template dot<1>(p.rhi);
             // odd-frequency parents list their children (d, a)
             const int par = (k == 2) ? h : (q & 1);
             float* na = dst0 + (2 * q + par) * pout;
             float* nd = dst0 + (2 * q + 1 - par) * pout;
-            na[i] = ca;
-            nd[i] = cd;
-            // the L-2 coefficients next to a border also fill the pad slots that mirror them
-            if ((unsigned)(i - 1) < (unsigned)PAD) {
-                na[-i] = ca;
-                nd[-i] = cd;
+            const bool two = i + 1 < nk;
+            if (two) {
+                *reinterpret_cast<f2*>(na + i) = f2{ca0, ca1};
+                *reinterpret_cast<f2*>(nd + i) = f2{cd0, cd1};
+            } else {
+                na[i] = ca0;
+                nd[i] = cd0;
             }
-            if ((unsigned)(nk - 2 - i) < (unsigned)padr) {
-                na[2 * (nk - 1) - i] = ca;
-                nd[2 * (nk - 1) - i] = cd;
+            // the L-2 coefficients next to a border also fill the pad slots that mirror them
+            if (i <= PAD) {
+                if (i >= 1) { na[-i] = ca0; nd[-i] = cd0; }
+                if (two && i + 1 <= PAD) { na[-i - 1] = ca1; nd[-i - 1] = cd1; }
+            }
+            if (nk - 2 - i < padr + 1) {
+                if ((unsigned)(nk - 2 - i) < (unsigned)padr) { na[2 * (nk - 1) - i] = ca0; nd[2 * (nk - 1) - i] = cd0; }
+                if (two && (unsigned)(nk - 3 - i) < (unsigned)padr) { na[2 * (nk - 1) - i - 1] = ca1; nd[2 * (nk - 1) - i - 1] = cd1; }
             }
         }
         __syncthreads();
@@ -224,7 +237,7 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         const int logM = k - 2;  // parents in this half: 2^(k-2)
         const int Mp = 1 << logM;
         const int nk = p.n[k];
-        const int total = nk << logM;
+        const int total = ((nk + 1) >> 1) << logM;
         const float* src0 = lds + p.off[k - 1];
         const int pin = p.pitch[k - 1];
         const size_t P = (size_t)1 << k;
@@ -233,26 +246,33 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         float* outb = p.dst + (size_t)b * nch * chan;
         for (int idx = tid; idx < total; idx += kTopThreads) {
             const int q = idx & (Mp - 1);
-            const int i = idx >> logM;
-            float ca, cd;
-            dot_both<L>(p, src0 + q * pin + 2 * i, ca, cd);
-            const int par = (k == 2) ? h : (q & 1);
-            f2 v;
-            v.x = par ? cd : ca;
-            v.y = par ? ca : cd;
-            const size_t o = (size_t)i * P + 2 * ((size_t)(h << logM) + q);
-            if (FIN < 0) {
-                *reinterpret_cast<f2*>(outb + o) = v;
-            } else {
-                f2 r;
-                r.x = epi_value<(FIN < 0 ? 0 : FIN)>(v.x, p.e);
-                r.y = epi_value<(FIN < 0 ? 0 : FIN)>(v.y, p.e);
-                *reinterpret_cast<f2*>(outb + o) = r;
-                if (p.e.flags & AFD_WPT_SIGN) {
-                    f2 sg;
-                    sg.x = v.x < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
-                    sg.y = v.y < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
-                    *reinterpret_cast<f2*>(outb + chan + o) = sg;
+            const int i = 2 * (idx >> logM);
+            Window<L> win;
+            win.load(src0 + q * pin + 2 * i);
+            const int par = (k == 2) ? h : (q & 1);  // odd-frequency parents list their children (d, a)
+            float* o = outb + (size_t)i * P + 2 * ((size_t)(h << logM) + q);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (i + u < nk) {
+                    const float ca = u ? win.template dot<1>(p.rlo) : win.template dot<0>(p.rlo);
+                    const float cd = u ? win.template dot<1>(p.rhi) : win.template dot<0>(p.rhi);
+                    f2 v;
+                    v.x = par ? cd : ca;
+                    v.y = par ? ca : cd;
+                    if (FIN < 0) {
+                        *reinterpret_cast<f2*>(o + u * P) = v;
+                    } else {
+                        f2 r;
+                        r.x = epi_value<(FIN < 0 ? 0 : FIN)>(v.x, p.e);
+                        r.y = epi_value<(FIN < 0 ? 0 : FIN)>(v.y, p.e);
+                        *reinterpret_cast<f2*>(o + u * P) = r;
+                        if (p.e.flags & AFD_WPT_SIGN) {
+                            f2 sg;
+                            sg.x = v.x < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                            sg.y = v.y < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                            *reinterpret_cast<f2*>(o + chan + u * P) = sg;
+                        }
+                    }
                 }
             }
         }
@@ -649,18 +669,19 @@ bool plan_top(T3Params& p, int L) {
     const int PAD = L - 2;
     long size[kKsMax + 1];
     for (int k = 0; k <= p.Ks; ++k) {
-        int pitch = p.n[k] + 2 * PAD + 2;
-        while (pitch % 4 != 2) ++pitch;  // even, and pitch / 2 odd: node-strided b64 reads hit distinct banks
+        // node = [L-2 left pad | n samples | L-2 (+1) right pad | up to 3 floats an odd node's last item reads]
+        int pitch = p.n[k] + 2 * PAD + 5;
+        while (pitch % 8 != 4) ++pitch;  // 16-byte aligned nodes; pitch / 4 odd: node-strided b128 reads hit distinct banks
         p.pitch[k] = pitch;
         const long nodes = k == 0 ? 1 : (1L << (k - 1));
         size[k] = nodes * pitch;
-        p.magic[k] = (unsigned)(0x100000000ULL / (unsigned)p.n[k]) + 1u;
+        p.magic[k] = (unsigned)(0x100000000ULL / (unsigned)((p.n[k] + 1) / 2)) + 1u;
     }
     // images alternate between the two ends of the carve; the last level is never stored
     for (int k = 0; k < p.Ks; ++k) {
         if (size[k] > kTopLdsFloats) return false;
         if (k + 1 < p.Ks && size[k] + size[k + 1] > kTopLdsFloats) return false;
-        p.off[k] = (k & 1) ? (int)((kTopLdsFloats - size[k]) & ~1L) : 0;
+        p.off[k] = (k & 1) ? (int)((kTopLdsFloats - size[k]) & ~3L) : 0;
     }
     p.off[p.Ks] = 0;
     return true;
