@@ -396,6 +396,27 @@ __device__ __forceinline__ void step_tile(const float (&a)[KP], int mt, int kst,
 }
 
 // fragments of row tile mt: KP floats per lane, KP % 4 == 0; table [mt][KP / 4][lane][4]
+// 4 x 4 transpose inside every quad of lanes: on return register i of lane j (j = lane & 3) holds what
+// register j of lane i held.  Two exchange stages (lane ^ 1, lane ^ 2) over DPP quad permutes -- vector
+// ALU work, which runs beside the f32 matrix instructions at no measurable cost (tools/micro).
+__device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2, float& v3, int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    auto xchg = [](float keep_lo, float keep_hi, bool hi, int ctrl_is_2, float& out_lo, float& out_hi) {
+        const float send = hi ? keep_lo : keep_hi;
+        const int si = __builtin_bit_cast(int, send);
+        const int ri = ctrl_is_2 ? __builtin_amdgcn_mov_dpp(si, 0x4E, 0xF, 0xF, true)   // quad_perm [2,3,0,1]
+                                 : __builtin_amdgcn_mov_dpp(si, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+        const float recv = __builtin_bit_cast(float, ri);
+        out_lo = hi ? recv : keep_lo;
+        out_hi = hi ? keep_hi : recv;
+    };
+    float a0, a1, a2, a3;
+    xchg(v0, v1, b0, 0, a0, a1);
+    xchg(v2, v3, b0, 0, a2, a3);
+    xchg(a0, a2, b1, 1, v0, v2);
+    xchg(a1, a3, b1, 1, v1, v3);
+}
+
 template <int KP>
 __device__ __forceinline__ void load_frags(float (&a)[KP], const float* tab, int mt, int lane) {
     const f4* t = reinterpret_cast<const f4*>(tab) + (size_t)mt * (KP / 4) * 64 + lane;
@@ -443,9 +464,11 @@ wpt3_deep_kernel(const D3Params p) {
 
     // composite phase: wave = (half of the row tiles, two of the eight 32-column tiles).  The node image is
     // the A operand and the matrix fragment the B operand, i.e. the wave computes the TRANSPOSED tile
-    // D[node][row]: a lane then owns one composite row (time, packet offset) and its 16 registers are 16
-    // nodes, so one store instruction writes, for a fixed register, 16 consecutive packets of a node from
-    // 16 consecutive lanes -- whole 64-byte lines (four per instruction) instead of 64 quarter lines.
+    // D[node][row]: a lane owns one composite row (time, packet offset f) and its 16 registers are 16 nodes.
+    // Four registers (nodes 8g + {0..3}) are then transposed inside the lane quads (packet offsets 4a + {0..3}),
+    // after which lane j of a quad holds four consecutive packets of node 8g + j: one 16-byte store per lane,
+    // the four quads of a 16-lane group complete the node's 64-byte line -- a store instruction writes 16
+    // whole lines (cost inside an f32 matrix stream goes by the lines touched, tools/micro).
     constexpr int KS3 = D::KS3, T3 = D::T3, TH = (T3 + 1) / 2;
     const int rh = wave & 1, cp = wave >> 1;
     const int half = lane >> 5, col = lane & 31;
@@ -500,10 +523,12 @@ wpt3_deep_kernel(const D3Params p) {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             // registers q of this lane are nodes 8 (q >> 2) + 4 half + (q & 3) of the column tile
-            float* oute = p.out + (size_t)b * (SIGN ? 2 : 1) * chan +
-                          (size_t)16 * (grp * 256 + 32 * (2 * cp + c) + 4 * half) + (size_t)lane_t * P;
-            float* outo = oute + (15 - lane_f);
-            oute += lane_f;
+            // after the quad transpose: this lane writes packets 4a .. 4a + 3 (a = lane_f >> 2) of node
+            // 8g + (lane & 3) + 4 half; an odd-frequency node's packets come out reversed (15 - f)
+            const int qj = lane & 3, qa = lane_f >> 2;
+            float* outq = p.out + (size_t)b * (SIGN ? 2 : 1) * chan +
+                          (size_t)16 * (grp * 256 + 32 * (2 * cp + c) + 4 * half + qj) + (size_t)lane_t * P +
+                          ((qj & 1) ? 12 - 4 * qa : 4 * qa);
 #pragma unroll
             for (int r = 0; r < TH; ++r) {
                 const int rt = rt0 + r;
@@ -516,12 +541,22 @@ wpt3_deep_kernel(const D3Params p) {
                         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][s], fa[r][s], acc, 0, 0, 0);
                     const size_t trow = (size_t)(2 * rt) * P;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int node = 8 * (q >> 2) + (q & 3);  // + 4 half: inside oute / outo
-                        const float v = acc[q];
-                        float* o = ((q & 1) ? outo : oute) + trow + 16 * node;
-                        *o = epi_value<MODE>(v, p.e);
-                        if (SIGN) o[chan] = v < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                    for (int g = 0; g < 4; ++g) {
+                        float v0 = acc[4 * g], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+                        quad_transpose4(v0, v1, v2, v3, lane);
+                        const bool odd = qj & 1;
+                        const float w0 = odd ? v3 : v0, w1 = odd ? v2 : v1, w2 = odd ? v1 : v2, w3 = odd ? v0 : v3;
+                        float* o = outq + trow + 16 * 8 * g;
+                        f4 w;
+                        w.x = epi_value<MODE>(w0, p.e); w.y = epi_value<MODE>(w1, p.e);
+                        w.z = epi_value<MODE>(w2, p.e); w.w = epi_value<MODE>(w3, p.e);
+                        *reinterpret_cast<f4*>(o) = w;
+                        if (SIGN) {
+                            f4 sg;
+                            sg.x = w0 < 0.f ? p.e.sgn_neg : p.e.sgn_pos; sg.y = w1 < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                            sg.z = w2 < 0.f ? p.e.sgn_neg : p.e.sgn_pos; sg.w = w3 < 0.f ? p.e.sgn_neg : p.e.sgn_pos;
+                            *reinterpret_cast<f4*>(o + chan) = sg;
+                        }
                     }
                 }
             }
