@@ -44,13 +44,15 @@ struct HaarParams {
     int B;
     unsigned flags;
     float eps, mean, inv_std, scale, sgn_neg, sgn_pos;
+    float scale2, k1, k0;  // scale^2; ln 2 / std (or scale / std without the log); -mean / std
 };
 
+// (1/sqrt 2)^14 scale, log(v^2 + eps) and (x - mean) / std in three instructions per coefficient:
+// log2((v s^2) v + eps) * (ln 2 / std) - mean / std -- the kernel is bound by its vector instructions
+// (75 % issue occupancy measured), not by HBM
 __device__ __forceinline__ float haar_epilogue(float v, const HaarParams& p) {
-    v *= p.scale;
-    if (p.flags & AFD_WPT_LOG) v = __builtin_amdgcn_logf(fmaf(v, v, p.eps)) * 0.6931471805599453f;
-    if (p.flags & AFD_WPT_NORM) v = (v - p.mean) * p.inv_std;
-    return v;
+    if (p.flags & AFD_WPT_LOG) return fmaf(__builtin_amdgcn_logf(fmaf(v * p.scale2, v, p.eps)), p.k1, p.k0);
+    return fmaf(v, p.k1, p.k0);
 }
 
 // registers -> leaves.  `s` is +1 when the node's frequency index is even (first child =
@@ -108,18 +110,10 @@ __device__ __forceinline__ void quad_transpose(float (&v)[16], int lane) {
     }
 }
 
-// The four samples feeding element i of a node's grandchildren are x[4i .. 4i+3], except for
-// the last element of an odd-length node, where the reflect rule (twice: at the node and at
-// its children) gives, for n = 4k + 1, (x[n-1], x[n-2], x[n-3], x[n-2]) and, for n = 4k + 3,
-// (x[n-3], x[n-2], x[n-1], x[n-2]).  Selects instead of branches: every LDS read of a pass is
-// issued before the first is used.  `before` = x[4i-2], x[4i-1] (only read when n = 4k + 1).
-template <int n>
-__device__ __forceinline__ float4 fix_tail(const float4 v, const float2 before, bool last) {
-    if (n % 4 == 1) return last ? make_float4(v.x, before.y, before.x, before.y) : v;
-    static_assert(n % 4 == 1 || n % 4 == 3, "node length");
-    return last ? make_float4(v.x, v.y, v.z, v.y) : v;
-}
-
+// The four samples feeding element i of a node's grandchildren are x[4i .. 4i+3]; for the last element of an
+// odd-length node the reflect rule (twice: at the node and at its children) gives, for n = 4k + 1,
+// (x[n-1], x[n-2], x[n-3], x[n-2]) and, for n = 4k + 3, (x[n-3], x[n-2], x[n-1], x[n-2]): the slots past the
+// node end hold exactly those mirrored samples (write_tail_pads), so every element is a plain butterfly.
 // element i of the grandchildren 4F .. 4F+3 of a node with frequency parity `odd`
 __device__ __forceinline__ float4 butterfly4(const float4 x, bool odd) {
     const float s = odd ? -1.f : 1.f;
@@ -129,6 +123,31 @@ __device__ __forceinline__ float4 butterfly4(const float4 x, bool odd) {
 }
 
 // one radix-4 pass: levels LEV -> LEV + 2 for the 2^(LEV-1) nodes of the half, in place
+// Reflect pads of the nodes of a level (length n, slot `cap`, `nodes` of them): the last radix-4 element of an
+// odd-length node reads x[4i .. 4i+3] past the node end; with the mirrored samples stored there -- n = 4k + 1:
+// (x[n-2], x[n-3], x[n-2]) at n .. n+2; n = 4k + 3: x[n-2] at n -- every element of the pass is the plain
+// butterfly of four consecutive slots (no per-element tail selects in the vector-instruction-bound passes).
+template <int n, int cap, int nodes>
+__device__ __forceinline__ void write_tail_pads(float* buf, int tid) {
+    static_assert(nodes <= kThreads, "one thread per node");
+    if (n % 4 == 1) {
+        static_assert(n % 4 != 1 || n + 3 <= cap, "pad slots");
+        if (tid < nodes) {
+            float* x = buf + tid * cap;
+            const float a = x[n - 2], b = x[n - 3];
+            x[n] = a;
+            x[n + 1] = b;
+            x[n + 2] = a;
+        }
+    } else if (n % 4 == 3) {
+        static_assert(n % 4 != 3 || n + 1 <= cap, "pad slot");
+        if (tid < nodes) {
+            float* x = buf + tid * cap;
+            x[n] = x[n - 2];
+        }
+    }
+}
+
 template <int LEV>
 __device__ __forceinline__ void lds_pass(float* buf, int tid) {
     constexpr int M = 1 << (LEV - 1);
@@ -138,16 +157,14 @@ __device__ __forceinline__ void lds_pass(float* buf, int tid) {
     static_assert(total <= kItems * kThreads && kLen[2] <= kLoadItems * kThreads,
                   "pass does not fit the register staging");
     static_assert(n_gc <= capOut && 4 * n_gc <= capIn, "slot capacity");
-    constexpr int n_in = kLen[LEV];
+    static_assert(kLen[LEV] % 2 == 1, "the tail pads cover odd node lengths (all pass inputs of N = 22050)");
     float4 v[kItems];
-    float2 e[kItems];
 #pragma unroll
     for (int r = 0; r < kItems; ++r) {
         int w = r * kThreads + tid;
         w = w < total ? w : total - 1;
         const int q = w / n_gc, i = w - q * n_gc;
         v[r] = *reinterpret_cast<const float4*>(buf + q * capIn + 4 * i);
-        if (n_in % 4 == 1) e[r] = *reinterpret_cast<const float2*>(buf + q * capIn + (i ? 4 * i - 2 : 0));
     }
     __syncthreads();
 #pragma unroll
@@ -155,7 +172,7 @@ __device__ __forceinline__ void lds_pass(float* buf, int tid) {
         const int w = r * kThreads + tid;
         if (w < total) {
             const int q = w / n_gc, i = w - q * n_gc;
-            const float4 g = butterfly4(fix_tail<n_in>(v[r], e[r], i == n_gc - 1), q & 1);
+            const float4 g = butterfly4(v[r], q & 1);
             float* o = buf + q * capIn + i;
             o[0] = g.x;
             o[capOut] = g.y;
@@ -164,6 +181,11 @@ __device__ __forceinline__ void lds_pass(float* buf, int tid) {
         }
     }
     __syncthreads();
+    // the grandchildren are the next reader's nodes: their reflect pads
+    if (n_gc % 2 == 1) {
+        write_tail_pads<n_gc, capOut, 4 * M>(buf, tid);
+        __syncthreads();
+    }
 }
 
 // Items [R0, R1) of the frame load: x[4i .. 4i+3] for the level-2 element i; the last element
@@ -241,6 +263,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
         const float* xn = p.x + (size_t)(nb < p.B ? nb : b) * kN;
         float2 lo[kLoadItems], hi[kLoadItems], nxt[kLoadItems];
         load_items<0, 4>(xn, lt, lo, hi);
+        write_tail_pads<kLen[2], kCap2, 2>(buf, lt);  // level-2 image of this frame (written before the last barrier)
+        __syncthreads();
         lds_pass<2>(buf, lt);
         level2_items<0, 4>(lo, hi, lt, half, nxt);
         load_items<4, 8>(xn, lt, lo, hi);
@@ -264,9 +288,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
 #pragma unroll
                 for (int k = 0; k < 11; ++k) {
                     const int i = 11 * h + k;
-                    // 87 samples: level-9 element 43 is the reflected pair (86, 85)
-                    const float4 xv = fix_tail<87>(*reinterpret_cast<const float4*>(nd + 4 * i),
-                                                   make_float2(0.f, 0.f), i == 21);
+                    // 87 samples: level-9 element 43 is the reflected pair (86, 85) -- slot 87 holds x[85]
+                    const float4 xv = *reinterpret_cast<const float4*>(nd + 4 * i);
                     v10[i] = fmaf(sg10, fmaf(sg9, xv.w, xv.z), fmaf(sg9, xv.y, xv.x));
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -349,6 +372,13 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     p.sgn_neg = (flags & AFD_WPT_NORM) ? (-1.f - sign_mean) / sign_std : -1.f;
     p.sgn_pos = (flags & AFD_WPT_NORM) ? (1.f - sign_mean) / sign_std : 1.f;
     p.scale = 1.0f / 128.0f;  // (1/sqrt 2)^14
+    {
+        const bool norm = flags & AFD_WPT_NORM;
+        const double inv = norm ? 1.0 / (double)(std == 0.f ? 1.f : std) : 1.0;
+        p.scale2 = p.scale * p.scale;  // exact: a power of two
+        p.k1 = (float)(((flags & AFD_WPT_LOG) ? 0.6931471805599453 : (double)p.scale) * inv);
+        p.k0 = norm ? (float)(-(double)mean * inv) : 0.f;
+    }
     afd::ScopedTiming timing(AFD_K_WPT, 4.0 * B * ((double)N + ((flags & AFD_WPT_SIGN) ? 2.0 : 1.0) * 32768.0), stream);
     // two workgroups (frame halves) per CU, 16 per XCD pair up on a frame; the grid is a
     // multiple of 16 so that every workgroup has its partner
