@@ -9,9 +9,14 @@
 // lives in one 44 KB LDS image that every level overwrites in place:
 //   levels 1-2   straight from global memory: element i of the two level-2 nodes is a +/-
 //                combination of x[4i .. 4i+3];
-//   levels 3-8   three radix-4 passes in LDS (two levels per pass): each work item reads four
-//                consecutive samples of a node into registers, barrier, writes element i of
-//                the four grandchildren into the parent's own slot (quartered);
+//   levels 3-8   two radix-8 passes in LDS (three levels per pass): each work item reads eight
+//                consecutive samples of a node into registers, barrier, writes element i of the
+//                eight great-grandchildren into the parent's own slot (split in eight).  The slots
+//                past the end of an odd-length node hold the samples the reflect rule mirrors there
+//                (compile-time index maps, written by one thread per node after each pass), so
+//                every element is the plain butterfly: the kernel is bound by its vector
+//                instructions (75 % issue occupancy with radix-4 passes and per-element tail
+//                selects), three levels per pass cut the index arithmetic per output by 40 %;
 //   levels 9-14  in registers: thread = level-10 node (512 per half, 22 samples each),
 //                compile-time recursion down to its 16 leaf nodes of 2 samples;
 //   store        a thread owns 16 consecutive packets of both time rows (one 64-byte segment
@@ -31,11 +36,10 @@ constexpr int kThreads = 512;
 constexpr int kN = 22050;
 // node lengths of the Haar tree for N = 22050
 constexpr int kLen[15] = {22050, 11025, 5513, 2757, 1379, 690, 345, 173, 87, 44, 22, 11, 6, 3, 2};
-// LDS slot per node at levels 2, 4, 6, 8 (quartered every two levels).  A workgroup holds one
+// LDS slot per node at levels 2, 5, 8 (one eighth every three levels).  A workgroup holds one
 // level-1 half of a frame: 2 * 5632 floats = 44 KB
 constexpr int kCap2 = 5632;
 constexpr int kLdsFloats = 2 * kCap2;
-constexpr int kItems = 6;   // work items per thread in an LDS pass
 constexpr int kLoadItems = 11;  // ... and in the frame load (both halves read the whole frame)
 
 struct HaarParams {
@@ -122,70 +126,98 @@ __device__ __forceinline__ float4 butterfly4(const float4 x, bool odd) {
     return make_float4(a0 + a1, a0 - a1, d0 - d1, d0 + d1);
 }
 
-// one radix-4 pass: levels LEV -> LEV + 2 for the 2^(LEV-1) nodes of the half, in place
-// Reflect pads of the nodes of a level (length n, slot `cap`, `nodes` of them): the last radix-4 element of an
-// odd-length node reads x[4i .. 4i+3] past the node end; with the mirrored samples stored there -- n = 4k + 1:
-// (x[n-2], x[n-3], x[n-2]) at n .. n+2; n = 4k + 3: x[n-2] at n -- every element of the pass is the plain
-// butterfly of four consecutive slots (no per-element tail selects in the vector-instruction-bound passes).
+// The reflect rule of an odd-length node, xe[n] = x[n-2], as an index map
+constexpr int refl1(int j, int n) { return (j >= n) ? n - 2 : j; }
+
+// Base position that slot p >= n of a node of length n must mirror so that a plain radix-8 element over
+// x[8i .. 8i+7] equals three reflect-extended Haar levels: follow the element's inputs down the three levels,
+// applying the rule at each (node lengths n -> (n+1)/2 -> ...).
+constexpr int pad_src8(int p, int n) {
+    const int n1 = (n + 1) / 2, n2 = (n1 + 1) / 2;
+    const int i = p >> 3, s = p & 7;
+    const int j2 = refl1(2 * i + ((s >> 2) & 1), n2);   // level + 2 element
+    const int j1 = refl1(2 * j2 + ((s >> 1) & 1), n1);  // level + 1 element
+    return refl1(2 * j1 + (s & 1), n);
+}
+
+// reflect pads for a radix-8 reader: slots n .. 8 ceil(n/8) - 1 of every node (one thread per node)
 template <int n, int cap, int nodes>
-__device__ __forceinline__ void write_tail_pads(float* buf, int tid) {
-    static_assert(nodes <= kThreads, "one thread per node");
-    if (n % 4 == 1) {
-        static_assert(n % 4 != 1 || n + 3 <= cap, "pad slots");
-        if (tid < nodes) {
-            float* x = buf + tid * cap;
-            const float a = x[n - 2], b = x[n - 3];
-            x[n] = a;
-            x[n + 1] = b;
-            x[n + 2] = a;
-        }
-    } else if (n % 4 == 3) {
-        static_assert(n % 4 != 3 || n + 1 <= cap, "pad slot");
-        if (tid < nodes) {
-            float* x = buf + tid * cap;
-            x[n] = x[n - 2];
-        }
+__device__ __forceinline__ void write_pads8(float* buf, int tid) {
+    constexpr int n3 = (((n + 1) / 2 + 1) / 2 + 1) / 2;  // elements three levels down
+    constexpr int end = 8 * n3;
+    static_assert(nodes <= kThreads && end <= cap && end - n <= 7, "pad slots");
+    if (tid < nodes) {
+        float* x = buf + tid * cap;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < end - n; ++k) v[k] = x[pad_src8(n + k, n)];
+#pragma unroll
+        for (int k = 0; k < end - n; ++k) x[n + k] = v[k];
     }
 }
 
-template <int LEV>
-__device__ __forceinline__ void lds_pass(float* buf, int tid) {
+// reflect pad for the radix-4 reader of the level-8 nodes (n = 87 = 4k + 3): x[n] = x[n-2]
+template <int n, int cap, int nodes>
+__device__ __forceinline__ void write_pad4(float* buf, int tid) {
+    static_assert(n % 4 == 3 && n + 1 <= cap && nodes <= kThreads, "pad slot");
+    if (tid < nodes) {
+        float* x = buf + tid * cap;
+        x[n] = x[n - 2];
+    }
+}
+
+// element i of the great-grandchildren 8F .. 8F+7 of a node with frequency parity `odd`: two radix-4 halves
+// (x[0..3] -> element 2i of the grandchildren, x[4..7] -> element 2i + 1), then one more level; grandchildren
+// 4F, 4F+2 have even frequency (first child = sum), 4F+1, 4F+3 odd (first child = difference)
+__device__ __forceinline__ void butterfly8(const float4 lo, const float4 hi, bool odd, float (&out)[8]) {
+    const float4 p = butterfly4(lo, odd), q = butterfly4(hi, odd);
+    out[0] = p.x + q.x; out[1] = p.x - q.x;
+    out[2] = p.y - q.y; out[3] = p.y + q.y;
+    out[4] = p.z + q.z; out[5] = p.z - q.z;
+    out[6] = p.w - q.w; out[7] = p.w + q.w;
+}
+
+// one radix-8 pass: levels LEV -> LEV + 3 for the 2^(LEV-1) nodes of the half, in place (element i of the
+// eight great-grandchildren goes to the parent's own slot, split in eight); then the pads its reader needs
+constexpr int kItems8 = 3;
+template <int LEV, int CAPIN>
+__device__ __forceinline__ void lds_pass8(float* buf, int tid) {
     constexpr int M = 1 << (LEV - 1);
-    constexpr int n_gc = kLen[LEV + 2];
-    constexpr int capIn = kCap2 >> (LEV - 2), capOut = capIn / 4;
-    constexpr int total = M * n_gc;
-    static_assert(total <= kItems * kThreads && kLen[2] <= kLoadItems * kThreads,
-                  "pass does not fit the register staging");
-    static_assert(n_gc <= capOut && 4 * n_gc <= capIn, "slot capacity");
-    static_assert(kLen[LEV] % 2 == 1, "the tail pads cover odd node lengths (all pass inputs of N = 22050)");
-    float4 v[kItems];
+    constexpr int n_out = kLen[LEV + 3];
+    constexpr int capOut = CAPIN / 8;
+    constexpr int total = M * n_out;
+    static_assert(total <= kItems8 * kThreads, "pass does not fit the register staging");
+    static_assert(n_out <= capOut && 8 * n_out <= CAPIN, "slot capacity");
+    float4 va[kItems8], vb[kItems8];
 #pragma unroll
-    for (int r = 0; r < kItems; ++r) {
+    for (int r = 0; r < kItems8; ++r) {
         int w = r * kThreads + tid;
         w = w < total ? w : total - 1;
-        const int q = w / n_gc, i = w - q * n_gc;
-        v[r] = *reinterpret_cast<const float4*>(buf + q * capIn + 4 * i);
+        const int q = w / n_out, i = w - q * n_out;
+        const float4* src = reinterpret_cast<const float4*>(buf + q * CAPIN + 8 * i);
+        va[r] = src[0];
+        vb[r] = src[1];
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < kItems; ++r) {
+    for (int r = 0; r < kItems8; ++r) {
         const int w = r * kThreads + tid;
         if (w < total) {
-            const int q = w / n_gc, i = w - q * n_gc;
-            const float4 g = butterfly4(v[r], q & 1);
-            float* o = buf + q * capIn + i;
-            o[0] = g.x;
-            o[capOut] = g.y;
-            o[2 * capOut] = g.z;
-            o[3 * capOut] = g.w;
+            const int q = w / n_out, i = w - q * n_out;
+            float g[8];
+            butterfly8(va[r], vb[r], q & 1, g);
+            float* o = buf + q * CAPIN + i;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k * capOut] = g[k];
         }
     }
     __syncthreads();
-    // the grandchildren are the next reader's nodes: their reflect pads
-    if (n_gc % 2 == 1) {
-        write_tail_pads<n_gc, capOut, 4 * M>(buf, tid);
-        __syncthreads();
+    if constexpr (LEV + 3 == 8) {
+        write_pad4<n_out, capOut, 8 * M>(buf, tid);
+    } else {
+        write_pads8<n_out, capOut, 8 * M>(buf, tid);
     }
+    __syncthreads();
 }
 
 // Items [R0, R1) of the frame load: x[4i .. 4i+3] for the level-2 element i; the last element
@@ -262,17 +294,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
         const int nb = b + fstride;
         const float* xn = p.x + (size_t)(nb < p.B ? nb : b) * kN;
         float2 lo[kLoadItems], hi[kLoadItems], nxt[kLoadItems];
-        load_items<0, 4>(xn, lt, lo, hi);
-        write_tail_pads<kLen[2], kCap2, 2>(buf, lt);  // level-2 image of this frame (written before the last barrier)
+        load_items<0, 6>(xn, lt, lo, hi);
+        write_pads8<kLen[2], kCap2, 2>(buf, lt);  // level-2 image of this frame (written before the last barrier)
         __syncthreads();
-        lds_pass<2>(buf, lt);
-        level2_items<0, 4>(lo, hi, lt, half, nxt);
-        load_items<4, 8>(xn, lt, lo, hi);
-        lds_pass<4>(buf, lt);
-        level2_items<4, 8>(lo, hi, lt, half, nxt);
-        load_items<8, kLoadItems>(xn, lt, lo, hi);
-        lds_pass<6>(buf, lt);
-        level2_items<8, kLoadItems>(lo, hi, lt, half, nxt);
+        lds_pass8<2, kCap2>(buf, lt);  // levels 2 -> 5
+        level2_items<0, 6>(lo, hi, lt, half, nxt);
+        load_items<6, kLoadItems>(xn, lt, lo, hi);
+        lds_pass8<5, kCap2 / 8>(buf, lt);  // levels 5 -> 8
+        level2_items<6, kLoadItems>(lo, hi, lt, half, nxt);
         // ---- levels 9-10: thread = level-10 node `tid`; its level-8 grandparent is shared by
         // four threads, each forms the level-9 node it needs (44 samples) ----
         float v10[22];
