@@ -1,12 +1,21 @@
-# Round-end measurement set: GPU tests, headline bench under rocprofv3 --kernel-trace --stats,
-# the other workloads' bench lines.  Output under gpurun_out/round/.
-set -e
+# Round-end evidence: rocprofv3 kernel statistics of the headline bench and the front-end workloads, copied
+# into profiles/ (run through gpurun; rocprofv3 gets the program itself after `--`).
+#   tools/round_profile.sh <round tag, e.g. r02>
+tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/round; rm -rf $O; mkdir -p $O
-python3 -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1 && tail -2 $O/pytest_gpu.log
-python3 bench.py > $O/bench_coif4l14.json 2> $O/bench_coif4l14.err && cat $O/bench_coif4l14.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 3 --warmup 1 --cpu-frames 0 > $O/bench_prof.json 2> $O/bench_prof.err
-for w in coif4-l8 sym5-l8 stft stft-lcnn-eval; do
-  python3 bench.py --workload $w --cpu-frames 0 --steps 10 --warmup 3 > $O/bench_$w.json 2> $O/bench_$w.err && cat $O/bench_$w.json
-done
-python3 tools/frontend_bench.py > $O/frontend.log 2>&1 && cat $O/frontend.log
+run() {  # name, bench flags...
+  name=$1; shift
+  O=gpurun_out/rp_$name; rm -rf $O; mkdir -p $O
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py "$@" > $O/line.json 2> $O/err.txt || return 1
+  cp $(find $O/prof -name "*kernel_stats.csv" | head -1) profiles/${tag}_${name}_kernel_stats.csv
+  cp $O/line.json profiles/${tag}_${name}_line.json
+  echo "$name done"
+}
+run bench_coif4l14_b128 --steps 5 --warmup 3 --cpu-frames 0 &&
+AFD_WGRAD_STREAM=0 run bench_coif4l14_b128_serial --steps 5 --warmup 3 --cpu-frames 0 &&
+run frontend_coif4l14_b128 --workload coif4-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
+run frontend_coif4l14_b4096 --workload coif4-l14-frontend --batch 4096 --steps 20 --warmup 5 --cpu-frames 0 &&
+run frontend_sym5l14_b128 --workload sym5-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
+run frontend_haarl14_b4096 --workload haar-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
+run lcnn_eval_bf16 --workload stft-lcnn-eval-bf16 --steps 30 --warmup 5 --cpu-frames 0 &&
+cp profiles/${tag}_*kernel_stats.csv profiles/${tag}_*_line.json gpurun_out/
