@@ -97,6 +97,50 @@ def read_wav_window(path: str, frame_offset: int, num_frames: int) -> Tuple[torc
     return torch.from_numpy(np.ascontiguousarray(data)).unsqueeze(0), rate
 
 
+_sinc_kernels: dict = {}
+
+
+def _sinc_resample_kernel(orig: int, new: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Polyphase bank [new, 1, 2 * width + orig] of the Hann-windowed sinc interpolator (orig, new already
+    divided by their gcd), evaluated in float32 like the waveform it filters."""
+    key = (orig, new, lowpass_filter_width, rolloff)
+    hit = _sinc_kernels.get(key)
+    if hit is not None:
+        return hit
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float32)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float32)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+    _sinc_kernels[key] = (kernels, width)
+    return kernels, width
+
+
+def sinc_resample(waveform: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """Band-limited sinc resampling with the defaults of ``torchaudio.functional.resample`` (the call at
+    reference data_loader.py:343-345; torchaudio==2.0.0, ``requirements.txt:8``: Hann-windowed sinc,
+    ``lowpass_filter_width=6``, ``rolloff=0.99``).  torchaudio is a third-party dependency that is not
+    installed here; this restates its published algorithm: the rates are reduced by their gcd, the signal is
+    zero-padded by ``width`` on the left and ``width + orig`` on the right, filtered by a bank of ``new``
+    phase kernels with stride ``orig``, the phases interleaved and cut to ``ceil(new * length / orig)``."""
+    if int(orig_freq) == int(new_freq):
+        return waveform
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    kernels, width = _sinc_resample_kernel(orig, new)
+    shape = waveform.shape
+    flat = waveform.reshape(-1, shape[-1]).to(torch.float32)
+    length = flat.shape[-1]
+    padded = torch.nn.functional.pad(flat, (width, width + orig))
+    out = torch.nn.functional.conv1d(padded[:, None], kernels, stride=orig)
+    out = out.transpose(1, 2).reshape(flat.shape[0], -1)
+    target = -(-new * length // orig)
+    return out[..., :target].reshape(shape[:-1] + (target,))
+
+
 class CustomDataset(Dataset):
     """Balanced frame dataset over ``<letter>_<name>/`` folders of WAV files.
 
@@ -184,11 +228,7 @@ class CustomDataset(Dataset):
         path, frame, win, _ = self.audio_data[idx]
         audio, rate = read_wav_window(str(path), int(frame) * int(win), int(win))
         if rate > self.resample_rate:
-            from scipy.signal import resample_poly
-
-            g = math.gcd(int(rate), int(self.resample_rate))
-            res = resample_poly(audio.numpy(), self.resample_rate // g, rate // g, axis=-1)
-            audio = torch.from_numpy(np.ascontiguousarray(res, dtype=np.float32))
+            audio = sinc_resample(audio, int(rate), int(self.resample_rate))
         elif rate < self.resample_rate:
             raise RuntimeError("Sample rate is smaller than desired sample rate. No upsampling possible here.")
         return audio, rate

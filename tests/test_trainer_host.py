@@ -127,7 +127,7 @@ def test_custom_dataset_index_split_and_window_reader(tmp_path):
     want = signals[str(path)][frame * win:(frame + 1) * win].astype(np.float32) / 32768.0
     assert torch.equal(item["audio"][0], torch.from_numpy(want))
     assert sets["train"].get_label_name(1) == "fakegan" and len(get_costum_dataset(ds_type="train", **kw)) == 22
-    # resampling down (polyphase) keeps the one-second frame length at the new rate
+    # resampling down (windowed sinc) keeps the one-second frame length at the new rate
     half = get_costum_dataset(ds_type="val", **{**kw, "resample_rate": rate // 2})
     assert half[0]["audio"].shape == (1, rate // 2)
     import pytest
@@ -143,3 +143,39 @@ def test_graycode_keys_match_oracle_order():
     assert graycode_keys(2) == ["aa", "ad", "dd", "da"]
     for level in (3, 8, 14):
         assert graycode_keys(level) == graycode_paths(level)
+
+
+def test_sinc_resample_known_answers():
+    """`sinc_resample` (torchaudio.functional.resample defaults, reference data_loader.py:343-345): kernel
+    geometry for 44 100 -> 22 050 (gcd-reduced 2 -> 1: width ceil(6 * 2 / 0.99) = 13, 28 taps), output
+    length ceil(new * n / orig), unit DC gain, a tone below the new Nyquist frequency keeps amplitude and
+    phase, a tone above it is removed, and agreement with scipy's polyphase resampler on a band-limited
+    signal away from the edges."""
+    import math
+
+    from scipy.signal import resample_poly
+
+    from src.audiofakedetect.data_loader import _sinc_resample_kernel, sinc_resample
+
+    k, width = _sinc_resample_kernel(2, 1)
+    assert width == 13 and tuple(k.shape) == (1, 1, 28)
+    assert abs(float(k.sum()) - 1.0) < 2e-3
+    k3, w3 = _sinc_resample_kernel(160, 147)  # 48 000 -> 44 100
+    assert w3 == math.ceil(6 * 160 / (147 * 0.99)) and tuple(k3.shape) == (147, 1, 2 * w3 + 160)
+
+    n = 44100
+    t = torch.arange(n, dtype=torch.float64) / 44100.0
+    for orig, new in ((44100, 22050), (48000, 22050), (24000, 22050)):
+        x = torch.randn(2, 1, 1000)
+        assert sinc_resample(x, orig, new).shape == (2, 1, -(-new * 1000 // orig))
+    assert sinc_resample(torch.ones(5), 22050, 22050).shape == (5,)
+
+    low = torch.sin(2 * math.pi * 3000.0 * t).float()[None]
+    y = sinc_resample(low, 44100, 22050)
+    ref = torch.sin(2 * math.pi * 3000.0 * torch.arange(22050, dtype=torch.float64) / 22050.0).float()
+    assert (y[0, 100:-100] - ref[100:-100]).abs().max() < 2e-3
+    high = torch.sin(2 * math.pi * 15000.0 * t).float()[None]
+    assert sinc_resample(high, 44100, 22050)[0, 100:-100].abs().max() < 5e-2
+    mix = (low + 0.5 * torch.sin(2 * math.pi * 700.0 * t).float()[None])
+    poly = resample_poly(mix.numpy().astype(np.float64), 1, 2, axis=-1)
+    assert np.abs(sinc_resample(mix, 44100, 22050)[0, 200:-200].numpy() - poly[0, 200:-200]).max() < 5e-3
