@@ -53,6 +53,10 @@ _SIGNATURES = {
     "afd_conv1_pool_workspace_bytes": (c_sz, [c_i] * 5),
     "afd_conv1_pool_forward": (c_i, [c_p] * 6 + [c_i] * 5 + [c_p]),
     "afd_conv1_pool_backward": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p]),
+    "afd_conv1_pool_backward_affine": (c_i, [c_p] * 10 + [c_i] * 5 + [c_p, c_sz, c_p]),
+    "afd_conv1x1_prelu_bn_backward_applicable": (c_i, [c_i, c_i]),
+    "afd_conv1x1_prelu_bn_backward_workspace_bytes": (c_sz, [c_i, c_i]),
+    "afd_conv1x1_prelu_bn_backward": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_l, c_p, c_sz, c_p]),
     "afd_moments_accumulate": (c_i, [c_p, c_sz, c_p, c_p]),
     "afd_normalize_forward": (c_i, [c_p, c_p, c_sz, c_f, c_f, c_p]),
     "afd_packet_stats": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),

@@ -66,6 +66,7 @@ class DCNN(nn.Module):
             h = ops.transpose_contiguous(x.contiguous())
         cnn = self.cnn
         pending_bn = None  # a BatchNorm waiting to be folded into the 1x1 convolution after it
+        link = None        # hand-over of a gradient term from block 2's backward to block 1's
         for step, (conv_i, prelu_i, pooled, bn_i) in enumerate(self._cnn_plan):
             conv = cnn[conv_i]
             slope = cnn[prelu_i].weight
@@ -75,13 +76,22 @@ class DCNN(nn.Module):
             if (pooled and conv.in_channels == 1 and conv.kernel_size == (3, 3)
                     and conv.dilation == (1, 1) and not h.requires_grad):
                 # single-channel first block: conv + PReLU + pool in one kernel
-                h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0])
+                link = {} if fold_next else None
+                h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0], link)
                 if fold_next:
                     pending_bn = cnn[bn_i]
                 elif bn_i is not None:
                     h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
                 continue
             fused_pool = False
+            if (pending_bn is not None and not pooled and bn_i is not None
+                    and ops.bn_conv1x1_prelu_bn_applicable(pending_bn, conv, cnn[bn_i])):
+                # training step of block 2: BatchNorm -> 1x1 convolution -> PReLU -> BatchNorm with a one-pass backward
+                h = ops.bn_conv1x1_prelu_bn(h, pending_bn, conv.weight, conv.bias, slope, cnn[bn_i],
+                                            self.sync_bn, link)
+                pending_bn = link = None
+                continue
+            link = None
             if pending_bn is not None:
                 # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
                 z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)

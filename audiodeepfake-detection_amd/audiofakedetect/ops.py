@@ -352,12 +352,13 @@ class _Conv1PReLUPool(torch.autograd.Function):
     """Conv2d(1 -> Cout, 3x3, pad) + PReLU + MaxPool2d(2,2), fused (single-channel first block)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, slope, pad):
+    def forward(ctx, x, w, b, slope, pad, link=None):
         lib = _lib()
         x = _f32c(x)
         w = _f32c(w)
         n, _, h, wd = x.shape
         cout = w.shape[0]
+        ctx.link = link
         hp, wp = (h + 2 * pad - 2) // 2, (wd + 2 * pad - 2) // 2
         u = torch.empty((n, cout, hp, wp), dtype=torch.float32, device=x.device)
         idx = torch.empty((n, cout, hp, wp), dtype=torch.uint8, device=x.device)
@@ -379,17 +380,24 @@ class _Conv1PReLUPool(torch.autograd.Function):
         db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
         dslope = torch.zeros(1, dtype=torch.float32, device=x.device)
         ws = _ws(lib.afd_conv1_pool_workspace_bytes(n, h, wd, cout, pad), x.device)
-        _native.check(lib.afd_conv1_pool_backward(
+        # the consumer of u (`_BNConv1x1PReLUBN`) may have left the affine part of its input gradient,
+        # alpha[c] * u + beta[c], to this kernel, which reads du and u anyway
+        aff = ctx.link.pop("affine", None) if ctx.link is not None else None
+        alpha, beta = aff if aff is not None else (None, None)
+        _native.check(lib.afd_conv1_pool_backward_affine(
             _native.ptr(x), _native.ptr(du), _native.ptr(idx), _native.ptr(u), _native.ptr(slope),
-            _native.ptr(dw), _native.ptr(db), _native.ptr(dslope), n, h, wd, cout, pad,
-            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv1_pool_backward")
-        return None, dw, db, dslope, None
+            _native.ptr(alpha), _native.ptr(beta), _native.ptr(dw), _native.ptr(db), _native.ptr(dslope),
+            n, h, wd, cout, pad, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+            "afd_conv1_pool_backward")
+        return None, dw, db, dslope, None, None
 
 
-def conv1_prelu_maxpool(x, w, b, slope, padding: int):
+def conv1_prelu_maxpool(x, w, b, slope, padding: int, link: Optional[dict] = None):
     """Fused first block for single-channel inputs (no gradient w.r.t. x: the features are
-    produced under no_grad, reference train_classifier.py:965-967)."""
-    return _Conv1PReLUPool.apply(x, w, b, slope, int(padding))
+    produced under no_grad, reference train_classifier.py:965-967).  `link`: a dict shared with the
+    consumer of the result (`bn_conv1x1_prelu_bn`), through which that layer's backward hands over the
+    affine part of the gradient."""
+    return _Conv1PReLUPool.apply(x, w, b, slope, int(padding), link)
 
 
 def prelu_maxpool2x2(z, slope: Optional[torch.Tensor]):
@@ -726,6 +734,147 @@ def bn_conv1x1_applicable(bn: torch.nn.Module, conv: torch.nn.Module) -> bool:
             and bn.running_mean is not None
             and conv.kernel_size == (1, 1) and conv.padding == (0, 0) and conv.stride == (1, 1)
             and conv.in_channels <= 128 and conv.out_channels <= 128)
+
+
+def _bn_batch_stats(x, slope, c, n, hw, bn, sync):
+    """Training-mode statistics of PReLU(x) (or x): (mean, invstd, count); updates bn's running buffers."""
+    lib = _lib()
+    dev = x.device
+    count = float(n * hw)
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+    _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c, hw,
+                                   _native.stream_ptr()), "afd_bn_stats")
+    dist_on = _dist_on(sync)
+    if dist_on:
+        sums[2 * c] = count
+        dist.all_reduce(sums)
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    invstd = torch.empty(c, dtype=torch.float32, device=dev)
+    cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
+    mom = bn.momentum
+    nbt = bn.num_batches_tracked
+    if mom is None:
+        mom = 1.0 / float(int(nbt) + 1) if nbt is not None else 0.0
+    with torch.no_grad():
+        _native.check(lib.afd_bn_finalize(
+            _native.ptr(sums), c, -1.0 if dist_on else count, float(bn.eps), float(mom),
+            _native.ptr(mean), _native.ptr(invstd), _native.ptr(bn.running_mean),
+            _native.ptr(bn.running_var), _native.ptr(nbt), _native.ptr(cnt),
+            _native.stream_ptr()), "afd_bn_finalize")
+    return mean, invstd, (cnt if dist_on else count)
+
+
+class _BNConv1x1PReLUBN(torch.autograd.Function):
+    """DCNN block 2 in training mode (reference models.py:260-264):
+
+        u -> BatchNorm2d(affine=False) -> Conv2d(k=1) -> z -> PReLU -> BatchNorm2d(affine=False) -> xhat
+
+    Forward: the first normalisation is folded into the weights (as `_BNConv1x1`), the second one runs on
+    PReLU(z) without materialising it.  Backward: ONE pass over the activations
+    (`afd_conv1x1_prelu_bn_backward`) does the second BatchNorm's backward, the PReLU backward and both
+    GEMMs of the convolution's backward; the affine term of the first BatchNorm's backward is handed to the
+    producer of u through `link` (or added here when there is no such producer)."""
+
+    @staticmethod
+    def forward(ctx, u, w, b, slope, bn1, bn2, sync, link):
+        lib = _lib()
+        u = _f32c(u)
+        n, c, h, wd = u.shape
+        cout = w.shape[0]
+        hw = h * wd
+        dev = u.device
+        mean1, invstd1, cnt1 = _bn_batch_stats(u, None, c, n, hw, bn1, sync)
+        w2 = _f32c(w).reshape(cout, c)
+        wf = (w2 * invstd1).contiguous()
+        bf = -(wf @ mean1)
+        if b is not None:
+            bf = bf + b
+        z = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
+        ws = _ws(lib.afd_conv2d_workspace_bytes(n, c, h, wd, cout, 1, 0, 1), dev)
+        _native.check(lib.afd_conv2d_forward(
+            _native.ptr(u), _native.ptr(wf), _native.ptr(bf), _native.ptr(z), n, c, h, wd, cout, 1, 0, 1,
+            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_forward")
+        mean2, invstd2, cnt2 = _bn_batch_stats(z, slope, cout, n, hw, bn2, sync)
+        y = torch.empty_like(z)
+        _native.check(lib.afd_bn_apply_forward(
+            _native.ptr(z), _native.ptr(slope), _native.ptr(mean2), _native.ptr(invstd2), None, None,
+            _native.ptr(y), n, cout, hw, _native.stream_ptr()), "afd_bn_apply_forward")
+        _tap("prelu", z)
+        ctx.save_for_backward(u, z, w2, wf, mean1, invstd1, mean2, invstd2, slope)
+        ctx.geom = (n, c, h, wd, cout)
+        ctx.cfg = (sync, b is not None, tuple(w.shape), cnt1, cnt2, link)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib()
+        u, z, w2, wf, mean1, invstd1, mean2, invstd2, slope = ctx.saved_tensors
+        n, c, h, wd, cout = ctx.geom
+        sync, has_bias, wshape, cnt1, cnt2, link = ctx.cfg
+        hw = h * wd
+        dev = u.device
+        g = _f32c(g)
+        # second BatchNorm: batch means of g and g * xhat (one reduction pass), folded into per-channel constants
+        sums = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+        _native.check(lib.afd_bn_backward_stats(
+            _native.ptr(z), _native.ptr(slope), _native.ptr(g), _native.ptr(mean2), _native.ptr(invstd2),
+            _native.ptr(sums), n, cout, hw, _native.stream_ptr()), "afd_bn_backward_stats")
+        if _dist_on(sync):
+            dist.all_reduce(sums)
+        mdy = torch.empty(cout, dtype=torch.float32, device=dev)
+        mdyx = torch.empty(cout, dtype=torch.float32, device=dev)
+        on_dev = torch.is_tensor(cnt2)
+        _native.check(lib.afd_bn_backward_means(
+            _native.ptr(sums), cout, -1.0 if on_dev else float(cnt2), _native.ptr(cnt2) if on_dev else None,
+            _native.ptr(mdy), _native.ptr(mdyx), _native.stream_ptr()), "afd_bn_backward_means")
+        s2m = invstd2 * invstd2 * mdyx
+        coef = torch.stack([invstd2, -s2m, s2m * mean2 - invstd2 * mdy, torch.zeros_like(mdy)], dim=1).contiguous()
+        t = torch.empty_like(u)
+        gw = torch.empty((cout, c), dtype=torch.float32, device=dev)
+        db = torch.empty(cout, dtype=torch.float32, device=dev)
+        dslope = torch.zeros(1, dtype=torch.float32, device=dev)
+        ws = _ws(lib.afd_conv1x1_prelu_bn_backward_workspace_bytes(c, cout), dev)
+        _native.check(lib.afd_conv1x1_prelu_bn_backward(
+            _native.ptr(g), _native.ptr(z), _native.ptr(u), _native.ptr(wf), _native.ptr(coef),
+            _native.ptr(slope), _native.ptr(t), _native.ptr(gw), _native.ptr(db), _native.ptr(dslope),
+            n, c, cout, hw, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+            "afd_conv1x1_prelu_bn_backward")
+        # first BatchNorm, from the small matrices alone (as in `_BNConv1x1`)
+        dw = (gw - db[:, None] * mean1[None, :]) * invstd1[None, :]
+        du = None
+        if ctx.needs_input_grad[0]:
+            sums1 = torch.stack([w2.t() @ db, (w2 * dw).sum(0)]).double().reshape(-1)
+            if _dist_on(sync):
+                dist.all_reduce(sums1)
+            cnt = cnt1 if torch.is_tensor(cnt1) else float(cnt1)
+            m1 = (sums1[:c] / cnt).float()
+            m2 = (sums1[c:] / cnt).float()
+            s2m2 = invstd1 * invstd1 * m2
+            alpha = (-s2m2).contiguous()
+            beta = (s2m2 * mean1 - invstd1 * m1).contiguous()
+            if link is not None:
+                link["affine"] = (alpha, beta)  # added by the producer of u where it reads du and u
+                du = t
+            else:
+                du = torch.addcmul(t + beta.view(1, -1, 1, 1), u, alpha.view(1, -1, 1, 1))
+        return (du, dw.reshape(wshape) if ctx.needs_input_grad[1] else None,
+                db if (has_bias and ctx.needs_input_grad[2]) else None,
+                dslope if ctx.needs_input_grad[3] else None, None, None, None, None)
+
+
+def bn_conv1x1_prelu_bn_applicable(bn1: torch.nn.Module, conv: torch.nn.Module, bn2: torch.nn.Module) -> bool:
+    if not bn_conv1x1_applicable(bn1, conv):
+        return False
+    if not (bn1.training and bn2.training and bn2.weight is None and bn2.bias is None
+            and bn2.running_mean is not None):
+        return False
+    return bool(_lib().afd_conv1x1_prelu_bn_backward_applicable(conv.in_channels, conv.out_channels))
+
+
+def bn_conv1x1_prelu_bn(u, bn1, w, b, slope, bn2, sync: bool = True, link: Optional[dict] = None):
+    """batch_norm2(PReLU(conv1x1(batch_norm1(u)))) in training mode with the one-pass backward of
+    `_BNConv1x1PReLUBN`.  `link`: the dict given to `conv1_prelu_maxpool` when that call produced u."""
+    return _BNConv1x1PReLUBN.apply(u, w, b, slope, bn1, bn2, sync, link)
 
 
 def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True):

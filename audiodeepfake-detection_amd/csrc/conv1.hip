@@ -80,7 +80,8 @@ __global__ void __launch_bounds__(kT)
 conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
                       const unsigned char* __restrict__ idx, const float* __restrict__ u,
                       const float* __restrict__ slope, float* __restrict__ partial, int N, int H,
-                      int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalTiles) {
+                      int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalTiles,
+                      const float* __restrict__ aff_alpha, const float* __restrict__ aff_beta) {
     __shared__ float red[kT / 64][kCG * 11];
     const int cg = blockIdx.x;
     const int split = blockIdx.y;
@@ -89,6 +90,14 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
     const float inva = a != 0.f ? 1.f / a : 0.f;
     float acc[kCG][9];
     float accb[kCG], accs[kCG];
+    // AFFINE: the gradient of the pooled tensor is du + alpha[c] * u + beta[c] (uniform addresses: scalar loads)
+    float al[kCG], be[kCG];
+#pragma unroll
+    for (int c = 0; c < kCG; ++c) {
+        const bool ok = aff_alpha && cg * kCG + c < Cout;
+        al[c] = ok ? aff_alpha[cg * kCG + c] : 0.f;
+        be[c] = ok ? aff_beta[cg * kCG + c] : 0.f;
+    }
 #pragma unroll
     for (int c = 0; c < kCG; ++c) {
         accb[c] = 0.f;
@@ -121,7 +130,7 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
         }
 #pragma unroll
         for (int c = 0; c < kCG; ++c) {
-            float g = gv[c];
+            float g = fmaf(al[c], uv[c], gv[c] + be[c]);
             if (code[c] & 4) {
                 accs[c] += g * uv[c] * inva;
                 g *= a;
@@ -227,6 +236,16 @@ extern "C" int afd_conv1_pool_backward(const float* x, const float* du, const ui
                                        const float* u, const float* slope, float* dw, float* dbias,
                                        float* dslope, int N, int H, int W, int Cout, int pad, void* ws,
                                        size_t ws_bytes, afd_stream_t stream) {
+    return afd_conv1_pool_backward_affine(x, du, idx, u, slope, nullptr, nullptr, dw, dbias, dslope, N, H, W,
+                                          Cout, pad, ws, ws_bytes, stream);
+}
+
+extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, const uint8_t* idx,
+                                              const float* u, const float* slope, const float* alpha,
+                                              const float* beta, float* dw, float* dbias, float* dslope,
+                                              int N, int H, int W, int Cout, int pad, void* ws,
+                                              size_t ws_bytes, afd_stream_t stream) {
+    if ((alpha == nullptr) != (beta == nullptr)) return afd::fail(AFD_ERR_ARG, "conv1 bwd: alpha and beta come together");
     if (!x || !du || !idx || !u || !slope || !dw || !dslope) return afd::fail(AFD_ERR_ARG, "conv1 bwd: null pointer");
     const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
     if (N < 1 || Cout < 1 || Hp < 1 || Wp < 1) return afd::fail(AFD_ERR_ARG, "conv1 bwd: bad geometry");
@@ -238,7 +257,7 @@ extern "C" int afd_conv1_pool_backward(const float* x, const float* du, const ui
         return afd::fail(AFD_ERR_WORKSPACE, "conv1 bwd: workspace too small");
     float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL(conv1_pool_bwd_kernel, dim3(CG, S), dim3(kT), 0, AFD_STREAM, x, du, idx, u, slope,
-                       partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles);
+                       partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles, alpha, beta);
     const int total = CG * kCG * 11;
     hipLaunchKernelGGL(conv1_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, AFD_STREAM, partial,
                        dw, dbias, dslope, Cout, CG, S);

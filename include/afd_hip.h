@@ -146,6 +146,21 @@ int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, const float* 
 int afd_conv1x1_bn_backward_data(const float* dz, const float* wf, const float* u, const float* alpha,
                                  const float* beta, float* du, int N, int Cin, int Cout, long HW,
                                  afd_stream_t stream);
+/* Backward of  u -> [BatchNorm(affine=False) folded into wf] -> Conv2d(Cin, C, 1) -> z -> PReLU -> P ->
+ * BatchNorm(affine=False) -> xhat  (reference src/audiofakedetect/models.py:260-264, DCNN block 2) in ONE pass
+ * over the activations; replaces cudnn's batch-norm backward, the PReLU backward and the convolution's
+ * backward-weight and backward-data for this chain.  g = dL/dxhat [N][C][HW], z [N][C][HW], u [N][Cin][HW],
+ * wf [C][Cin] the folded weights, coef [C][4] = (A, B, K, 0) with dP = A g + B P + K
+ * (A = invstd, B = -invstd^2 E[g xhat], K = invstd^2 E[g xhat] mean - invstd E[g] of the SECOND BatchNorm).
+ * Outputs: t [N][Cin][HW] = wf^T dz (the first BatchNorm's affine backward term is added by the consumer,
+ * afd_conv1_pool_backward_affine), G [C][Cin] = sum_p dz u (gradient against the un-normalised input),
+ * db [C] = sum_p dz, dslope (+=).  Cin, C <= 64. */
+int afd_conv1x1_prelu_bn_backward_applicable(int Cin, int C);
+size_t afd_conv1x1_prelu_bn_backward_workspace_bytes(int Cin, int C);
+int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, const float* u, const float* wf,
+                                  const float* coef, const float* slope, float* t, float* G, float* db,
+                                  float* dslope /* += */, int N, int Cin, int C, long HW, void* ws,
+                                  size_t ws_bytes, afd_stream_t stream);
 int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                float* dbias /* may be NULL */, int N, int Cin, int H, int W,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,
@@ -179,6 +194,13 @@ int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx,
                             const float* slope, float* dw, float* dbias, float* dslope /* += */,
                             int N, int H, int W, int Cout, int pad, void* ws, size_t ws_bytes,
                             afd_stream_t stream);
+/* The same with the gradient of the pooled tensor given as du + alpha[c] * u + beta[c] (alpha, beta [Cout]):
+ * the affine part of a following BatchNorm's backward is applied where du and u are read anyway
+ * (see afd_conv1x1_prelu_bn_backward). */
+int afd_conv1_pool_backward_affine(const float* x, const float* du, const uint8_t* idx, const float* u,
+                                   const float* slope, const float* alpha, const float* beta, float* dw,
+                                   float* dbias, float* dslope /* += */, int N, int H, int W, int Cout,
+                                   int pad, void* ws, size_t ws_bytes, afd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * HBM-bound layers.  `slope` is the device address of the single shared PReLU parameter

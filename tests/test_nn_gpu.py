@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from audiofakedetect import ops
+from audiofakedetect import _native, ops
 
 pytestmark = pytest.mark.gpu
 
@@ -365,6 +365,88 @@ def test_batchnorm_folded_into_the_1x1_convolution(shape, cout, training):
         close(bn.running_mean, ref_bn.running_mean, 1e-6)
         close(bn.running_var, ref_bn.running_var, 1e-6)
         assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,cout,linked", [((2, 64, 13, 1157), 64, True), ((3, 64, 5, 333), 64, False),
+                                               ((2, 48, 3, 130), 40, False), ((1, 64, 2, 31), 64, True)])
+def test_block2_one_pass_backward(shape, cout, linked):
+    """DCNN block 2 in training mode, u -> BatchNorm -> Conv2d(k=1) -> PReLU -> BatchNorm (reference
+    models.py:260-264), with its backward in one pass over the activations (`afd_conv1x1_prelu_bn_backward`)
+    against the four layers in float64: output, weight / bias / slope gradients, running statistics and the
+    input gradient -- directly, or (`linked`) as the (t, alpha, beta) hand-over that the first block's backward
+    consumes (`afd_conv1_pool_backward_affine`).  Shapes cover whole and partial 64-pixel tiles, unaligned rows
+    and fewer than 64 channels."""
+    torch.manual_seed(11)
+    n, c, h, w = shape
+    u = (torch.randn(shape).abs() * 0.7 + 0.3 * torch.rand(1, c, 1, 1)).cuda().requires_grad_(True)
+    conv = torch.nn.Conv2d(c, cout, 1).cuda()
+    bn1 = torch.nn.BatchNorm2d(c, affine=False).cuda().train()
+    bn2 = torch.nn.BatchNorm2d(cout, affine=False).cuda().train()
+    act = torch.nn.PReLU().cuda()
+    assert ops.bn_conv1x1_prelu_bn_applicable(bn1, conv, bn2)
+    ref = torch.nn.Sequential(torch.nn.BatchNorm2d(c, affine=False), torch.nn.Conv2d(c, cout, 1), torch.nn.PReLU(),
+                              torch.nn.BatchNorm2d(cout, affine=False)).double().cuda().train()
+    ref[1].load_state_dict(conv.state_dict())
+    u64 = u.detach().double().requires_grad_(True)
+    g = torch.randn(n, cout, h, w, device="cuda")
+
+    link = {} if linked else None
+    y = ops.bn_conv1x1_prelu_bn(u, bn1, conv.weight, conv.bias, act.weight, bn2, sync=False, link=link)
+    y.backward(g)
+    yr = ref(u64)
+    yr.backward(g.double())
+
+    def close(a, b, tol):
+        scale = b.abs().max().item()
+        assert (a.double() - b).abs().max().item() <= tol * scale, ((a.double() - b).abs().max().item(), scale)
+
+    close(y, yr, 5e-6)
+    du = u.grad
+    if linked:
+        alpha, beta = link.pop("affine")
+        du = du + alpha.view(1, -1, 1, 1) * u.detach() + beta.view(1, -1, 1, 1)
+    close(du, u64.grad, 5e-5)
+    close(conv.weight.grad, ref[1].weight.grad, 5e-5)
+    close(conv.bias.grad, ref[1].bias.grad, 5e-5)
+    close(act.weight.grad, ref[2].weight.grad, 5e-5)
+    close(bn1.running_mean, ref[0].running_mean, 1e-6)
+    close(bn2.running_var, ref[3].running_var, 1e-5)
+
+
+@pytest.mark.gpu
+def test_conv1_pool_backward_with_affine_gradient():
+    """`afd_conv1_pool_backward_affine`: the first block's backward with its incoming gradient given as
+    du + alpha[c] * u + beta[c] equals the plain backward on the materialised sum."""
+    torch.manual_seed(12)
+    lib = _native.load()
+    n, h, w, cout, pad = 2, 10, 300, 24, 2
+    x = torch.randn(n, 1, h, w, device="cuda")
+    conv = torch.nn.Conv2d(1, cout, 3, padding=pad).cuda()
+    slope = torch.full((1,), 0.25, device="cuda")
+    hp, wp = (h + 2 * pad - 2) // 2, (w + 2 * pad - 2) // 2
+    u = torch.empty(n, cout, hp, wp, device="cuda")
+    idx = torch.empty(n, cout, hp, wp, dtype=torch.uint8, device="cuda")
+    _native.check(lib.afd_conv1_pool_forward(_native.ptr(x), _native.ptr(conv.weight.detach().contiguous()),
+                                             _native.ptr(conv.bias.detach()), _native.ptr(slope), _native.ptr(u),
+                                             _native.ptr(idx), n, h, w, cout, pad, _native.stream_ptr()), "fwd")
+    du = torch.randn_like(u)
+    alpha, beta = torch.randn(cout, device="cuda"), torch.randn(cout, device="cuda")
+    ws = torch.empty(lib.afd_conv1_pool_workspace_bytes(n, h, w, cout, pad), dtype=torch.uint8, device="cuda")
+
+    def run(grad, a, b):
+        dw = torch.empty(cout, 1, 3, 3, device="cuda")
+        db = torch.empty(cout, device="cuda")
+        ds = torch.zeros(1, device="cuda")
+        _native.check(lib.afd_conv1_pool_backward_affine(
+            _native.ptr(x), _native.ptr(grad), _native.ptr(idx), _native.ptr(u), _native.ptr(slope), _native.ptr(a),
+            _native.ptr(b), _native.ptr(dw), _native.ptr(db), _native.ptr(ds), n, h, w, cout, pad, _native.ptr(ws),
+            ws.numel(), _native.stream_ptr()), "bwd")
+        return dw, db, ds
+
+    full = du + alpha.view(1, -1, 1, 1) * u + beta.view(1, -1, 1, 1)
+    for got, want in zip(run(du, alpha, beta), run(full, None, None)):
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
 WIDE3X3 = [(2, 32, 6, 1100, 64), (1, 96, 4, 1025, 128), (1, 64, 13, 1157, 96), (2, 64, 51, 129, 96)]
