@@ -736,14 +736,11 @@ def bn_conv1x1_applicable(bn: torch.nn.Module, conv: torch.nn.Module) -> bool:
             and conv.in_channels <= 128 and conv.out_channels <= 128)
 
 
-def _bn_batch_stats(x, slope, c, n, hw, bn, sync):
-    """Training-mode statistics of PReLU(x) (or x): (mean, invstd, count); updates bn's running buffers."""
+def _bn_finalize_sums(sums, c, count, bn, sync):
+    """(mean, invstd, count) from the packed [sum | sum of squares | count slot] double vector of a training
+    batch (all-reduced first when a process group is up); updates bn's running buffers."""
     lib = _lib()
-    dev = x.device
-    count = float(n * hw)
-    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-    _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c, hw,
-                                   _native.stream_ptr()), "afd_bn_stats")
+    dev = sums.device
     dist_on = _dist_on(sync)
     if dist_on:
         sums[2 * c] = count
@@ -762,6 +759,14 @@ def _bn_batch_stats(x, slope, c, n, hw, bn, sync):
             _native.ptr(bn.running_var), _native.ptr(nbt), _native.ptr(cnt),
             _native.stream_ptr()), "afd_bn_finalize")
     return mean, invstd, (cnt if dist_on else count)
+
+
+def _bn_batch_stats(x, slope, c, n, hw, bn, sync):
+    """Training-mode statistics of PReLU(x) (or x): (mean, invstd, count); updates bn's running buffers."""
+    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+    _native.check(_lib().afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c, hw,
+                                      _native.stream_ptr()), "afd_bn_stats")
+    return _bn_finalize_sums(sums, c, float(n * hw), bn, sync)
 
 
 class _BNConv1x1PReLUBN(torch.autograd.Function):
@@ -790,11 +795,14 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         if b is not None:
             bf = bf + b
         z = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
-        ws = _ws(lib.afd_conv2d_workspace_bytes(n, c, h, wd, cout, 1, 0, 1), dev)
-        _native.check(lib.afd_conv2d_forward(
-            _native.ptr(u), _native.ptr(wf), _native.ptr(bf), _native.ptr(z), n, c, h, wd, cout, 1, 0, 1,
-            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_forward")
-        mean2, invstd2, cnt2 = _bn_batch_stats(z, slope, cout, n, hw, bn2, sync)
+        # the convolution's epilogue also sums PReLU(z) and its square per channel: no statistics pass
+        ws = _ws(lib.afd_conv1x1_forward_stats_workspace_bytes(cout), dev)
+        sums2 = torch.empty(2 * cout + 1, dtype=torch.float64, device=dev)
+        _native.check(lib.afd_conv1x1_forward_stats(
+            _native.ptr(u), _native.ptr(wf), _native.ptr(bf), _native.ptr(slope), _native.ptr(z),
+            _native.ptr(sums2), n, c, cout, hw, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+            "afd_conv1x1_forward_stats")
+        mean2, invstd2, cnt2 = _bn_finalize_sums(sums2, cout, float(n * hw), bn2, sync)
         y = torch.empty_like(z)
         _native.check(lib.afd_bn_apply_forward(
             _native.ptr(z), _native.ptr(slope), _native.ptr(mean2), _native.ptr(invstd2), None, None,

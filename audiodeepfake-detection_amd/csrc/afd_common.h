@@ -62,6 +62,10 @@ bool conv1x1_wgrad_applicable(int Cin, int Cout);
 size_t conv1x1_workspace_bytes(int Cin, int Cout);
 int conv1x1_forward(const float* x, const float* w, const float* bias, float* y, int N, int Cin,
                     int Cout, long HW, hipStream_t s);
+size_t conv1x1_stats_workspace_bytes(int Cout);
+int conv1x1_forward_stats(const float* x, const float* w, const float* bias, const float* slope, float* y,
+                          double* sums, int N, int Cin, int Cout, long HW, void* ws, size_t ws_bytes,
+                          hipStream_t s);
 int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout,
                           long HW, hipStream_t s);
 int conv1x1_backward_data_affine(const float* dy, const float* w, const float* res, const float* alpha,

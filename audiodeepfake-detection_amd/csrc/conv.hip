@@ -1383,6 +1383,21 @@ extern "C" int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, co
                          static_cast<hipStream_t>(stream), slope, u, idx);
 }
 
+extern "C" size_t afd_conv1x1_forward_stats_workspace_bytes(int Cout) {
+    return afd::conv1x1_stats_workspace_bytes(Cout);
+}
+
+extern "C" int afd_conv1x1_forward_stats(const float* x, const float* w, const float* bias, const float* slope,
+                                         float* y, double* sums, int N, int Cin, int Cout, long HW, void* ws,
+                                         size_t ws_bytes, afd_stream_t stream) {
+    if (!x || !w || !slope || !y || !sums || !ws) return afd::fail(AFD_ERR_ARG, "conv1x1 stats: null pointer");
+    if (N < 1 || Cin < 1 || Cout < 1 || HW < 1 || HW > 0x7fffffffL)
+        return afd::fail(AFD_ERR_ARG, "conv1x1 stats: bad shape");
+    if (Cin > 128 || Cout > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1 stats: more than 128 channels");
+    return afd::conv1x1_forward_stats(x, w, bias, slope, y, sums, N, Cin, Cout, HW, ws, ws_bytes,
+                                      static_cast<hipStream_t>(stream));
+}
+
 extern "C" int afd_conv1x1_bn_backward_data(const float* dz, const float* wf, const float* u,
                                             const float* alpha, const float* beta, float* du, int N,
                                             int Cin, int Cout, long HW, afd_stream_t stream) {

@@ -106,11 +106,12 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
         for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
     }
     const size_t plane = (size_t)Hp * Wp;
-    for (long t = split; t < totalTiles; t += S) {
-        const int xc = (int)(t % tilesX);
-        const long row = t / tilesX;
-        const int py = (int)(row % Hp);
-        const int n = (int)(row / Hp);
+    const int ntiles = (int)totalTiles;  // < 2^31 (checked by the host): 32-bit tile arithmetic
+    for (int t = split; t < ntiles; t += S) {
+        const int row = t / tilesX;
+        const int xc = t - row * tilesX;
+        const int n = row / Hp;
+        const int py = row - n * Hp;
         const int px = xc * kT + threadIdx.x;
         if (px >= Wp) continue;
         float p[4][4];
@@ -252,6 +253,7 @@ extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, c
     const int CG = (Cout + kCG - 1) / kCG;
     const int tilesX = (Wp + kT - 1) / kT;
     const long tiles = (long)N * Hp * tilesX;
+    if (tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 bwd: too many tiles");
     const int S = bwd_splits(tiles, CG);
     if (!ws || ws_bytes < (size_t)S * CG * kCG * 11 * sizeof(float))
         return afd::fail(AFD_ERR_WORKSPACE, "conv1 bwd: workspace too small");

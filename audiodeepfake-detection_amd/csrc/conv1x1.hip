@@ -42,11 +42,14 @@ struct VecU<4> { typedef float type __attribute__((ext_vector_type(4), aligned(4
 // AFF: the epilogue adds a per-output-channel affine function of a second tensor of the output's
 // shape, y = W.x + alpha[c] * res + beta[c] (the BatchNorm backward folded into the backward-data
 // GEMM of the 1x1 convolution that follows the normalisation, see afd_conv1x1_bn_backward_data).
-template <int MW, int NW, bool AFF>
+// STATS: the epilogue also accumulates, per output channel, the sum and the sum of squares of PReLU(y) (slope
+// `res[0]`) -- the batch statistics of the BatchNorm that follows the activation -- into one partial row per
+// wave (`stat_part` [wave][2][MW*32]); a second kernel adds the rows in double precision.
+template <int MW, int NW, bool AFF, bool STATS = false>
 __global__ void __launch_bounds__(256)
 conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict__ w,
                const float* __restrict__ bias, float* __restrict__ y, const float* __restrict__ res,
-               const float* __restrict__ alpha) {
+               const float* __restrict__ alpha, float* __restrict__ stat_part = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];  // [Kpad][MW*32], k-major
     typedef typename VecU<NW>::type vec_t;
     constexpr int CO_PAD = MW * 32;
@@ -95,6 +98,19 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
     };
 
     int t = blockIdx.x * 4 + wave;
+    float s1[STATS ? MW : 1][16], s2[STATS ? MW : 1][16];
+    float slope_a = 0.f;
+    if constexpr (STATS) {
+        slope_a = res[0];
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s1[m][r] = s2[m][r] = 0.f;
+        if (t >= g.ntiles) {  // a wave without tiles still owns a (zero) partial row
+            for (int e = lane; e < 2 * CO_PAD; e += 64)
+                stat_part[((size_t)blockIdx.x * 4 + wave) * (2 * CO_PAD) + e] = 0.f;
+        }
+    }
     if (t >= g.ntiles) return;
     f32x16 acc[MW][NW];
 #pragma unroll
@@ -192,10 +208,26 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
 #pragma unroll
                             for (int i = 0; i < NW; ++i) v[i] = acc[m][i][r] + bv;
                             *reinterpret_cast<vec_t*>(o) = v;
+                            if constexpr (STATS) {
+#pragma unroll
+                                for (int i = 0; i < NW; ++i) {
+                                    const float pv = v[i] > 0.f ? v[i] : slope_a * v[i];
+                                    s1[m][r] += pv;
+                                    s2[m][r] = fmaf(pv, pv, s2[m][r]);
+                                }
+                            }
                         } else {
 #pragma unroll
                             for (int i = 0; i < NW; ++i)
-                                if (p + i < g.HW) o[i] = acc[m][i][r] + bv;
+                                if (p + i < g.HW) {
+                                    const float zv = acc[m][i][r] + bv;
+                                    o[i] = zv;
+                                    if constexpr (STATS) {
+                                        const float pv = zv > 0.f ? zv : slope_a * zv;
+                                        s1[m][r] += pv;
+                                        s2[m][r] = fmaf(pv, pv, s2[m][r]);
+                                    }
+                                }
                         }
                     }
                 }
@@ -213,6 +245,41 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
         t = tn;
         c = cn;
     }
+    if constexpr (STATS) {
+        // a register row is one output channel over the 32 lanes of a wave half
+        float* row = stat_part + ((size_t)blockIdx.x * 4 + wave) * (2 * CO_PAD);
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a1 = s1[m][r], a2 = s2[m][r];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    a1 += __shfl_xor(a1, off, 64);
+                    a2 += __shfl_xor(a2, off, 64);
+                }
+                if (l31 == 0) {
+                    const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    row[co] = a1;
+                    row[CO_PAD + co] = a2;
+                }
+            }
+    }
+}
+
+// sums[c] = sum over the waves' partial rows (double), sums[C + c] likewise for the squares: one wave per output,
+// lanes stride over the rows
+__global__ void __launch_bounds__(256)
+conv1x1_stats_reduce_kernel(const float* __restrict__ part, int rows, int co_pad, int C, double* __restrict__ sums) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= 2 * C) return;
+    const int which = e / C, c = e - which * C;
+    double s = 0.0;
+    for (int r = lane; r < rows; r += 64) s += (double)part[(size_t)r * 2 * co_pad + which * co_pad + c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) sums[e] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -356,6 +423,29 @@ int num_cus() {
 }
 
 template <int MW, int NW>
+int launch_gemm_stats(G1 g, const float* x, const float* w, const float* bias, const float* slope, float* y,
+                      double* sums, float* part, size_t part_bytes, hipStream_t s) {
+    g.tiles_per_img = (g.HW + 32 * NW - 1) / (32 * NW);
+    const long nt = (long)g.N * g.tiles_per_img;
+    if (nt > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1: too many tiles");
+    g.ntiles = (int)nt;
+    const int Kpad = (g.Cin + 31) / 32 * 32;
+    const size_t lds = (size_t)Kpad * MW * 32 * sizeof(float);
+    long blocks = (nt + 3) / 4;
+    const long cap = (long)num_cus();  // the kernel holds one wave per SIMD: one persistent workgroup per CU
+    if (blocks > cap) blocks = cap;
+    if (part_bytes < (size_t)blocks * 4 * 2 * MW * 32 * sizeof(float))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv1x1 stats: workspace too small");
+    hipLaunchKernelGGL((conv1x1_kernel<MW, NW, false, true>), dim3((unsigned)blocks), dim3(256), lds, s, g, x, w,
+                       bias, y, slope, nullptr, part);
+    int rc = afd::check_launch("conv1x1_kernel(stats)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv1x1_stats_reduce_kernel, dim3((2 * g.Cout + 3) / 4), dim3(256), 0, s, part,
+                       (int)blocks * 4, MW * 32, g.Cout, sums);
+    return afd::check_launch("conv1x1_stats_reduce_kernel");
+}
+
+template <int MW, int NW>
 int launch_gemm(G1 g, const float* x, const float* w, const float* bias, float* y, hipStream_t s,
                 const float* res = nullptr, const float* alpha = nullptr) {
     g.tiles_per_img = (g.HW + 32 * NW - 1) / (32 * NW);
@@ -449,6 +539,29 @@ int conv1x1_forward(const float* x, const float* w, const float* bias, float* y,
 }
 
 // dx[n][ci][p] = sum_co w[co][ci] dy[n][co][p]
+size_t conv1x1_stats_workspace_bytes(int Cout) {
+    return (size_t)num_cus() * 4 * 2 * ((size_t)(Cout + 31) / 32 * 32) * sizeof(float);
+}
+
+// y = W x + bias, and sums[c] = sum PReLU(y[c]), sums[Cout + c] = sum PReLU(y[c])^2 over all pixels
+int conv1x1_forward_stats(const float* x, const float* w, const float* bias, const float* slope, float* y,
+                          double* sums, int N, int Cin, int Cout, long HW, void* ws, size_t ws_bytes,
+                          hipStream_t s) {
+    G1 g{};
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.HW = (int)HW; g.trans = 0;
+    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    timing.issued(2.0 * N * pad32(Cout) * (double)HW * Cin);
+    timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
+    float* part = static_cast<float*>(ws);
+    switch ((Cout + 31) / 32) {
+        case 1: return launch_gemm_stats<1, 4>(g, x, w, bias, slope, y, sums, part, ws_bytes, s);
+        case 2: return launch_gemm_stats<2, 4>(g, x, w, bias, slope, y, sums, part, ws_bytes, s);
+        case 3: return launch_gemm_stats<3, 2>(g, x, w, bias, slope, y, sums, part, ws_bytes, s);
+        // 4 channel tiles: the statistics registers do not fit next to 128 accumulators (58 spills): not built
+    }
+    return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1 stats: Cout %d > 96", Cout);
+}
+
 int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout,
                           long HW, hipStream_t s) {
     G1 g{};

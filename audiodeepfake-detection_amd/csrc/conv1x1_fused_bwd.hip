@@ -298,19 +298,22 @@ conv1x1_fused_bwd_kernel(const FB p) {
     if (lane == 0) slab[kCh * kCh + kCh] = ds;
 }
 
-__global__ void __launch_bounds__(256)
+// 64 outputs per workgroup, 16 slab groups (waves) each: coalesced reads, fixed summation order
+__global__ void __launch_bounds__(1024)
 conv1x1_fused_bwd_reduce_kernel(const float* __restrict__ partial, int nslabs, int Cin, int C,
                                 float* __restrict__ G, float* __restrict__ db, float* __restrict__ dslope) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e > kCh * kCh + kCh) return;
-    float s0 = 0.f, s1 = 0.f;
-    int b = 0;
-    for (; b + 1 < nslabs; b += 2) {
-        s0 += partial[(size_t)b * kSlab + e];
-        s1 += partial[(size_t)(b + 1) * kSlab + e];
-    }
-    if (b < nslabs) s0 += partial[(size_t)b * kSlab + e];
-    const float s = s0 + s1;
+    __shared__ float red[16][64];
+    const int o = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + o;
+    float s = 0.f;
+    if (e <= kCh * kCh + kCh)
+        for (int b = sg; b < nslabs; b += 16) s += partial[(size_t)b * kSlab + e];
+    red[sg][o] = s;
+    __syncthreads();
+    if (sg != 0 || e > kCh * kCh + kCh) return;
+    s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += red[j][o];
     if (e < kCh * kCh) {
         const int co = e >> 6, ci = e & 63;
         if (co < C && ci < Cin) G[(size_t)co * Cin + ci] = s;
@@ -391,7 +394,7 @@ extern "C" int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, con
         hipLaunchKernelGGL(conv1x1_fused_bwd_kernel<false>, dim3((unsigned)blocks), dim3(kWaves * 64), lds, s, p);
     int rc = afd::check_launch("conv1x1_fused_bwd_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(conv1x1_fused_bwd_reduce_kernel, dim3((kCh * kCh + kCh + 1 + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(conv1x1_fused_bwd_reduce_kernel, dim3((kCh * kCh + kCh + 1 + 63) / 64), dim3(1024), 0, s,
                        p.partial, nslabs, Cin, C, G, db, dslope);
     return afd::check_launch("conv1x1_fused_bwd_reduce_kernel");
 }

@@ -135,6 +135,14 @@ int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, const float* 
                                    const float* slope, float* u, uint8_t* idx, int N, int Cin, int H, int W,
                                    int Cout, void* ws, size_t ws_bytes, afd_stream_t stream);
 
+/* 1x1 convolution forward that also produces the batch statistics of the BatchNorm behind its activation:
+ * y = w x + bias ([N][Cout][HW]) and sums[c] = sum PReLU(y[c]), sums[Cout + c] = sum PReLU(y[c])^2 over all
+ * pixels (the layout afd_bn_finalize takes; overwritten, deterministic).  Saves the statistics pass of
+ * Conv2d(k=1) -> PReLU -> BatchNorm (reference models.py:262-264). */
+size_t afd_conv1x1_forward_stats_workspace_bytes(int Cout);
+int afd_conv1x1_forward_stats(const float* x, const float* w, const float* bias /* may be NULL */,
+                              const float* slope, float* y, double* sums, int N, int Cin, int Cout, long HW,
+                              void* ws, size_t ws_bytes, afd_stream_t stream);
 /* BatchNorm2d(affine=False) -> Conv2d(k=1, pad 0) pair (reference models.py:260-262, DCNN blocks 1-2).
  * Forward needs no kernel of its own: the normalisation is a per-input-channel scale and shift, so the
  * caller folds it into the weights (wf[co][ci] = w[co][ci] * invstd[ci], bf = b - wf . mean) and runs

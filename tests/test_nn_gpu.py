@@ -449,6 +449,36 @@ def test_conv1_pool_backward_with_affine_gradient():
         assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
 
 
+def test_conv1x1_epilogue_returns_batchnorm_sums():
+    """`afd_conv1x1_forward_stats`: the output equals the plain launch bit for bit and the per-channel sums of
+    PReLU(y) and its square match float64 sums of that output."""
+    torch.manual_seed(13)
+    lib = _native.load()
+    slope = torch.full((1,), 0.25, device="cuda")
+
+    for cin, co, hw in ((64, 64, 13 * 1157), (32, 40, 999), (64, 96, 4097)):
+        xx = torch.randn(2, cin, hw, device="cuda")
+        c1 = torch.nn.Conv2d(cin, co, 1).cuda()
+        w1, b1 = c1.weight.detach().reshape(co, cin).contiguous(), c1.bias.detach()
+        y0 = torch.empty(2, co, hw, device="cuda")
+        wsz = lib.afd_conv2d_workspace_bytes(2, cin, 1, hw, co, 1, 0, 1)
+        ws0 = torch.empty(max(wsz, 16), dtype=torch.uint8, device="cuda")
+        _native.check(lib.afd_conv2d_forward(_native.ptr(xx), _native.ptr(w1), _native.ptr(b1), _native.ptr(y0), 2,
+                                             cin, 1, hw, co, 1, 0, 1, _native.ptr(ws0), ws0.numel(),
+                                             _native.stream_ptr()), "conv")
+        y1 = torch.empty_like(y0)
+        s2 = torch.empty(2 * co + 1, dtype=torch.float64, device="cuda")
+        ws1 = torch.empty(lib.afd_conv1x1_forward_stats_workspace_bytes(co), dtype=torch.uint8, device="cuda")
+        _native.check(lib.afd_conv1x1_forward_stats(
+            _native.ptr(xx), _native.ptr(w1), _native.ptr(b1), _native.ptr(slope), _native.ptr(y1), _native.ptr(s2),
+            2, cin, co, hw, _native.ptr(ws1), ws1.numel(), _native.stream_ptr()), "conv stats")
+        assert torch.equal(y0, y1)
+        pz = torch.where(y0 > 0, y0, 0.25 * y0).double()
+        ref = torch.cat([pz.sum((0, 2)), (pz ** 2).sum((0, 2))])
+        err = (s2[:2 * co] - ref).abs()
+        assert (err <= 3e-6 * ref.abs() + 1e-4).all(), err.max().item()
+
+
 WIDE3X3 = [(2, 32, 6, 1100, 64), (1, 96, 4, 1025, 128), (1, 64, 13, 1157, 96), (2, 64, 51, 129, 96)]
 
 
