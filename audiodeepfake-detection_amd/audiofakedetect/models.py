@@ -67,6 +67,8 @@ class DCNN(nn.Module):
         cnn = self.cnn
         pending_bn = None  # a BatchNorm waiting to be folded into the 1x1 convolution after it
         link = None        # hand-over of a gradient term from block 2's backward to block 1's
+        bn_link = None     # from a BatchNorm to the 3x3 convolution after it: that layer's backward-data launch
+        #                    also produces the BatchNorm's backward sums
         for step, (conv_i, prelu_i, pooled, bn_i) in enumerate(self._cnn_plan):
             conv = cnn[conv_i]
             slope = cnn[prelu_i].weight
@@ -87,30 +89,35 @@ class DCNN(nn.Module):
             if (pending_bn is not None and not pooled and bn_i is not None
                     and ops.bn_conv1x1_prelu_bn_applicable(pending_bn, conv, cnn[bn_i])):
                 # training step of block 2: BatchNorm -> 1x1 convolution -> PReLU -> BatchNorm with a one-pass backward
+                bn_link = {}
                 h = ops.bn_conv1x1_prelu_bn(h, pending_bn, conv.weight, conv.bias, slope, cnn[bn_i],
-                                            self.sync_bn, link)
+                                            self.sync_bn, link, bn_link)
                 pending_bn = link = None
                 continue
             link = None
+            in_link, bn_link = bn_link, None
             if pending_bn is not None:
                 # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
                 z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)
                 pending_bn = None
             elif pooled and ops.conv3x3_prelu_maxpool_applicable(h, conv):
                 # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue: the conv output is never written
-                h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope)
+                h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link)
                 fused_pool = True
             else:
-                z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled)
+                z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled,
+                               bn_link=in_link)
             if pooled:
                 if not fused_pool:
                     h = ops.prelu_maxpool2x2(z, slope)
                 if fold_next:
                     pending_bn = cnn[bn_i]
                 elif bn_i is not None:
-                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
+                    bn_link = {}
+                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link)
             else:
-                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn)
+                bn_link = {}
+                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link)
         # Dropout + [batch, channels, time, packets] -> [batch, time, channels, packets]
         h = ops.dropout_permute(h, cnn[-1].p, self.training)
         dil = self.dil_conv

@@ -216,7 +216,8 @@ def transpose_contiguous(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, pad, dil, pooled):
+    def forward(ctx, x, w, b, pad, dil, pooled, bn_link=None):
+        ctx.bn_link = bn_link
         lib = _lib()
         x = _f32c(x)
         w = _f32c(w)
@@ -248,20 +249,33 @@ class _Conv2d(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dy,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link)
+        return dx, dw, db, None, None, None, None
 
 
-def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db):
+def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None):
     """Backward-data on the current stream; backward-weight on the second stream, added straight into
-    the FusedAdam gradient arena, when the parameters live there (see `_Conv2d`)."""
+    the FusedAdam gradient arena, when the parameters live there (see `_Conv2d`).  `bn_link`: when x was the
+    output of a training-mode BatchNorm (which set "bn" there), the backward-data launch also produces that
+    BatchNorm's backward sums -- of dx and of dx * x -- and leaves them in the dict."""
     lib = _lib()
     n, cin, h, wd, cout, k, pad, dil = geom
     dy = _f32c(dy)
     nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
     ws = _ws(nbytes, x.device)
     dx = dw = db = None
-    if need_dx:
+    bn = bn_link.get("bn") if bn_link is not None else None
+    if (need_dx and bn is not None and k == 3 and pad == 1 and dil == 1
+            and lib.afd_conv3x3_backward_data_bnstats_applicable(cin, h, wd, cout)):
+        dx = torch.empty_like(x)
+        sums = torch.empty(2 * cin, dtype=torch.float64, device=x.device)
+        sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), x.device, "bnstats")
+        _native.check(lib.afd_conv3x3_backward_data_bnstats(
+            _native.ptr(dy), _native.ptr(w), _native.ptr(dx), _native.ptr(x), _native.ptr(sums), n, cin, h, wd,
+            cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()),
+            "afd_conv3x3_backward_data_bnstats")
+        bn_link["bwd_sums"] = sums
+    elif need_dx:
         dx = torch.empty_like(x)
         _native.check(lib.afd_conv2d_backward_data(
             _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
@@ -307,10 +321,12 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
     return dx, dw, db
 
 
-def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1, pooled: bool = False):
+def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1, pooled: bool = False,
+           bn_link: Optional[dict] = None):
     """``pooled=True``: the result only feeds ``prelu_maxpool2x2`` (whose backward zeroes the
-    gradient of an odd last row / column), so those need not be computed."""
-    return _Conv2d.apply(x, w, b, int(padding), int(dilation), bool(pooled))
+    gradient of an odd last row / column), so those need not be computed.  ``bn_link``: the dict given to the
+    BatchNorm call that produced x (its ONLY consumer being this convolution), see `_conv2d_backward`."""
+    return _Conv2d.apply(x, w, b, int(padding), int(dilation), bool(pooled), bn_link)
 
 
 # --------------------------------------------------------------------------------------
@@ -411,7 +427,8 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
     written.  Backward: pool/PReLU backward from (u, code), then the convolution's backward."""
 
     @staticmethod
-    def forward(ctx, x, w, b, slope):
+    def forward(ctx, x, w, b, slope, bn_link=None):
+        ctx.bn_link = bn_link
         lib = _lib()
         x = _f32c(x)
         w = _f32c(w)
@@ -446,8 +463,8 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
             _native.ptr(dslope), n * cout, h, wd, _native.stream_ptr()), "afd_prelu_pool_backward")
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dz,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, dslope
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link)
+        return dx, dw, db, dslope, None
 
 
 def conv3x3_prelu_maxpool_applicable(x, conv: torch.nn.Module) -> bool:
@@ -461,9 +478,10 @@ def conv3x3_prelu_maxpool_applicable(x, conv: torch.nn.Module) -> bool:
     return bool(_lib().afd_conv3x3_prelu_pool_applicable(cin, h, w, conv.out_channels))
 
 
-def conv3x3_prelu_maxpool(x, w, b, slope):
-    """MaxPool2d(2, 2)(PReLU(conv2d(x, w, b, padding=1))) without materialising the convolution output."""
-    return _Conv3x3PReLUPool.apply(x, w, b, slope)
+def conv3x3_prelu_maxpool(x, w, b, slope, bn_link: Optional[dict] = None):
+    """MaxPool2d(2, 2)(PReLU(conv2d(x, w, b, padding=1))) without materialising the convolution output.
+    ``bn_link``: as for `conv2d`."""
+    return _Conv3x3PReLUPool.apply(x, w, b, slope, bn_link)
 
 
 # --------------------------------------------------------------------------------------
@@ -506,7 +524,8 @@ def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, sync):
+                eps, sync, link=None):
+        ctx.link = link
         lib = _lib()
         x = _f32c(x)
         n, c = x.shape[0], x.shape[1]
@@ -554,6 +573,9 @@ class _BatchNorm(torch.autograd.Function):
         ctx.save_for_backward(x, slope if slope is not None else empty, mean, invstd,
                               gamma if gamma is not None else empty)
         ctx.flags = (slope is not None, gamma is not None, training, sync)
+        if link is not None and training and gamma is None:
+            # the consumer's backward-data launch can produce this layer's backward sums (`_conv2d_backward`)
+            link["bn"] = True
         return y
 
     @staticmethod
@@ -581,17 +603,19 @@ class _BatchNorm(torch.autograd.Function):
                 neg = x <= 0
                 dslope = (g * x * neg).sum().reshape(1)
                 g = torch.where(neg, g * slope, g)
-            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None
+            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]
         hw = x.numel() // (n * c)
         dy = _f32c(dy)
-        sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
-        _native.check(lib.afd_bn_backward_stats(
-            _native.ptr(x), _native.ptr(slope), _native.ptr(dy), _native.ptr(mean),
-            _native.ptr(invstd), _native.ptr(sums), n, c, hw, _native.stream_ptr()),
-            "afd_bn_backward_stats")
+        sums = ctx.link.pop("bwd_sums", None) if ctx.link is not None else None
+        if sums is None:
+            sums = torch.empty(2 * c, dtype=torch.float64, device=x.device)
+            _native.check(lib.afd_bn_backward_stats(
+                _native.ptr(x), _native.ptr(slope), _native.ptr(dy), _native.ptr(mean),
+                _native.ptr(invstd), _native.ptr(sums), n, c, hw, _native.stream_ptr()),
+                "afd_bn_backward_stats")
         dgamma = dbeta = None
         if has_gamma:
             dbeta = sums[:c].float()
@@ -613,7 +637,7 @@ class _BatchNorm(torch.autograd.Function):
             _native.ptr(invstd), _native.ptr(gamma), _native.ptr(mdy), _native.ptr(mdyx),
             _native.ptr(dx), _native.ptr(dslope), n, c, hw, _native.stream_ptr()),
             "afd_bn_backward_apply")
-        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 class _BNConv1x1(torch.autograd.Function):
@@ -781,7 +805,8 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
     producer of u through `link` (or added here when there is no such producer)."""
 
     @staticmethod
-    def forward(ctx, u, w, b, slope, bn1, bn2, sync, link):
+    def forward(ctx, u, w, b, slope, bn1, bn2, sync, link, out_link=None):
+        ctx.out_link = out_link
         lib = _lib()
         u = _f32c(u)
         n, c, h, wd = u.shape
@@ -808,6 +833,8 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
             _native.ptr(z), _native.ptr(slope), _native.ptr(mean2), _native.ptr(invstd2), None, None,
             _native.ptr(y), n, cout, hw, _native.stream_ptr()), "afd_bn_apply_forward")
         _tap("prelu", z)
+        if out_link is not None:
+            out_link["bn"] = True
         ctx.save_for_backward(u, z, w2, wf, mean1, invstd1, mean2, invstd2, slope)
         ctx.geom = (n, c, h, wd, cout)
         ctx.cfg = (sync, b is not None, tuple(w.shape), cnt1, cnt2, link)
@@ -822,11 +849,14 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         hw = h * wd
         dev = u.device
         g = _f32c(g)
-        # second BatchNorm: batch means of g and g * xhat (one reduction pass), folded into per-channel constants
-        sums = torch.empty(2 * cout, dtype=torch.float64, device=dev)
-        _native.check(lib.afd_bn_backward_stats(
-            _native.ptr(z), _native.ptr(slope), _native.ptr(g), _native.ptr(mean2), _native.ptr(invstd2),
-            _native.ptr(sums), n, cout, hw, _native.stream_ptr()), "afd_bn_backward_stats")
+        # second BatchNorm: batch sums of g and g * xhat -- from the launch that produced g, or one reduction
+        # pass -- folded into per-channel constants
+        sums = ctx.out_link.pop("bwd_sums", None) if ctx.out_link is not None else None
+        if sums is None:
+            sums = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+            _native.check(lib.afd_bn_backward_stats(
+                _native.ptr(z), _native.ptr(slope), _native.ptr(g), _native.ptr(mean2), _native.ptr(invstd2),
+                _native.ptr(sums), n, cout, hw, _native.stream_ptr()), "afd_bn_backward_stats")
         if _dist_on(sync):
             dist.all_reduce(sums)
         mdy = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -867,7 +897,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
                 du = torch.addcmul(t + beta.view(1, -1, 1, 1), u, alpha.view(1, -1, 1, 1))
         return (du, dw.reshape(wshape) if ctx.needs_input_grad[1] else None,
                 db if (has_bias and ctx.needs_input_grad[2]) else None,
-                dslope if ctx.needs_input_grad[3] else None, None, None, None, None)
+                dslope if ctx.needs_input_grad[3] else None, None, None, None, None, None)
 
 
 def bn_conv1x1_prelu_bn_applicable(bn1: torch.nn.Module, conv: torch.nn.Module, bn2: torch.nn.Module) -> bool:
@@ -879,18 +909,23 @@ def bn_conv1x1_prelu_bn_applicable(bn1: torch.nn.Module, conv: torch.nn.Module, 
     return bool(_lib().afd_conv1x1_prelu_bn_backward_applicable(conv.in_channels, conv.out_channels))
 
 
-def bn_conv1x1_prelu_bn(u, bn1, w, b, slope, bn2, sync: bool = True, link: Optional[dict] = None):
+def bn_conv1x1_prelu_bn(u, bn1, w, b, slope, bn2, sync: bool = True, link: Optional[dict] = None,
+                        out_link: Optional[dict] = None):
     """batch_norm2(PReLU(conv1x1(batch_norm1(u)))) in training mode with the one-pass backward of
-    `_BNConv1x1PReLUBN`.  `link`: the dict given to `conv1_prelu_maxpool` when that call produced u."""
-    return _BNConv1x1PReLUBN.apply(u, w, b, slope, bn1, bn2, sync, link)
+    `_BNConv1x1PReLUBN`.  `link`: the dict given to `conv1_prelu_maxpool` when that call produced u;
+    `out_link`: as `batch_norm`'s `link`, for the second BatchNorm and the convolution that consumes the result."""
+    return _BNConv1x1PReLUBN.apply(u, w, b, slope, bn1, bn2, sync, link, out_link)
 
 
-def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True):
+def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True,
+               link: Optional[dict] = None):
     """BatchNorm (batch statistics across all ranks when a process group is up) of
-    PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats."""
+    PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats.  `link`: a dict shared with
+    the convolution that is the ONLY consumer of the result (its `bn_link`): that layer's backward-data launch
+    then also produces this layer's backward sums."""
     training = bn.training or bn.running_mean is None
     return _BatchNorm.apply(x, slope, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync)
+                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link)
 
 
 # --------------------------------------------------------------------------------------

@@ -46,6 +46,13 @@ struct GW {
     float* u;
     unsigned char* idx;
     int nchunks;
+    // backward-data launches whose result is the gradient of a BatchNorm output (afd_conv3x3_backward_data_bnstats):
+    // the epilogue also sums, per channel, g and g * xhat over its outputs, xhat the BatchNorm output (the forward
+    // convolution's input) at the same position -- one partial row [sum g | sum g xhat] per workgroup, rows of
+    // this launch from part_row0
+    const float* bn_in;
+    float* stat_part;
+    int part_row0;
 };
 
 // U table: [chunk][position][mt][kstep][lane] = U_p[32 mt + (lane & 31)][8 chunk + 2 kstep + (lane >> 5)]
@@ -92,7 +99,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restri
 // BORDER: the launch covers the first and last workgroup column of every tile row (patches that
 // reach outside the image: element loads with clamped addresses); the other launch covers the
 // columns in between with one unaligned 16-byte load per patch row.  No divergent paths inside.
-template <int MT, int NT, bool BORDER, bool POOL>
+template <int MT, int NT, bool BORDER, bool POOL, bool BST = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ U,
                  const float* __restrict__ bias, float* __restrict__ y) {
@@ -262,11 +269,31 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     const int tl_e = tid & 31;
     const int co_l = tid >> 5;  // 0..15 (+16 for the second pair)
     const int oy = 2 * ty;
+    float sg[BST ? MT : 1][2], sgv[BST ? MT : 1][2];  // BST: sums over this thread's outputs of channel 32 m + co_l + 16 j
+    if constexpr (BST) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) sg[m][0] = sg[m][1] = sgv[m][0] = sgv[m][1] = 0.f;
+    }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float* E = lds + ((m * NT + nt) & 1) * (16 * 32 * kTiles);  // [16][32][kTiles]
+            // BST: the BatchNorm inputs at this round's output positions are requested before the LDS round trip
+            f2u zq[BST ? 2 : 1][2];
+            if constexpr (BST) {
+                // two 8-byte loads per channel from clamped (always valid) addresses; the products are masked below
+                const int txq = tx0 + nt * 32 + tl_e;
+                const int oxq = min(2 * txq, g.W - 2);
+                const int r1 = oy + 1 < g.H ? g.W : 0;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = min(32 * m + co_l + 16 * j, g.Cout - 1);
+                    const float* zi = g.bn_in + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + oxq;
+                    zq[j][0] = *reinterpret_cast<const f2u*>(zi);
+                    zq[j][1] = *reinterpret_cast<const f2u*>(zi + r1);
+                }
+            }
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
                 float* e = E + (size_t)(2 * wave + pi) * (32 * kTiles) + l31;
@@ -316,6 +343,15 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
                 } else if (co < g.Cout && txe < g.tilesX) {
                     float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
                     const bool two = ox + 1 < g.cols;
+                    if constexpr (BST) {
+                        // (the clamped column only differs from ox where `two` is false: W odd, last column, whose
+                        // value then sits in the pair's second element)
+                        const bool row2 = oy + 1 < g.rows;
+                        const float z00 = two ? zq[j][0].x : zq[j][0].y, z10 = two ? zq[j][1].x : zq[j][1].y;
+                        const float g01 = two ? y01 : 0.f, g10 = row2 ? y10 : 0.f, g11 = (two && row2) ? y11 : 0.f;
+                        sg[m][j] += (y00 + g01) + (g10 + g11);
+                        sgv[m][j] += fmaf(y00, z00, g01 * zq[j][0].y) + fmaf(g10, z10, g11 * zq[j][1].y);
+                    }
                     if (two) {
                         f2u v0 = {y00, y01};
                         *reinterpret_cast<f2u*>(yo) = v0;
@@ -331,18 +367,65 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
             }
         }
     }
+    if constexpr (BST) {
+        // a channel's outputs of this workgroup sit in the 32 lanes of one wave half
+        constexpr int CO_PAD = MT * 32;
+        float* row = g.stat_part + ((size_t)g.part_row0 + blockIdx.x) * (2 * CO_PAD);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float a1 = sg[m][j], a2 = sgv[m][j];
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    a1 += __shfl_xor(a1, off, 64);
+                    a2 += __shfl_xor(a2, off, 64);
+                }
+                if (tl_e == 0) {
+                    row[32 * m + co_l + 16 * j] = a1;
+                    row[CO_PAD + 32 * m + co_l + 16 * j] = a2;
+                }
+            }
+    }
 }
 
-template <int MT, int NT, bool POOL>
+// partial rows [rows][2 co_pad] -> part2 [gridDim.x][2 co_pad] doubles (thread = slot, rows strided over the blocks)
+__global__ void __launch_bounds__(256)
+wino_bnstats_reduce1_kernel(const float* __restrict__ part, int rows, int slots, double* __restrict__ part2) {
+    const int e = threadIdx.x;
+    if (e >= slots) return;
+    double s = 0.0;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) s += (double)part[(size_t)r * slots + e];
+    part2[(size_t)blockIdx.x * slots + e] = s;
+}
+
+// sums[c] = sum g, sums[C + c] = sum g xhat: what afd_bn_backward_means takes
+__global__ void __launch_bounds__(256)
+wino_bnstats_reduce2_kernel(const double* __restrict__ part2, int rows2, int co_pad, int C,
+                            double* __restrict__ sums) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows2; ++r) {
+        s1 += part2[(size_t)r * 2 * co_pad + c];
+        s2 += part2[(size_t)r * 2 * co_pad + co_pad + c];
+    }
+    sums[c] = s1;
+    sums[C + c] = s2;
+}
+
+constexpr int kStatBlocks = 256;
+
+template <int MT, int NT, bool POOL, bool BST = false>
 int launch_wino_t(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 16 * 32 * kTiles * sizeof(float);  // 128 KB: two epilogue images (V double buffer inside)
     static_assert(2 * 16 * kCh * kTiles * NT * sizeof(float) <= lds, "V double buffer fits the epilogue image");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, false, POOL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, false, POOL, BST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, true, POOL>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, true, POOL, BST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd conv: %s", hipGetErrorString(e));
         attr = true;
@@ -355,20 +438,33 @@ int launch_wino_t(GW g, const float* x, const float* U, const float* bias, float
     const int edge = g.wgX >= 2 ? 2 : 1;
     if (rows * (inner > edge ? inner : edge) > 0x7fffffffL)
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: grid too large");
+    g.part_row0 = 0;
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino_conv_kernel<MT, NT, false, POOL>), dim3((unsigned)(rows * inner)), dim3(kThreads), lds,
+        hipLaunchKernelGGL((wino_conv_kernel<MT, NT, false, POOL, BST>), dim3((unsigned)(rows * inner)), dim3(kThreads), lds,
                            s, g, x, U, bias, y);
+        g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino_conv_kernel<MT, NT, true, POOL>), dim3((unsigned)(rows * edge)), dim3(kThreads), lds, s,
+    hipLaunchKernelGGL((wino_conv_kernel<MT, NT, true, POOL, BST>), dim3((unsigned)(rows * edge)), dim3(kThreads), lds, s,
                        g, x, U, bias, y);
     return afd::check_launch("wino_conv_kernel");
 }
 
 template <int MT, int NT>
 int launch_wino(const GW& g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
+    if constexpr (NT == 2 && (MT == 2 || MT == 3)) {
+        if (g.stat_part) return launch_wino_t<MT, NT, false, true>(g, x, U, bias, y, s);
+    }
+    if (g.stat_part) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: statistics epilogue not built for this shape");
     return g.u ? launch_wino_t<MT, NT, true>(g, x, U, bias, y, s) : launch_wino_t<MT, NT, false>(g, x, U, bias, y, s);
+}
+
+// workgroups (= partial rows) of a launch pair over N images of H x W outputs
+long wino_stat_rows(int N, int H, int W) {
+    const int tilesX = (W + 1) / 2, tilesY = (H + 1) / 2;
+    const int wgX = (tilesX + kTiles * 2 - 1) / (kTiles * 2);
+    return (long)N * tilesY * wgX;
 }
 
 }  // namespace
@@ -391,7 +487,7 @@ size_t wino_workspace_bytes(int Cin, int Cout) {
 // same contract as conv3x3_run (conv3x3.hip)
 int wino_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
              int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
-             const float* slope, float* u, unsigned char* idx) {
+             const float* slope, float* u, unsigned char* idx, const float* bn_in, float* stat_part) {
     if (!ws || ws_bytes < wino_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd conv: workspace too small");
     GW g{};
@@ -403,6 +499,7 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     g.nchunks = Cin / kCh;
     g.slope = slope; g.u = u; g.idx = idx;
+    g.bn_in = bn_in; g.stat_part = stat_part;
     if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx))
         return afd::fail(AFD_ERR_ARG, "winograd conv + pool: bad arguments");
     const int MT = (Cout + 31) / 32;
@@ -425,3 +522,44 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
 }
 
 }  // namespace afd
+
+// ---- backward-data of a 3x3 convolution whose input was a BatchNorm output, with that BatchNorm's backward sums ----
+extern "C" int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int W, int Cout) {
+    // the backward-data GEMM has the forward's Cout as its input channels; only the wide 32x32x2 Winograd kernel
+    // with two or three channel tiles carries the statistics epilogue
+    if (getenv("AFD_NO_BWD_BNSTATS")) return 0;
+    if (afd::wino16_applicable(Cout, H, W, Cin) || !afd::wino_applicable(Cout, H, W, Cin)) return 0;
+    if (getenv("AFD_WINO_NT1")) return 0;
+    const int mt = (Cin + 31) / 32;
+    return mt == 2 || mt == 3;
+}
+
+extern "C" size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, int W) {
+    const size_t slots = 2 * ((size_t)(Cin + 31) / 32 * 32);
+    return (size_t)wino_stat_rows(N, H, W) * slots * sizeof(float) + (size_t)kStatBlocks * slots * sizeof(double) + 64;
+}
+
+extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w, float* dx, const float* xhat,
+                                                 double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
+                                                 size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes,
+                                                 afd_stream_t stream) {
+    if (!dy || !w || !dx || !xhat || !sums || !ws || !stat_ws)
+        return afd::fail(AFD_ERR_ARG, "conv3x3 dgrad + bn sums: null pointer");
+    if (N < 1 || W < 2 || !afd_conv3x3_backward_data_bnstats_applicable(Cin, H, W, Cout))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 dgrad + bn sums: shape not on the Winograd kernel");
+    if (stat_ws_bytes < afd_conv3x3_backward_data_bnstats_workspace_bytes(N, Cin, H, W))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv3x3 dgrad + bn sums: statistics workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int co_pad = (Cin + 31) / 32 * 32;
+    const int slots = 2 * co_pad;
+    const long rows = wino_stat_rows(N, H, W);
+    float* part = static_cast<float*>(stat_ws);
+    double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
+    int rc = afd::wino_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, nullptr, nullptr, nullptr,
+                           xhat, part);
+    if (rc) return rc;
+    const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
+    hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3(1), dim3(256), 0, s, part2, blocks, co_pad, Cin, sums);
+    return afd::check_launch("wino_bnstats_reduce kernels");
+}

@@ -169,6 +169,17 @@ int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, const float* u
                                   const float* coef, const float* slope, float* t, float* G, float* db,
                                   float* dslope /* += */, int N, int Cin, int C, long HW, void* ws,
                                   size_t ws_bytes, afd_stream_t stream);
+/* Backward-data of Conv2d(Cin, Cout, 3, padding=1) whose input xhat [N][Cin][H][W] was the output of a
+ * training-mode BatchNorm without affine parameters, with that BatchNorm's backward sums from the same launch:
+ * dx = conv_transpose(dy, w) as afd_conv2d_backward_data, and sums[c] = sum_px dx[c], sums[Cin + c] =
+ * sum_px dx[c] xhat[c] (double, the layout afd_bn_backward_means takes; deterministic).  Saves the statistics
+ * pass of the batch-norm backward (reference models.py:264-268: SyncBatchNorm -> Conv2d k3).
+ * `ws` as for afd_conv2d_backward_data. */
+int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int W, int Cout);
+size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, int W);
+int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w, float* dx, const float* xhat, double* sums,
+                                      int N, int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes,
+                                      void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
 int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                float* dbias /* may be NULL */, int N, int Cin, int H, int W,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,

@@ -479,6 +479,51 @@ def test_conv1x1_epilogue_returns_batchnorm_sums():
         assert (err <= 3e-6 * ref.abs() + 1e-4).all(), err.max().item()
 
 
+@pytest.mark.parametrize("shape,cout,act", [((2, 64, 13, 1157), 96, True), ((1, 96, 6, 1030), 128, False),
+                                            ((2, 64, 4, 200), 96, True), ((1, 64, 3, 131), 96, False)])
+def test_backward_data_with_batchnorm_sums(shape, cout, act):
+    """`afd_conv3x3_backward_data_bnstats`: dx equals the plain backward-data launch bit for bit, and the sums of
+    dx and dx * xhat (xhat the convolution's input) match float64 sums; then end to end through autograd:
+    BatchNorm -> 3x3 convolution with the linked backward equals the unlinked one."""
+    torch.manual_seed(14)
+    lib = _native.load()
+    n, cin, h, w = shape
+    assert lib.afd_conv3x3_backward_data_bnstats_applicable(cin, h, w, cout)
+    dy = torch.randn(n, cout, h, w, device="cuda")
+    wt = (torch.randn(cout, cin, 3, 3, device="cuda") * 0.05).contiguous()
+    xhat = torch.randn(shape, device="cuda")
+    slope = torch.full((1,), 0.25, device="cuda") if act else None
+    ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin, h, w, cout, 3, 1, 1), dtype=torch.uint8, device="cuda")
+    dx0 = torch.empty(shape, device="cuda")
+    _native.check(lib.afd_conv2d_backward_data(_native.ptr(dy), _native.ptr(wt), _native.ptr(dx0), n, cin, h, w, cout,
+                                               3, 1, 1, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "dgrad")
+    dx1 = torch.empty_like(dx0)
+    sums = torch.empty(2 * cin, dtype=torch.float64, device="cuda")
+    sws = torch.empty(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, w), dtype=torch.uint8,
+                      device="cuda")
+    _native.check(lib.afd_conv3x3_backward_data_bnstats(
+        _native.ptr(dy), _native.ptr(wt), _native.ptr(dx1), _native.ptr(xhat), _native.ptr(sums), n, cin, h, w, cout,
+        _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "dgrad + sums")
+    assert torch.equal(dx0, dx1)
+    ref = torch.cat([dx0.double().sum((0, 2, 3)), (dx0.double() * xhat.double()).sum((0, 2, 3))])
+    scale = (dx0.double().abs() * xhat.double().abs()).sum((0, 2, 3)).max().item()
+    assert (sums - ref).abs().max().item() <= 2e-6 * scale
+    bn_in = xhat
+
+    # autograd: BatchNorm -> Conv2d(3x3) with and without the link
+    bn = torch.nn.BatchNorm2d(cin, affine=False).cuda().train()
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    grads = []
+    for linked in (False, True):
+        z = bn_in.clone().requires_grad_(True)
+        link = {} if linked else None
+        y = ops.conv2d(ops.batch_norm(z, bn, slope, False, link), conv.weight, conv.bias, 1, 1, bn_link=link)
+        y.backward(dy)
+        grads.append(z.grad)
+        assert not linked or "bwd_sums" not in link  # consumed by the BatchNorm's backward
+    _close(grads[1], grads[0].cpu(), 2e-6, "linked BatchNorm backward")
+
+
 WIDE3X3 = [(2, 32, 6, 1100, 64), (1, 96, 4, 1025, 128), (1, 64, 13, 1157, 96), (2, 64, 51, 129, 96)]
 
 
