@@ -270,9 +270,25 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     const int co_l = tid >> 5;  // 0..15 (+16 for the second pair)
     const int oy = 2 * ty;
     float sg[BST ? MT : 1][2], sgv[BST ? MT : 1][2];  // BST: sums over this thread's outputs of channel 32 m + co_l + 16 j
+    f2u zn[BST ? 2 : 1][2];
+    // BST: the BatchNorm outputs at a round's output positions: two 8-byte loads per channel from clamped (always
+    // valid) addresses; the products are masked where they are used
+    auto load_xhat = [&](int m, int nt) {
+        const int txq = tx0 + nt * 32 + tl_e;
+        const int oxq = min(2 * txq, g.W - 2);
+        const int r1 = oy + 1 < g.H ? g.W : 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = min(32 * m + co_l + 16 * j, g.Cout - 1);
+            const float* zi = g.bn_in + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + oxq;
+            zn[j][0] = *reinterpret_cast<const f2u*>(zi);
+            zn[j][1] = *reinterpret_cast<const f2u*>(zi + r1);
+        }
+    };
     if constexpr (BST) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) sg[m][0] = sg[m][1] = sgv[m][0] = sgv[m][1] = 0.f;
+        load_xhat(0, 0);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -282,17 +298,13 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
             // BST: the BatchNorm inputs at this round's output positions are requested before the LDS round trip
             f2u zq[BST ? 2 : 1][2];
             if constexpr (BST) {
-                // two 8-byte loads per channel from clamped (always valid) addresses; the products are masked below
-                const int txq = tx0 + nt * 32 + tl_e;
-                const int oxq = min(2 * txq, g.W - 2);
-                const int r1 = oy + 1 < g.H ? g.W : 0;
+                // this round's values were requested a round ago; the next round's are requested now
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int co = min(32 * m + co_l + 16 * j, g.Cout - 1);
-                    const float* zi = g.bn_in + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + oxq;
-                    zq[j][0] = *reinterpret_cast<const f2u*>(zi);
-                    zq[j][1] = *reinterpret_cast<const f2u*>(zi + r1);
+                    zq[j][0] = zn[j][0];
+                    zq[j][1] = zn[j][1];
                 }
+                if (m * NT + nt + 1 < MT * NT) load_xhat((m * NT + nt + 1) / NT, (m * NT + nt + 1) % NT);
             }
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
