@@ -640,6 +640,41 @@ class _BatchNorm(torch.autograd.Function):
         return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
+def _fold_forward(w2, b, mean, invstd):
+    """(wf, bf): weights / bias of the 1x1 convolution with the BatchNorm in front of it folded in."""
+    cout, c = w2.shape
+    wf = torch.empty_like(w2)
+    bf = torch.empty(cout, dtype=torch.float32, device=w2.device)
+    _native.check(_lib().afd_bn_fold_forward(_native.ptr(w2), _native.ptr(b), _native.ptr(mean), _native.ptr(invstd),
+                                             _native.ptr(wf), _native.ptr(bf), cout, c, _native.stream_ptr()),
+                  "afd_bn_fold_forward")
+    return wf, bf
+
+
+def _fold_backward(gw, db, w2, mean, invstd, count, sync, need_affine):
+    """dw against the normalised input from the gradient gw against the un-normalised one, and (alpha, beta) of
+    the input gradient du = wf^T dz + alpha u + beta (the BatchNorm backward rebuilt from the small matrices)."""
+    lib = _lib()
+    cout, c = w2.shape
+    dw = torch.empty_like(w2)
+    sums = torch.empty(2 * c, dtype=torch.float64, device=w2.device)
+    _native.check(lib.afd_bn_fold_backward_weights(
+        _native.ptr(gw), _native.ptr(db), _native.ptr(w2), _native.ptr(mean), _native.ptr(invstd), _native.ptr(dw),
+        _native.ptr(sums), cout, c, _native.stream_ptr()), "afd_bn_fold_backward_weights")
+    if not need_affine:
+        return dw, None, None
+    if _dist_on(sync):
+        dist.all_reduce(sums)
+    alpha = torch.empty(c, dtype=torch.float32, device=w2.device)
+    beta = torch.empty(c, dtype=torch.float32, device=w2.device)
+    on_dev = torch.is_tensor(count)
+    _native.check(lib.afd_bn_fold_backward_affine(
+        _native.ptr(sums), -1.0 if on_dev else float(count), _native.ptr(count) if on_dev else None,
+        _native.ptr(mean), _native.ptr(invstd), _native.ptr(alpha), _native.ptr(beta), c, _native.stream_ptr()),
+        "afd_bn_fold_backward_affine")
+    return dw, alpha, beta
+
+
 class _BNConv1x1(torch.autograd.Function):
     """BatchNorm2d(affine=False) followed by Conv2d(k=1, pad 0) as ONE pass over the activations
     in each direction (DCNN blocks 1 -> 2, reference models.py:260-262).
@@ -685,10 +720,7 @@ class _BNConv1x1(torch.autograd.Function):
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
         w2 = _f32c(w).reshape(cout, c)
-        wf = (w2 * invstd).contiguous()
-        bf = -(wf @ mean)
-        if b is not None:
-            bf = bf + b
+        wf, bf = _fold_forward(w2, b, mean.contiguous(), invstd.contiguous())
         z = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
         nbytes = lib.afd_conv2d_workspace_bytes(n, c, h, wd, cout, 1, 0, 1)
         ws = _ws(nbytes, dev)
@@ -716,21 +748,14 @@ class _BNConv1x1(torch.autograd.Function):
         _native.check(lib.afd_conv2d_backward_weight(
             _native.ptr(u), _native.ptr(dz), _native.ptr(g), _native.ptr(db), n, c, h, wd, cout, 1, 0, 1,
             _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_weight")
-        dw = (g - db[:, None] * mean[None, :]) * invstd[None, :]
+        need_aff = bool(ctx.needs_input_grad[0] and training)
+        # sums over pixels of dxhat and of dxhat * xhat come from the small matrices alone
+        dw, alpha, beta = _fold_backward(g, db, w2, mean.contiguous(), invstd.contiguous(),
+                                         ctx.count if training else 1.0, sync, need_aff)
         du = None
         if ctx.needs_input_grad[0]:
             du = torch.empty_like(u)
             if training:
-                # sum over pixels of dxhat and of dxhat * xhat, from the small matrices alone
-                sums = torch.stack([w2.t() @ db, (w2 * dw).sum(0)]).double().reshape(-1)
-                if _dist_on(sync):
-                    dist.all_reduce(sums)
-                cnt = ctx.count if torch.is_tensor(ctx.count) else float(ctx.count)
-                m1 = (sums[:c] / cnt).float()
-                m2 = (sums[c:] / cnt).float()
-                s2m2 = invstd * invstd * m2
-                alpha = (-s2m2).contiguous()
-                beta = (s2m2 * mean - invstd * m1).contiguous()
                 _native.check(lib.afd_conv1x1_bn_backward_data(
                     _native.ptr(dz), _native.ptr(wf), _native.ptr(u), _native.ptr(alpha),
                     _native.ptr(beta), _native.ptr(du), n, c, cout, h * wd, _native.stream_ptr()),
@@ -815,10 +840,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         dev = u.device
         mean1, invstd1, cnt1 = _bn_batch_stats(u, None, c, n, hw, bn1, sync)
         w2 = _f32c(w).reshape(cout, c)
-        wf = (w2 * invstd1).contiguous()
-        bf = -(wf @ mean1)
-        if b is not None:
-            bf = bf + b
+        wf, bf = _fold_forward(w2, b, mean1, invstd1)
         z = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
         # the convolution's epilogue also sums PReLU(z) and its square per channel: no statistics pass
         ws = _ws(lib.afd_conv1x1_forward_stats_workspace_bytes(cout), dev)
@@ -865,8 +887,10 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         _native.check(lib.afd_bn_backward_means(
             _native.ptr(sums), cout, -1.0 if on_dev else float(cnt2), _native.ptr(cnt2) if on_dev else None,
             _native.ptr(mdy), _native.ptr(mdyx), _native.stream_ptr()), "afd_bn_backward_means")
-        s2m = invstd2 * invstd2 * mdyx
-        coef = torch.stack([invstd2, -s2m, s2m * mean2 - invstd2 * mdy, torch.zeros_like(mdy)], dim=1).contiguous()
+        coef = torch.empty((cout, 4), dtype=torch.float32, device=dev)
+        _native.check(lib.afd_bn_backward_coef(_native.ptr(mean2), _native.ptr(invstd2), _native.ptr(mdy),
+                                               _native.ptr(mdyx), _native.ptr(coef), cout, _native.stream_ptr()),
+                      "afd_bn_backward_coef")
         t = torch.empty_like(u)
         gw = torch.empty((cout, c), dtype=torch.float32, device=dev)
         db = torch.empty(cout, dtype=torch.float32, device=dev)
@@ -878,18 +902,9 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
             n, c, cout, hw, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
             "afd_conv1x1_prelu_bn_backward")
         # first BatchNorm, from the small matrices alone (as in `_BNConv1x1`)
-        dw = (gw - db[:, None] * mean1[None, :]) * invstd1[None, :]
+        dw, alpha, beta = _fold_backward(gw, db, w2, mean1, invstd1, cnt1, sync, bool(ctx.needs_input_grad[0]))
         du = None
         if ctx.needs_input_grad[0]:
-            sums1 = torch.stack([w2.t() @ db, (w2 * dw).sum(0)]).double().reshape(-1)
-            if _dist_on(sync):
-                dist.all_reduce(sums1)
-            cnt = cnt1 if torch.is_tensor(cnt1) else float(cnt1)
-            m1 = (sums1[:c] / cnt).float()
-            m2 = (sums1[c:] / cnt).float()
-            s2m2 = invstd1 * invstd1 * m2
-            alpha = (-s2m2).contiguous()
-            beta = (s2m2 * mean1 - invstd1 * m1).contiguous()
             if link is not None:
                 link["affine"] = (alpha, beta)  # added by the producer of u where it reads du and u
                 du = t

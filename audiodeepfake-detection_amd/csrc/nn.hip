@@ -756,6 +756,115 @@ extern "C" int afd_bn_backward_means(const double* sums, int C, double count, co
     return afd::check_launch("bn_bwd_means_kernel");
 }
 
+// ---- the small matrices of a BatchNorm folded into the 1x1 convolution after it (ops._BNConv1x1*) ----
+namespace {
+
+// wf[co][ci] = w[co][ci] * invstd[ci];  bf[co] = b[co] - sum_ci wf[co][ci] * mean[ci]; one wave per output channel
+__global__ void __launch_bounds__(64)
+bn_fold_forward_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ mean,
+                       const float* __restrict__ invstd, float* __restrict__ wf, float* __restrict__ bf, int Cin) {
+    const int co = blockIdx.x, lane = threadIdx.x;
+    float acc = 0.f;
+    for (int ci = lane; ci < Cin; ci += 64) {
+        const float v = w[(size_t)co * Cin + ci] * invstd[ci];
+        wf[(size_t)co * Cin + ci] = v;
+        acc = fmaf(v, mean[ci], acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) bf[co] = (b ? b[co] : 0.f) - acc;
+}
+
+// dw[co][ci] = (G[co][ci] - db[co] mean[ci]) invstd[ci]  (gradient against the normalised input from the one
+// against the un-normalised input); sums[ci] = sum_co w[co][ci] db[co] = sum_px dxhat[ci],
+// sums[Cin + ci] = sum_co w[co][ci] dw[co][ci] = sum_px dxhat[ci] xhat[ci]; thread = input channel
+__global__ void __launch_bounds__(128)
+bn_fold_backward_weights_kernel(const float* __restrict__ G, const float* __restrict__ db,
+                                const float* __restrict__ w, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, float* __restrict__ dw,
+                                double* __restrict__ sums, int C, int Cin) {
+    const int ci = blockIdx.x * 128 + threadIdx.x;
+    if (ci >= Cin) return;
+    const float m = mean[ci], is = invstd[ci];
+    double s1 = 0.0, s2 = 0.0;
+    for (int co = 0; co < C; ++co) {
+        const float d = db[co], wv = w[(size_t)co * Cin + ci];
+        const float g = (G[(size_t)co * Cin + ci] - d * m) * is;
+        dw[(size_t)co * Cin + ci] = g;
+        s1 += (double)wv * (double)d;
+        s2 += (double)wv * (double)g;
+    }
+    sums[ci] = s1;
+    sums[Cin + ci] = s2;
+}
+
+// alpha = -invstd^2 E[dxhat xhat], beta = invstd^2 E[dxhat xhat] mean - invstd E[dxhat]
+__global__ void __launch_bounds__(128)
+bn_fold_backward_affine_kernel(const double* __restrict__ sums, double count, const double* __restrict__ count_dev,
+                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                               float* __restrict__ alpha, float* __restrict__ beta, int Cin) {
+    const int ci = blockIdx.x * 128 + threadIdx.x;
+    if (ci >= Cin) return;
+    const double cnt = count < 0.0 ? count_dev[0] : count;
+    const float m1 = (float)(sums[ci] / cnt), m2 = (float)(sums[Cin + ci] / cnt);
+    const float is = invstd[ci];
+    const float s2m2 = is * is * m2;
+    alpha[ci] = -s2m2;
+    beta[ci] = s2m2 * mean[ci] - is * m1;
+}
+
+// coef[c] = (A, B, K, 0): dP = A g + B P + K is the BatchNorm backward with the batch means folded in
+__global__ void __launch_bounds__(128)
+bn_backward_coef_kernel(const float* __restrict__ mean, const float* __restrict__ invstd,
+                        const float* __restrict__ mdy, const float* __restrict__ mdyx, float* __restrict__ coef,
+                        int C) {
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (c >= C) return;
+    const float is = invstd[c];
+    const float s2m = is * is * mdyx[c];
+    coef[4 * c] = is;
+    coef[4 * c + 1] = -s2m;
+    coef[4 * c + 2] = s2m * mean[c] - is * mdy[c];
+    coef[4 * c + 3] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int afd_bn_fold_forward(const float* w, const float* b, const float* mean, const float* invstd,
+                                   float* wf, float* bf, int C, int Cin, afd_stream_t stream) {
+    if (!w || !mean || !invstd || !wf || !bf || C < 1 || Cin < 1) return afd::fail(AFD_ERR_ARG, "bn fold: bad argument");
+    hipLaunchKernelGGL(bn_fold_forward_kernel, dim3(C), dim3(64), 0, AFD_STREAM, w, b, mean, invstd, wf, bf, Cin);
+    return afd::check_launch("bn_fold_forward_kernel");
+}
+
+extern "C" int afd_bn_fold_backward_weights(const float* G, const float* db, const float* w, const float* mean,
+                                            const float* invstd, float* dw, double* sums, int C, int Cin,
+                                            afd_stream_t stream) {
+    if (!G || !db || !w || !mean || !invstd || !dw || !sums || C < 1 || Cin < 1)
+        return afd::fail(AFD_ERR_ARG, "bn fold backward: bad argument");
+    hipLaunchKernelGGL(bn_fold_backward_weights_kernel, dim3((Cin + 127) / 128), dim3(128), 0, AFD_STREAM, G, db, w,
+                       mean, invstd, dw, sums, C, Cin);
+    return afd::check_launch("bn_fold_backward_weights_kernel");
+}
+
+extern "C" int afd_bn_fold_backward_affine(const double* sums, double count, const double* count_dev,
+                                           const float* mean, const float* invstd, float* alpha, float* beta,
+                                           int Cin, afd_stream_t stream) {
+    if (!sums || !mean || !invstd || !alpha || !beta || Cin < 1 || (count < 0.0 && !count_dev))
+        return afd::fail(AFD_ERR_ARG, "bn fold backward affine: bad argument");
+    hipLaunchKernelGGL(bn_fold_backward_affine_kernel, dim3((Cin + 127) / 128), dim3(128), 0, AFD_STREAM, sums, count,
+                       count_dev, mean, invstd, alpha, beta, Cin);
+    return afd::check_launch("bn_fold_backward_affine_kernel");
+}
+
+extern "C" int afd_bn_backward_coef(const float* mean, const float* invstd, const float* mdy, const float* mdyx,
+                                    float* coef, int C, afd_stream_t stream) {
+    if (!mean || !invstd || !mdy || !mdyx || !coef || C < 1) return afd::fail(AFD_ERR_ARG, "bn backward coef: bad argument");
+    hipLaunchKernelGGL(bn_backward_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, AFD_STREAM, mean, invstd, mdy,
+                       mdyx, coef, C);
+    return afd::check_launch("bn_backward_coef_kernel");
+}
+
 extern "C" int afd_bn_stats(const float* x, const float* slope, double* sums, int N, int C, int HW,
                             afd_stream_t stream) {
     if (!x || !sums || N < 1 || C < 1 || HW < 1) return afd::fail(AFD_ERR_ARG, "bn stats: bad argument");

@@ -296,6 +296,25 @@ int afd_bn_backward_apply(const float* x, const float* slope, const float* dy, c
  *   cross-rank all-reduce), else the host value.  running_* / nbt may be NULL.
  * backward means: mdy = sums[0:C] / count, mdyx = sums[C:2C] / count (count as above, read from
  *   count_dev when count < 0). */
+/* The small matrices of a BatchNorm(affine=False) folded into the 1x1 convolution after it (ops._BNConv1x1*;
+ * reference models.py:260-262), one launch each:
+ * fold forward: wf[co][ci] = w[co][ci] invstd[ci], bf[co] = b[co] - sum_ci wf[co][ci] mean[ci] (b may be NULL);
+ * fold backward weights: dw = (G - db (x) mean) invstd from the gradient G against the un-normalised input, and
+ *   the BatchNorm's backward sums sums[ci] = sum_co w db, sums[Cin + ci] = sum_co w dw (double; all-reduced by the
+ *   caller across ranks);
+ * fold backward affine: alpha, beta of du = wf^T dz + alpha u + beta from those sums and the count (count_dev when
+ *   count < 0);
+ * backward coef: coef[c] = (invstd, -invstd^2 mdyx, invstd^2 mdyx mean - invstd mdy, 0) for
+ *   afd_conv1x1_prelu_bn_backward. */
+int afd_bn_fold_forward(const float* w, const float* b, const float* mean, const float* invstd, float* wf,
+                        float* bf, int C, int Cin, afd_stream_t stream);
+int afd_bn_fold_backward_weights(const float* G, const float* db, const float* w, const float* mean,
+                                 const float* invstd, float* dw, double* sums, int C, int Cin,
+                                 afd_stream_t stream);
+int afd_bn_fold_backward_affine(const double* sums, double count, const double* count_dev, const float* mean,
+                                const float* invstd, float* alpha, float* beta, int Cin, afd_stream_t stream);
+int afd_bn_backward_coef(const float* mean, const float* invstd, const float* mdy, const float* mdyx,
+                         float* coef, int C, afd_stream_t stream);
 int afd_bn_finalize(const double* sums, int C, double count, float eps, float momentum, float* mean,
                     float* invstd, float* running_mean, float* running_var, long long* nbt,
                     double* count_out, afd_stream_t stream);
