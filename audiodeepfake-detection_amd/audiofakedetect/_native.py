@@ -75,6 +75,7 @@ _SIGNATURES = {
     "afd_prelu_dropout_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_sz, c_f, c_ul, c_p]),
     "afd_prelu_pool_forward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_prelu_pool_backward": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "afd_prelu_pool_backward_affine": (c_i, [c_p] * 5 + [c_i, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_bn_stats": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_bn_apply_forward": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_p]),
     "afd_bn_backward_stats": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_p]),

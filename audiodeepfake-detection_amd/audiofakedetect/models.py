@@ -96,25 +96,27 @@ class DCNN(nn.Module):
                 continue
             link = None
             in_link, bn_link = bn_link, None
+            # from a pool to the BatchNorm right behind it: that BatchNorm's backward runs inside the pool's
+            pool_link = {} if (pooled and bn_i is not None and not fold_next) else None
             if pending_bn is not None:
                 # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
                 z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)
                 pending_bn = None
             elif pooled and ops.conv3x3_prelu_maxpool_applicable(h, conv):
                 # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue: the conv output is never written
-                h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link)
+                h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link, pool_link)
                 fused_pool = True
             else:
                 z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled,
                                bn_link=in_link)
             if pooled:
                 if not fused_pool:
-                    h = ops.prelu_maxpool2x2(z, slope)
+                    h = ops.prelu_maxpool2x2(z, slope, pool_link)
                 if fold_next:
                     pending_bn = cnn[bn_i]
                 elif bn_i is not None:
                     bn_link = {}
-                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link)
+                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link, pool_link)
             else:
                 bn_link = {}
                 h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link)

@@ -330,9 +330,26 @@ def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1, pooled: bool = Fal
 
 
 # --------------------------------------------------------------------------------------
+def _pool_backward(u, slope, idx, du, zshape, out_link):
+    """(dz, dslope) of PReLU + MaxPool2d(2, 2) from the pooled output and the argmax codes; when the BatchNorm
+    behind the pool left its backward coefficients in `out_link`, du is that layer's incoming gradient and the
+    BatchNorm backward is applied on load (`afd_prelu_pool_backward_affine`)."""
+    lib = _lib()
+    n, c, h, w = zshape
+    du = _f32c(du)
+    dz = torch.empty((n, c, h, w), dtype=torch.float32, device=u.device)
+    dslope = torch.zeros(1, dtype=torch.float32, device=u.device) if slope is not None else None
+    coef = out_link.pop("affine_coef", None) if out_link is not None else None
+    _native.check(lib.afd_prelu_pool_backward_affine(
+        _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(coef), c,
+        _native.ptr(dz), _native.ptr(dslope), n * c, h, w, _native.stream_ptr()), "afd_prelu_pool_backward")
+    return dz, dslope
+
+
 class _PReLUPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, slope):
+    def forward(ctx, z, slope, out_link=None):
+        ctx.out_link = out_link
         lib = _lib()
         z = _f32c(z)
         n, c, h, w = z.shape
@@ -351,17 +368,9 @@ class _PReLUPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, du):
-        lib = _lib()
         u, idx, slope = ctx.saved_tensors
-        slope = slope if ctx.has_slope else None
-        n, c, h, w = ctx.zshape
-        du = _f32c(du)
-        dz = torch.empty((n, c, h, w), dtype=torch.float32, device=u.device)
-        dslope = torch.zeros(1, dtype=torch.float32, device=u.device) if ctx.has_slope else None
-        _native.check(lib.afd_prelu_pool_backward(
-            _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(dz),
-            _native.ptr(dslope), n * c, h, w, _native.stream_ptr()), "afd_prelu_pool_backward")
-        return dz, dslope
+        dz, dslope = _pool_backward(u, slope if ctx.has_slope else None, idx, du, ctx.zshape, ctx.out_link)
+        return dz, dslope, None
 
 
 class _Conv1PReLUPool(torch.autograd.Function):
@@ -416,9 +425,11 @@ def conv1_prelu_maxpool(x, w, b, slope, padding: int, link: Optional[dict] = Non
     return _Conv1PReLUPool.apply(x, w, b, slope, int(padding), link)
 
 
-def prelu_maxpool2x2(z, slope: Optional[torch.Tensor]):
-    """MaxPool2d(2,2)(PReLU(z)); slope=None -> plain max pool."""
-    return _PReLUPool.apply(z, slope)
+def prelu_maxpool2x2(z, slope: Optional[torch.Tensor], out_link: Optional[dict] = None):
+    """MaxPool2d(2,2)(PReLU(z)); slope=None -> plain max pool.  `out_link`: a dict shared with the BatchNorm that
+    is the ONLY consumer of the result (`batch_norm(.., prod_link=)`): its backward is then applied inside this
+    layer's backward."""
+    return _PReLUPool.apply(z, slope, out_link)
 
 
 class _Conv3x3PReLUPool(torch.autograd.Function):
@@ -427,8 +438,9 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
     written.  Backward: pool/PReLU backward from (u, code), then the convolution's backward."""
 
     @staticmethod
-    def forward(ctx, x, w, b, slope, bn_link=None):
+    def forward(ctx, x, w, b, slope, bn_link=None, out_link=None):
         ctx.bn_link = bn_link
+        ctx.out_link = out_link
         lib = _lib()
         x = _f32c(x)
         w = _f32c(w)
@@ -452,19 +464,13 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, du):
-        lib = _lib()
         x, w, u, idx, slope = ctx.saved_tensors
         n, cin, h, wd, cout = ctx.geom[:5]
-        du = _f32c(du)
-        dz = torch.empty((n, cout, h, wd), dtype=torch.float32, device=u.device)
-        dslope = torch.zeros(1, dtype=torch.float32, device=u.device)
-        _native.check(lib.afd_prelu_pool_backward(
-            _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(dz),
-            _native.ptr(dslope), n * cout, h, wd, _native.stream_ptr()), "afd_prelu_pool_backward")
+        dz, dslope = _pool_backward(u, slope, idx, du, (n, cout, h, wd), ctx.out_link)
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dz,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                       ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link)
-        return dx, dw, db, dslope, None
+        return dx, dw, db, dslope, None, None
 
 
 def conv3x3_prelu_maxpool_applicable(x, conv: torch.nn.Module) -> bool:
@@ -478,10 +484,10 @@ def conv3x3_prelu_maxpool_applicable(x, conv: torch.nn.Module) -> bool:
     return bool(_lib().afd_conv3x3_prelu_pool_applicable(cin, h, w, conv.out_channels))
 
 
-def conv3x3_prelu_maxpool(x, w, b, slope, bn_link: Optional[dict] = None):
+def conv3x3_prelu_maxpool(x, w, b, slope, bn_link: Optional[dict] = None, out_link: Optional[dict] = None):
     """MaxPool2d(2, 2)(PReLU(conv2d(x, w, b, padding=1))) without materialising the convolution output.
-    ``bn_link``: as for `conv2d`."""
-    return _Conv3x3PReLUPool.apply(x, w, b, slope, bn_link)
+    ``bn_link``: as for `conv2d`; ``out_link``: as for `prelu_maxpool2x2`."""
+    return _Conv3x3PReLUPool.apply(x, w, b, slope, bn_link, out_link)
 
 
 # --------------------------------------------------------------------------------------
@@ -524,8 +530,9 @@ def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, sync, link=None):
+                eps, sync, link=None, prod_link=None):
         ctx.link = link
+        ctx.prod_link = prod_link
         lib = _lib()
         x = _f32c(x)
         n, c = x.shape[0], x.shape[1]
@@ -603,7 +610,7 @@ class _BatchNorm(torch.autograd.Function):
                 neg = x <= 0
                 dslope = (g * x * neg).sum().reshape(1)
                 g = torch.where(neg, g * slope, g)
-            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None
+            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]
@@ -630,6 +637,14 @@ class _BatchNorm(torch.autograd.Function):
             _native.ptr(sums), c, -1.0 if on_dev else float(ctx.count),
             _native.ptr(ctx.count) if on_dev else None, _native.ptr(mdy), _native.ptr(mdyx),
             _native.stream_ptr()), "afd_bn_backward_means")
+        if ctx.prod_link is not None and not has_slope and not has_gamma:
+            # the producer of x (a PReLU + max-pool backward) applies dx = A dy + B x + K where it reads dy and x
+            coef = torch.empty((c, 4), dtype=torch.float32, device=x.device)
+            _native.check(lib.afd_bn_backward_coef(_native.ptr(mean), _native.ptr(invstd), _native.ptr(mdy),
+                                                   _native.ptr(mdyx), _native.ptr(coef), c, _native.stream_ptr()),
+                          "afd_bn_backward_coef")
+            ctx.prod_link["affine_coef"] = coef
+            return dy, None, None, None, None, None, None, None, None, None, None, None, None
         dx = torch.empty_like(x)
         dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
         _native.check(lib.afd_bn_backward_apply(
@@ -637,7 +652,7 @@ class _BatchNorm(torch.autograd.Function):
             _native.ptr(invstd), _native.ptr(gamma), _native.ptr(mdy), _native.ptr(mdyx),
             _native.ptr(dx), _native.ptr(dslope), n, c, hw, _native.stream_ptr()),
             "afd_bn_backward_apply")
-        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def _fold_forward(w2, b, mean, invstd):
@@ -933,14 +948,18 @@ def bn_conv1x1_prelu_bn(u, bn1, w, b, slope, bn2, sync: bool = True, link: Optio
 
 
 def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True,
-               link: Optional[dict] = None):
+               link: Optional[dict] = None, prod_link: Optional[dict] = None):
     """BatchNorm (batch statistics across all ranks when a process group is up) of
     PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats.  `link`: a dict shared with
     the convolution that is the ONLY consumer of the result (its `bn_link`): that layer's backward-data launch
-    then also produces this layer's backward sums."""
+    then also produces this layer's backward sums.  `prod_link`: a dict shared with the PReLU + max-pool call that
+    produced x (its `out_link`, this layer being the ONLY consumer of x): in training mode and without affine
+    parameters this layer's backward is then applied inside the pool's backward."""
     training = bn.training or bn.running_mean is None
+    if not training or bn.weight is not None or slope is not None:
+        prod_link = None
     return _BatchNorm.apply(x, slope, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link)
+                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link)
 
 
 # --------------------------------------------------------------------------------------

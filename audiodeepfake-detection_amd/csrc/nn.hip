@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(kT)
 prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slope,
                       const unsigned char* __restrict__ idx, const float* __restrict__ du,
                       float* __restrict__ dz, float* __restrict__ dslope, int H, int W, int Hp, int Wp,
-                      float invWp, int chunks, long items) {
+                      float invWp, int chunks, long items, const float* __restrict__ coef, int C) {
     constexpr int UN = 4;  // pooled pixels per thread per round: 12 loads in flight, then stores
     const float a = slope ? slope[0] : 1.f;
     const float inva = (slope && a != 0.f) ? 1.f / a : 0.f;
@@ -191,6 +191,13 @@ prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slo
     for (long item = blockIdx.x; item < items; item += gridDim.x) {
         const size_t plane = (size_t)(item / chunks);
         const int base = (int)(item - (long)plane * chunks) * kT * UN;
+        // AFFINE (coef): the gradient of the pooled tensor is A[c] du + B[c] u + K[c] -- the backward of a
+        // BatchNorm(affine=False) that follows the pool, applied where du and u are read anyway
+        float kA = 1.f, kB = 0.f, kK = 0.f;
+        if (coef) {
+            const int c = (int)(plane % (size_t)C);
+            kA = coef[4 * c]; kB = coef[4 * c + 1]; kK = coef[4 * c + 2];
+        }
         float* dzp = dz + plane * (size_t)H * W;
         const size_t pbase = plane * (size_t)Hp * Wp;
         int code[UN];
@@ -201,7 +208,7 @@ prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slo
             const bool ok = i < total;
             code[r] = ok ? idx[pbase + i] : 0;
             g[r] = ok ? du[pbase + i] : 0.f;
-            uu[r] = (ok && slope) ? u[pbase + i] : 0.f;
+            uu[r] = (ok && (slope || coef)) ? u[pbase + i] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < UN; ++r) {
@@ -209,7 +216,7 @@ prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slo
             if (i >= total) continue;
             int py, px;
             divmod_small(i, Wp, invWp, py, px);
-            float gg = g[r];
+            float gg = fmaf(kA, g[r], fmaf(kB, uu[r], kK));
             if (code[r] & 4) {
                 ds += gg * uu[r] * inva;
                 gg *= a;
@@ -705,7 +712,14 @@ extern "C" int afd_prelu_pool_forward(const float* z, const float* slope, float*
 extern "C" int afd_prelu_pool_backward(const float* u, const float* slope, const uint8_t* idx,
                                        const float* du, float* dz, float* dslope, int NC, int H,
                                        int W, afd_stream_t stream) {
+    return afd_prelu_pool_backward_affine(u, slope, idx, du, nullptr, 1, dz, dslope, NC, H, W, stream);
+}
+
+extern "C" int afd_prelu_pool_backward_affine(const float* u, const float* slope, const uint8_t* idx,
+                                              const float* du, const float* coef, int C, float* dz,
+                                              float* dslope, int NC, int H, int W, afd_stream_t stream) {
     if (!u || !idx || !du || !dz || (slope && !dslope)) return afd::fail(AFD_ERR_ARG, "pool bwd: null pointer");
+    if (coef && (C < 1 || NC % C != 0)) return afd::fail(AFD_ERR_ARG, "pool bwd: planes are not a multiple of the channels");
     const int Hp = H / 2, Wp = W / 2;
     if ((long)Hp * Wp >= (1L << 23)) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: plane too large");
     const unsigned gx = grid1d(((size_t)Hp * Wp + 3) / 4, 16);
@@ -716,9 +730,9 @@ extern "C" int afd_prelu_pool_backward(const float* u, const float* slope, const
         const unsigned blocks = (unsigned)(items < 8192 ? items : 8192);
         (void)gx;
         if (vec)
-            hipLaunchKernelGGL(prelu_pool_bwd_kernel<true>, dim3(blocks), dim3(kT), 0, AFD_STREAM, u, slope, idx, du, dz, dslope, H, W, Hp, Wp, 1.0f / Wp, chunks, items);
+            hipLaunchKernelGGL(prelu_pool_bwd_kernel<true>, dim3(blocks), dim3(kT), 0, AFD_STREAM, u, slope, idx, du, dz, dslope, H, W, Hp, Wp, 1.0f / Wp, chunks, items, coef, C);
         else
-            hipLaunchKernelGGL(prelu_pool_bwd_kernel<false>, dim3(blocks), dim3(kT), 0, AFD_STREAM, u, slope, idx, du, dz, dslope, H, W, Hp, Wp, 1.0f / Wp, chunks, items);
+            hipLaunchKernelGGL(prelu_pool_bwd_kernel<false>, dim3(blocks), dim3(kT), 0, AFD_STREAM, u, slope, idx, du, dz, dslope, H, W, Hp, Wp, 1.0f / Wp, chunks, items, coef, C);
     }
     return afd::check_launch("prelu_pool_bwd_kernel");
 }

@@ -269,6 +269,12 @@ int afd_prelu_pool_forward(const float* z, const float* slope, float* u, uint8_t
 int afd_prelu_pool_backward(const float* u, const float* slope, const uint8_t* idx,
                             const float* du, float* dz, float* dslope /* += */, int NC, int H,
                             int W, afd_stream_t stream);
+/* The same with the gradient of the pooled tensor given as A[c] du + B[c] u + K[c], coef [C][4] = (A, B, K, 0)
+ * as written by afd_bn_backward_coef: the backward of a BatchNorm(affine=False) that follows the pool is applied
+ * where du and u are read anyway (no batch-norm backward pass over the pooled tensor).  NC = N * C planes. */
+int afd_prelu_pool_backward_affine(const float* u, const float* slope, const uint8_t* idx, const float* du,
+                                   const float* coef /* may be NULL */, int C, float* dz,
+                                   float* dslope /* += */, int NC, int H, int W, afd_stream_t stream);
 
 /* (Sync)BatchNorm over x [N][C][HW] (models.py:260-289), optional PReLU fused on the input.
  * stats: sums[0..C) = sum, sums[C..2C) = sum of squares (double; the caller all-reduces them

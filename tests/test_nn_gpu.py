@@ -524,6 +524,36 @@ def test_backward_data_with_batchnorm_sums(shape, cout, act):
     _close(grads[1], grads[0].cpu(), 2e-6, "linked BatchNorm backward")
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 12, 1030), (3, 24, 7, 131)])
+def test_batchnorm_backward_inside_the_pool_backward(shape):
+    """PReLU + MaxPool2d(2, 2) -> BatchNorm(affine=False): with the two calls linked the BatchNorm's backward is
+    applied inside the pool's backward (`afd_prelu_pool_backward_affine`); gradients equal the unlinked chain and
+    the same layers in float64."""
+    torch.manual_seed(15)
+    n, c, h, w = shape
+    z0 = torch.randn(shape, device="cuda")
+    act = torch.nn.PReLU().cuda()
+    bn = torch.nn.BatchNorm2d(c, affine=False).cuda().train()
+    g = torch.randn(n, c, h // 2, w // 2, device="cuda")
+    res = []
+    for linked in (False, True):
+        z = z0.clone().requires_grad_(True)
+        act.weight.grad = None
+        link = {} if linked else None
+        y = ops.batch_norm(ops.prelu_maxpool2x2(z, act.weight, link), bn, None, False, None, link)
+        y.backward(g)
+        assert not linked or not link
+        res.append((y.detach(), z.grad, act.weight.grad.clone()))
+    ref = torch.nn.Sequential(torch.nn.PReLU(), torch.nn.MaxPool2d(2, 2), torch.nn.BatchNorm2d(c, affine=False)).double().cuda().train()
+    z64 = z0.double().requires_grad_(True)
+    yr = ref(z64)
+    yr.backward(g.double())
+    for y, dz, ds in res:
+        _close(y, yr.detach().cpu(), 1e-5, "output")
+        _close(dz, z64.grad.cpu(), 2e-5, "dz")
+        _close(ds, ref[0].weight.grad.cpu(), 1e-4, "dslope")
+
+
 WIDE3X3 = [(2, 32, 6, 1100, 64), (1, 96, 4, 1025, 128), (1, 64, 13, 1157, 96), (2, 64, 51, 129, 96)]
 
 
