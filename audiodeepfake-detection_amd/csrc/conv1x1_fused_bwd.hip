@@ -215,35 +215,23 @@ conv1x1_fused_bwd_kernel(const FB p) {
         if (cc0 == 0) continue;
 
         // ---- end of the tile ----
-        // t leaves: D column = lane & 31 -> pixels 2 l31 + i, row = (r & 3) + 8 (r >> 2) + 4 half -> ci
-        {
-            float* tb = p.t + (size_t)n * p.Cin * HW + px0;
-            if (FULLC && px0 + kPx <= p.HW) {
-                const unsigned lo = 4u * (unsigned)half * (unsigned)p.HW + 2u * (unsigned)l31;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned row = (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.HW;
-                        *reinterpret_cast<f32x2u*>(tb + (row + lo)) = f32x2{acc1[m][0][r], acc1[m][1][r]};
-                    }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ci = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        float* o = tb + (size_t)ci * HW + 2 * l31;
-                        if (ci < p.Cin && ok0) o[0] = acc1[m][0][r];
-                        if (ci < p.Cin && ok1) o[1] = acc1[m][1][r];
-                    }
-            }
+        // t leaves: D column = lane & 31 -> pixels 2 l31 + i, row = (r & 3) + 8 (r >> 2) + 4 half -> ci.  Whole
+        // tiles: the 32 row stores are dealt out over GEMM 2's eight rounds (four after each round's matrix
+        // instructions) -- a CU drains ~6 B per cycle to HBM, so a burst of 4 x 32 KB would hold its four waves for
+        // ~20k cycles with nothing else to issue (measured on the 1x1 forward: the store burst is 1.0 of its 2.3 ms)
+        float* tb = p.t + (size_t)n * p.Cin * HW + px0;
+        const bool whole = FULLC && px0 + kPx <= p.HW;
+        const unsigned lo = 4u * (unsigned)half * (unsigned)p.HW + 2u * (unsigned)l31;
+        if (!whole) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[m][i][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    float* o = tb + (size_t)ci * HW + 2 * l31;
+                    if (ci < p.Cin && ok0) o[0] = acc1[m][0][r];
+                    if (ci < p.Cin && ok1) o[1] = acc1[m][1][r];
+                }
         }
 
         // GEMM 2 from the wave's own image (LDS operations of a wave execute in order; the fences keep the
@@ -268,7 +256,22 @@ conv1x1_fused_bwd_kernel(const FB p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc2[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(am[m][r], bj[j][r], acc2[m][j], 0, 0, 0);
+            if (whole) {
+#pragma unroll
+                for (int u4 = 0; u4 < 4; ++u4) {
+                    const int e = 4 * q + u4, m = e >> 4, r = e & 15;
+                    const unsigned row = (unsigned)(m * 32 + (r & 3) + 8 * (r >> 2)) * (unsigned)p.HW;
+                    *reinterpret_cast<f32x2u*>(tb + (row + lo)) = f32x2{acc1[m][0][r], acc1[m][1][r]};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[m][i][r] = 0.f;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
