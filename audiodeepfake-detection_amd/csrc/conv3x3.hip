@@ -529,11 +529,13 @@ wgrad3x3_kernel(const GW g, const float* __restrict__ x, const float* __restrict
 // branch -- a join makes the compiler wait for the loads where they are issued: rows above / below
 // the image are read from the clamped row and zeroed when stored to LDS, and the first / last tile
 // columns (patches that cross the left / right edge) go to wgrad3x3_kernel as a second launch.
-template <int MT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MT <= 2 ? 4 : 2, MT <= 2 ? 4 : 2)))
+// CT = input channels per workgroup: 32, or 64 (two 32-channel chunks of the slab layout at once: dz is staged
+// once for both, twice the matrix instructions per barrier)
+template <int MT, int CT = 32>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((MT <= 2 && CT == 32) ? 4 : 2, (MT <= 2 && CT == 32) ? 4 : 2)))
 wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dz,
                  float* __restrict__ part, float* __restrict__ partb) {
-    constexpr int CT = 32, TW = 64, NTH = 512, NW = 8;
+    constexpr int TW = 64, NTH = 512, NW = 8;
     constexpr int CO_PAD = MT * 32;
     constexpr int kPR = 3;
     constexpr int kWPC = TW + 4;
@@ -711,16 +713,18 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
         __syncthreads();
     }
 
-    float* slab = part + ((size_t)(g.split0 + split) * g.nchunks + chunk) * CO_PAD * NCOL;
+    // slabs are per 32-channel chunk ([CO_PAD][288]): column tile nt of this workgroup is tile nt % 9 of chunk
+    // (CT / 32) * blockIdx.y + nt / 9
 #pragma unroll
     for (int q = 0; q < TPW; ++q) {
         const int p = wave + NW * q;
         if (p >= PAIRS) continue;
         const int m = p / NTILES, nt = p - m * NTILES;
+        float* slab = part + ((size_t)(g.split0 + split) * g.nchunks + (CT / 32) * chunk + nt / 9) * CO_PAD * 288;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            slab[(size_t)co * NCOL + nt * 32 + l31] = acc[q][r];
+            slab[(size_t)co * 288 + (nt % 9) * 32 + l31] = acc[q][r];
         }
     }
     __syncthreads();  // the last tile's bias cells are written
@@ -731,17 +735,18 @@ wgrad3x3p_kernel(const GW g, const float* __restrict__ x, const float* __restric
     }
 }
 
-template <int MT>
+template <int MT, int CT = 32>
 int launchw_p(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
-    constexpr size_t lds = (size_t)(2 * (MT * 32 * kWPitch + 32 * 3 * 68) + MT * 32 * 16) * 4;  // two tile images
+    constexpr size_t lds = (size_t)(2 * (MT * 32 * kWPitch + CT * 3 * 68) + MT * 32 * 16) * 4;  // two tile images
+    static_assert(lds <= 160 * 1024, "two tile images fit the LDS");
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3p_kernel<MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3p_kernel<MT, CT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad3x3: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((wgrad3x3p_kernel<MT>), dim3(g.S, g.nchunks), dim3(512), lds, s, g, x, dz, part, partb);
+    hipLaunchKernelGGL((wgrad3x3p_kernel<MT, CT>), dim3(g.S, g.nchunks * 32 / CT), dim3(512), lds, s, g, x, dz, part, partb);
     return afd::check_launch("wgrad3x3p_kernel");
 }
 
@@ -791,14 +796,17 @@ struct WgCols {
     int tilesX, ninner, nborder, border[4];
 };
 
-// mt = 32-channel tiles of Cout.  Measured at B = 32 (new vs general kernel): mt 4 1.70 vs 1.80 ms (the
+// mt = 32-channel tiles of Cout.  Measured at B = 32 (new vs general kernel, 32 input channels per workgroup): mt 4 1.70 vs 1.80 ms (the
 // general kernel spills 116 registers there), mt 3 3.73 vs 3.46, mt 2 0.34 vs 0.31, mt 1 0.87 vs 0.72 ms --
 // two workgroups of four waves cover each other's loads better than one of eight covers its own, so
 // only the 128-channel layer takes the split; AFD_WGRAD3X3P=1 forces it for every layer (A/B runs).
-WgCols wgrad_cols(int W, int wc, int mt) {
+WgCols wgrad_cols(int W, int wc, int mt, int cin) {
     WgCols c{};
     c.tilesX = (wc + 63) / 64;
-    if (W < 1024 || getenv("AFD_NO_WGRAD3X3P") || (mt != 4 && !getenv("AFD_WGRAD3X3P"))) return c;
+    // the 96-channel layer on 64 input channels per workgroup (54 pairs on 8 waves, dz staged once): 12.4 -> 11.1 ms
+    // at level 14; for one channel tile of Cout the same change measured level (2.9 ms)
+    const bool ct64 = mt == 3 && cin % 64 == 0 && !getenv("AFD_NO_WGRAD_CT64");
+    if (W < 1024 || getenv("AFD_NO_WGRAD3X3P") || (mt != 4 && !getenv("AFD_WGRAD3X3P") && !ct64)) return c;
     int last = 0;
     for (int tx = 1; tx < c.tilesX; ++tx)
         if (tx * 64 + 64 + 3 <= W) last = tx;
@@ -852,7 +860,7 @@ void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int 
     const int hc = dz_rows < H ? dz_rows : H, wc = dz_cols < W ? dz_cols : W;
     const int tw = wgrad_tw(W), th = kWPix / tw;
     const int tilesY = (hc + th - 1) / th;
-    WgCols c = wgrad_cols(W, wc, mt);
+    WgCols c = wgrad_cols(W, wc, mt, Cin);
     if (tw != 64) {
         c = WgCols{};
         c.tilesX = (wc + tw - 1) / tw;
@@ -873,7 +881,7 @@ int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, 
     g.tilesY = (g.Hc + th - 1) / th;
     int ct, co_pad, ncol, s_total;
     wgrad3x3_geometry(N, Cin, H, W, Cout, dz_rows, dz_cols, &s_total, &g.nchunks, &ct, &co_pad, &ncol);
-    WgCols c = wgrad_cols(W, g.Wc, co_pad / 32);
+    WgCols c = wgrad_cols(W, g.Wc, co_pad / 32, Cin);
     if (tw != 64) {
         c = WgCols{};
         c.tilesX = g.tilesX;
@@ -904,7 +912,8 @@ int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, 
     int rc;
     if (mt == 1) rc = launchw_p<1>(g, x, dz, part, partb, s);
     else if (mt == 2) rc = launchw_p<2>(g, x, dz, part, partb, s);
-    else if (mt == 3) rc = launchw_p<3>(g, x, dz, part, partb, s);
+    else if (mt == 3) rc = (!getenv("AFD_NO_WGRAD_CT64") && Cin % 64 == 0) ? launchw_p<3, 64>(g, x, dz, part, partb, s)
+                                                                            : launchw_p<3>(g, x, dz, part, partb, s);
     else rc = launchw_p<4>(g, x, dz, part, partb, s);
     if (rc) return rc;
     g.S = s2; g.ncols = c.nborder; g.col0 = 0; g.ncl = c.nborder; g.split0 = s1;
