@@ -16,7 +16,7 @@ files = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 secs = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 root = tempfile.mkdtemp(prefix="afd_loader_")
 rng = np.random.default_rng(0)
-for name, rate in (("A_real", 22050), ("B_fake", 44100)):
+for name, rate in (("A_real", 22050), ("B_fake", int(os.environ.get("AFD_LOADER_RATE2", "44100")))):
     os.makedirs(os.path.join(root, name))
     for i in range(files):
         pcm = (rng.standard_normal(rate * secs) * 3000).astype(np.int16)
@@ -24,7 +24,8 @@ for name, rate in (("A_real", 22050), ("B_fake", 44100)):
             f.setnchannels(1); f.setsampwidth(2); f.setframerate(rate); f.writeframes(pcm.tobytes())
 ds = get_costum_dataset(data_path=root, save_path=os.path.join(root, "index"), ds_type="train", seconds=1,
                         resample_rate=22050, limit=-1)
-print(f"{len(ds)} one-second frames in the train split ({files} files x {secs} s per folder, half of them at 44.1 kHz)")
+print(f"{len(ds)} one-second frames in the train split ({files} files x {secs} s per folder; second folder at "
+      f"{os.environ.get('AFD_LOADER_RATE2', '44100')} Hz)")
 for workers in (0, 2, 4, 8):
     dl = torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True, num_workers=workers, drop_last=True,
                                      persistent_workers=False)
