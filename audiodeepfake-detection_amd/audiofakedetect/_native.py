@@ -54,6 +54,8 @@ _SIGNATURES = {
     "afd_bn_fold_backward_weights": (c_i, [c_p] * 7 + [c_i, c_i, c_p]),
     "afd_bn_fold_backward_affine": (c_i, [c_p, ctypes.c_double, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "afd_bn_backward_coef": (c_i, [c_p] * 5 + [c_i, c_p]),
+    "afd_wav_read_windows": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_i]),
+    "afd_pcm16_resample": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "afd_conv1x1_bn_backward_data": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_l, c_p]),
     "afd_conv2d_backward_data": (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     "afd_conv2d_backward_weight": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),

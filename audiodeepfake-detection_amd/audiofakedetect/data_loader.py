@@ -248,6 +248,124 @@ class CustomDatasetDetailed(CustomDataset):
                 "path": str(path), "frame": int(frame), "offset": int(frame) * int(win)}
 
 
+class NativeFrameLoader:
+    """Batches of a `CustomDataset` index without per-item Python work.
+
+    The windows of a batch are read by the library's threaded WAV reader (`afd_wav_read_windows`) into one pinned
+    int16 buffer, copied to the GPU, and converted / resampled there (`afd_pcm16_resample`, the interpolator of
+    `sinc_resample`) -- the reference does this per item in DataLoader workers (data_loader.py:323-353).  Yields
+    the reference's item format batched: ``{"audio": f32[B, 1, n] on the device, "label": int64[B]}``.
+    Sharding over ranks, shuffling and ``set_epoch`` follow ``DistributedSampler(shuffle, seed, drop_last=True)``.
+    A batch whose windows differ in rate or length, or a file that is not 16-bit PCM, goes through the dataset's
+    own ``__getitem__`` (same values, slower).
+    """
+
+    def __init__(self, dataset: "CustomDataset", batch_size: int, device, shuffle: bool = True, seed: int = 0,
+                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8) -> None:
+        self.ds = dataset
+        self.dataset = dataset  # the attribute the trainer reads from a torch DataLoader
+        self.batch_size = int(batch_size)
+        self.device = torch.device(device)
+        self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
+        self.rank, self.world, self.threads = rank, world, threads
+        self.epoch = 0
+        self._banks: dict = {}
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = int(epoch)
+
+    def _indices(self) -> np.ndarray:
+        n = len(self.ds)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            perm = torch.randperm(n, generator=g).numpy()
+        else:
+            perm = np.arange(n)
+        total = n // self.world * self.world
+        return perm[self.rank:total:self.world]
+
+    def __len__(self) -> int:
+        n = len(self._indices())
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def _bank(self, orig: int, new: int):
+        key = (orig, new)
+        hit = self._banks.get(key)
+        if hit is None:
+            kernels, width = _sinc_resample_kernel(orig, new)
+            hit = (kernels.reshape(new, -1).contiguous().to(self.device), width)
+            self._banks[key] = hit
+        return hit
+
+    def _fallback(self, idxs) -> dict:
+        items = [self.ds[int(i)] for i in idxs]
+        return {self.ds.key: torch.stack([it[self.ds.key] for it in items]).to(self.device, non_blocking=True),
+                "label": torch.stack([it["label"] for it in items]).to(self.device)}
+
+    def _pinned(self, n: int, win: int) -> torch.Tensor:
+        key = ("pin", n, win)
+        buf = self._banks.get(key)
+        if buf is None:
+            buf = torch.empty((n, win), dtype=torch.int16).pin_memory()
+            self._banks[key] = buf
+        return buf
+
+    def __iter__(self):
+        import ctypes
+
+        from . import _native
+
+        lib = _native.load()
+        idx = self._indices()
+        rows = self.ds.audio_data
+        target = int(self.ds.resample_rate)
+        n_target = int(round(target * float(self.ds.seconds)))
+        stream = torch.cuda.current_stream(self.device)
+        for b in range(len(self)):
+            sel = idx[b * self.batch_size:(b + 1) * self.batch_size]
+            batch = rows[sel]
+            n = len(sel)
+            wins = np.asarray([int(w) for w in batch[:, 2]])
+            out = None
+            ok = True
+            # windows of one length (= one file rate) are read and resampled together
+            for win in np.unique(wins):
+                pos = np.nonzero(wins == win)[0]
+                m = len(pos)
+                win = int(win)
+                stream.synchronize()  # the pinned buffer of this shape may still feed the previous batch's copy
+                pcm = self._pinned(m, win)
+                rates = (ctypes.c_int * m)()
+                paths = (ctypes.c_char_p * m)(*[os.fsencode(str(p)) for p in batch[pos, 0]])
+                offs = (ctypes.c_longlong * m)(*[int(f) * win for f in batch[pos, 1]])
+                rc = lib.afd_wav_read_windows(paths, offs, m, win, ctypes.c_void_p(pcm.data_ptr()), rates, self.threads)
+                rate = int(rates[0]) if rc == 0 else 0
+                if rc != 0 or any(int(r) != rate for r in rates) or rate < target:
+                    ok = False  # the dataset's own path raises its own errors (e.g. rate < target)
+                    break
+                g = math.gcd(rate, target)
+                orig, new = rate // g, target // g
+                n_out = win if orig == new else -(-new * win // orig)
+                if out is None:
+                    out = torch.empty((n, 1, n_out), dtype=torch.float32, device=self.device)
+                if n_out != out.shape[-1]:
+                    ok = False
+                    break
+                dev_pcm = pcm.to(self.device, non_blocking=True)
+                bank, width = (None, 0) if orig == new else self._bank(orig, new)
+                part = out if m == n else torch.empty((m, 1, n_out), dtype=torch.float32, device=self.device)
+                _native.check(lib.afd_pcm16_resample(_native.ptr(dev_pcm), m, win, orig, new, width, _native.ptr(bank),
+                                                     _native.ptr(part), n_out, _native.stream_ptr()),
+                              "afd_pcm16_resample")
+                if m != n:
+                    out.index_copy_(0, torch.as_tensor(pos, device=self.device), part)
+            if not ok:
+                yield self._fallback(sel)
+                continue
+            labels = torch.tensor([int(v) for v in batch[:, 3]], dtype=torch.int64)
+            yield {self.ds.key: out, "label": labels.to(self.device, non_blocking=True)}
+
+
 def get_costum_dataset(data_path=None, save_path=None, ds_type="train", only_test_folders=None,
                        only_use=None, seconds=1, resample_rate=22050, limit=55504, abort_on_save=False,
                        asvspoof_name=None, train_ratio=0.7, val_ratio=0.1, file_type="wav",

@@ -30,7 +30,7 @@ from torch.utils.data import DataLoader
 from torch.utils.data.distributed import DistributedSampler
 
 from . import ops
-from .data_loader import get_costum_dataset
+from .data_loader import CustomDataset, NativeFrameLoader, get_costum_dataset
 from .models import get_model, strip_ddp_prefix
 from .utils import DotDict, add_default_parser_args, build_new_grid, get_input_dims, set_seed
 from .wavelet_math import fuse_normalization, get_transforms
@@ -93,9 +93,15 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
     return 1.0
 
 
-def _loader(args: DotDict, ds, train: bool) -> DataLoader:
+def _loader(args: DotDict, ds, train: bool):
     """Only the training split drops its ragged tail (sampler and loader); validation / test see every
     sample, the DistributedSampler padding a shard by wrapping around (reference :118-158)."""
+    if args.native_loader and isinstance(ds, CustomDataset):
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        return NativeFrameLoader(ds, args.batch_size, torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))),
+                                 shuffle=train, seed=args.seed or 0, drop_last=train, rank=rank, world=world,
+                                 threads=max(1, int(args.num_workers or 8)))
     sampler = None
     if args.ddp:
         sampler = DistributedSampler(ds, shuffle=train, seed=args.seed or 0, drop_last=train)
@@ -254,6 +260,8 @@ class Trainer:
         sampler = getattr(self.train_data_loader, "sampler", None)
         if isinstance(sampler, DistributedSampler):
             sampler.set_epoch(epoch)
+        elif hasattr(self.train_data_loader, "set_epoch"):
+            self.train_data_loader.set_epoch(epoch)
         for batch in self.train_data_loader:
             self.model.train()
             self._run_batch(epoch, batch)

@@ -93,6 +93,9 @@ def add_default_parser_args(parser: ArgumentParser) -> ArgumentParser:
     f("--synthetic", action="store_true")
     f("--synthetic-steps", type=int, default=8)
     f("--num-workers", type=int, default=None)  # loader workers; default: CPU share (the reference hard-codes 10)
+    # batches straight from the library's threaded WAV reader + GPU PCM conversion / resampling instead of
+    # DataLoader workers (16-bit PCM WAV datasets; same values)
+    f("--native-loader", action="store_true")
     return parser
 
 

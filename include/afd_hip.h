@@ -332,6 +332,21 @@ int afd_bn_backward_means(const double* sums, int C, double count, const double*
 int afd_dropout_permute(const float* x, float* y, int B, int C, int H, int W, float p,
                         uint64_t seed, int inverse, afd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Input side: the windowed read + resample of CustomDataset.__getitem__ (reference
+ * src/audiofakedetect/data_loader.py:323-353: torchaudio.load(path, frame_offset, num_frames) +
+ * torchaudio.functional.resample) for a whole batch.
+ * afd_wav_read_windows (HOST pointers; no stream): window i = frames [frame_offsets[i], + win) of the first
+ *   channel of the 16-bit PCM WAV file paths[i] -> out[i * win ..] (int16; frames past the end are 0), its sample
+ *   rate -> rates[i]; `threads` reader threads.  AFD_ERR_UNSUPPORTED for files that are not 16-bit PCM.
+ * afd_pcm16_resample (DEVICE pointers): out[b][i] = pcm[b][i] / 32768 when orig == nnew (bank NULL), else the
+ *   polyphase Hann-windowed sinc filter out[j * nnew + ph] = sum_t bank[ph][t] x[j * orig + t - width], zero padded,
+ *   bank [nnew][2 width + orig] (orig, nnew reduced by their gcd; n_out = ceil(nnew * n_in / orig)). */
+int afd_wav_read_windows(const char* const* paths, const long long* frame_offsets, int n, int win, int16_t* out,
+                         int* rates, int threads);
+int afd_pcm16_resample(const int16_t* pcm, int B, int n_in, int orig, int nnew, int width, const float* bank,
+                       float* out, int n_out, afd_stream_t stream);
+
 /* Flatten(2) + Linear(F, O) + mean(1) (models.py:295-298,311): x [B][TD][F] -> y [B][O] */
 int afd_linear_mean_forward(const float* x, const float* w, const float* bias, float* y, int B,
                             int TD, int F, int O, afd_stream_t stream);

@@ -126,3 +126,57 @@ def test_integrated_gradients_match_cpu_restatement(tmp_path):
     assert [f.split("_target-01_")[1] for f in files] == ["integrated_gradients.npy", "last_image.npy", "mean_images.npy"]
     ig = np.load(tmp_path / "plots" / files[0])
     assert ig.shape == (256, image.shape[-1]) and np.isfinite(ig).all()
+
+
+@pytest.mark.gpu
+def test_native_loader_matches_the_dataset(tmp_path):
+    """`NativeFrameLoader` (threaded WAV reader + `afd_pcm16_resample` on the GPU) against the dataset's own items
+    (standard-library reader + `sinc_resample`, i.e. torchaudio.functional.resample's interpolator, reference
+    data_loader.py:323-353): identical frames for files at the target rate, within 2e-6 for resampled ones
+    (44.1 -> 22.05 kHz and 48 -> 22.05 kHz: 28 and 348 taps per phase); sharding and epoch shuffling as
+    DistributedSampler."""
+    import struct
+
+    import numpy as np
+
+    from audiofakedetect.data_loader import NativeFrameLoader, get_costum_dataset
+
+    def write_wav(path, pcm, rate):
+        data = pcm.astype("<i2").tobytes()
+        fmt = struct.pack("<HHIIHH", 1, 1, rate, rate * 2, 2, 16)
+        body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(data)) + data
+        with open(path, "wb") as f:
+            f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+    rng = np.random.default_rng(5)
+    for rate, tol in ((22050, 0.0), (44100, 2e-6), (48000, 2e-6)):
+        root = tmp_path / f"r{rate}"
+        for name in ("A_real", "B_fake"):
+            (root / name).mkdir(parents=True)
+            for i in range(3):
+                t = np.arange(rate * 6) / rate
+                sig = 8000 * np.sin(2 * np.pi * (300 + 170 * i) * t) + 1500 * rng.standard_normal(t.size)
+                write_wav(root / name / f"{i}.wav", sig, rate)
+        ds = get_costum_dataset(data_path=str(root), save_path=str(root / "idx"), ds_type="train", seconds=1,
+                                resample_rate=22050, limit=-1)
+        loader = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4)
+        seen = 0
+        order = loader._indices()
+        for b, batch in enumerate(loader):
+            sel = order[b * 8:(b + 1) * 8]
+            assert batch["audio"].is_cuda and batch["audio"].shape[1:] == (1, 22050)
+            for k, i in enumerate(sel):
+                item = ds[int(i)]
+                assert int(batch["label"][k]) == int(item["label"])
+                err = (batch["audio"][k].cpu() - item["audio"]).abs().max().item()
+                assert err <= tol, (rate, err)
+                seen += 1
+        assert seen == len(ds)
+    # two ranks see disjoint halves; another epoch another order
+    a = NativeFrameLoader(ds, 4, "cuda:0", shuffle=True, seed=1, rank=0, world=2)._indices()
+    b = NativeFrameLoader(ds, 4, "cuda:0", shuffle=True, seed=1, rank=1, world=2)._indices()
+    assert not set(a) & set(b) and len(a) == len(b) == len(ds) // 2
+    l2 = NativeFrameLoader(ds, 4, "cuda:0", shuffle=True, seed=1)
+    first = l2._indices().copy()
+    l2.set_epoch(1)
+    assert not np.array_equal(first, l2._indices())

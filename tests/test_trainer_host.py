@@ -179,3 +179,54 @@ def test_sinc_resample_known_answers():
     mix = (low + 0.5 * torch.sin(2 * math.pi * 700.0 * t).float()[None])
     poly = resample_poly(mix.numpy().astype(np.float64), 1, 2, axis=-1)
     assert np.abs(sinc_resample(mix, 44100, 22050)[0, 200:-200].numpy() - poly[0, 200:-200]).max() < 5e-3
+
+
+def _write_wav(path, pcm, rate, channels=1, extra_chunk=False):
+    import struct
+
+    data = pcm.astype("<i2").tobytes()
+    fmt = struct.pack("<HHIIHH", 1, channels, rate, rate * channels * 2, channels * 2, 16)
+    body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    if extra_chunk:
+        body += b"LIST" + struct.pack("<I", 5) + b"abcde" + b"\x00"  # odd-sized chunk + pad byte
+    body += b"data" + struct.pack("<I", len(data)) + data
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_native_wav_window_reader(tmp_path):
+    """`afd_wav_read_windows` (the batch form of the reference's torchaudio.load(path, frame_offset, num_frames),
+    data_loader.py:323-327) against the standard-library reader: mono and stereo files, a chunk between "fmt " and
+    "data", windows that run past the end (zero-filled), several threads; a non-PCM file is refused."""
+    import ctypes
+
+    from audiofakedetect import _native
+    from audiofakedetect.data_loader import read_wav_window
+
+    lib = _native.load()
+    rng = np.random.default_rng(3)
+    specs = [("a.wav", 22050, 1, False, 50000), ("b.wav", 44100, 2, True, 70001), ("c.wav", 16000, 1, True, 3000)]
+    for name, rate, ch, extra, frames in specs:
+        _write_wav(tmp_path / name, rng.integers(-30000, 30000, size=frames * ch), rate, ch, extra)
+    win = 4096
+    items = [("a.wav", 0), ("a.wav", 45000), ("b.wav", 1234), ("b.wav", 69000), ("c.wav", 0), ("c.wav", 2999),
+             ("a.wav", 60000)]
+    n = len(items)
+    paths = (ctypes.c_char_p * n)(*[str(tmp_path / p).encode() for p, _ in items])
+    offs = (ctypes.c_longlong * n)(*[o for _, o in items])
+    out = np.full((n, win), 77, dtype=np.int16)
+    rates = (ctypes.c_int * n)()
+    for threads in (1, 4):
+        rc = lib.afd_wav_read_windows(paths, offs, n, win, out.ctypes.data_as(ctypes.c_void_p), rates, threads)
+        assert rc == 0, lib.afd_last_error()
+        for i, (p, o) in enumerate(items):
+            if p == "a.wav" and o == 60000:
+                assert not out[i].any()  # the window starts past the end: all zeros (wave.setpos would raise)
+                continue
+            ref, rate = read_wav_window(str(tmp_path / p), o, win)
+            assert rates[i] == rate
+            assert np.array_equal(out[i].astype(np.float32) / 32768.0, ref[0].numpy())
+    with open(tmp_path / "bad.wav", "wb") as f:
+        f.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
+    bad = (ctypes.c_char_p * 1)(str(tmp_path / "bad.wav").encode())
+    assert lib.afd_wav_read_windows(bad, offs, 1, win, out.ctypes.data_as(ctypes.c_void_p), rates, 1) != 0

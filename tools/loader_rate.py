@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "audiodeepfake-detection_amd"))
-from audiofakedetect.data_loader import get_costum_dataset  # noqa: E402
+from audiofakedetect.data_loader import NativeFrameLoader, get_costum_dataset  # noqa: E402
 
 files = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 secs = int(sys.argv[2]) if len(sys.argv) > 2 else 30
@@ -34,3 +34,15 @@ for workers in (0, 2, 4, 8):
         n += batch["audio"].shape[0]
     dt = time.perf_counter() - t0
     print(f"workers {workers}: {n / dt:9.0f} frames/s ({n} frames in {dt:.2f} s)")
+if torch.cuda.is_available():
+    for threads in (1, 4, 8, 16):
+        nl = NativeFrameLoader(ds, 128, "cuda:0", shuffle=True, seed=0, drop_last=True, threads=threads)
+        for _ in nl:  # warm-up: kernel bank, pinned allocations
+            break
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); n = 0
+        for batch in nl:
+            n += batch["audio"].shape[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(f"native loader, {threads:2d} reader threads: {n / dt:9.0f} frames/s ({n} frames in {dt:.2f} s)")
