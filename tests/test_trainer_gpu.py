@@ -180,3 +180,39 @@ def test_native_loader_matches_the_dataset(tmp_path):
     first = l2._indices().copy()
     l2.set_epoch(1)
     assert not np.array_equal(first, l2._indices())
+
+
+def test_trainer_epoch_on_the_native_loader(tmp_path):
+    """`create_data_loaders` with `native_loader` hands the trainer `NativeFrameLoader`s over a WAV dataset on disk
+    (reference folder convention); one epoch of training + validation + test runs on them."""
+    import struct
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from audiofakedetect.data_loader import NativeFrameLoader
+    from audiofakedetect.train_classifier import create_data_loaders
+
+    rng = np.random.default_rng(9)
+    root = tmp_path / "data"
+    for name in ("A_real", "B_fake"):
+        (root / name).mkdir(parents=True)
+        for i in range(2):
+            pcm = (3000 * rng.standard_normal(22050 * 40)).astype("<i2")
+            fmt = struct.pack("<HHIIHH", 1, 1, 22050, 44100, 2, 16)
+            body = b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt + b"data" + struct.pack("<I", pcm.nbytes) + pcm.tobytes()
+            with open(root / name / f"{i}.wav", "wb") as f:
+                f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    torch.manual_seed(0)
+    args, trainer, _ = bench.build("sym5-l8", 8, False, torch.device("cuda", 0))
+    args.update(data_path=str(root), save_path=str(tmp_path / "idx"), synthetic=False, native_loader=True,
+                file_type="wav", limit_train=None, num_workers=4, seed=0, validation_interval=1, ckpt_every=0)
+    train, val, test, _, _ = create_data_loaders(args)
+    assert all(isinstance(l, NativeFrameLoader) for l in (train, val, test))
+    assert len(train) == (2 * int(0.7 * 80)) // 8
+    trainer.train_data_loader, trainer.val_data_loader, trainer.test_data_loader = train, val, test
+    trainer.snapshot_path = str(tmp_path / "snap.pt")
+    trainer.train(1)
+    assert trainer.step_total == len(train) and all(np.isfinite(l[2]) for l in trainer.loss_list)
+    assert 0.0 <= trainer.test_results[0] <= 1.0
