@@ -281,7 +281,12 @@ class NativeFrameLoader:
             perm = torch.randperm(n, generator=g).numpy()
         else:
             perm = np.arange(n)
-        total = n // self.world * self.world
+        if self.drop_last:
+            total = n // self.world * self.world
+        else:  # DistributedSampler(drop_last=False): the shards are evened out by wrapping around
+            total = -(-n // self.world) * self.world
+            if total > n:
+                perm = np.concatenate([perm, perm[:total - n]])
         return perm[self.rank:total:self.world]
 
     def __len__(self) -> int:
