@@ -701,7 +701,7 @@ conv_wgrad_kernel(const WgradGeom wg, const float* __restrict__ x, const float* 
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ partb,
                     float* __restrict__ dw, float* __restrict__ db, int Cin, int Cout, int KK,
-                    int CI_T, int nchunks, int CO_PAD, int NCOL, int S) {
+                    int CI_T, int nchunks, int CO_PAD, int NCOL, int S, int swapped = 0, int SB = 0) {
     __shared__ float red[8][33];
     const int total = Cout * Cin * KK;
     const int e = threadIdx.x & 31;
@@ -719,9 +719,16 @@ wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ pa
             const int r = i % KK;
             const int ci = (i / KK) % Cin;
             const int co = i / (KK * Cin);
-            const int chunk = ci / CI_T;
-            const int col = (ci - chunk * CI_T) * KK + r;
-            p = part + ((size_t)chunk * CO_PAD + co) * NCOL + col;
+            if (!swapped) {
+                const int chunk = ci / CI_T;
+                const int col = (ci - chunk * CI_T) * KK + r;
+                p = part + ((size_t)chunk * CO_PAD + co) * NCOL + col;
+            } else {
+                // slabs of the role-swapped product D[ci][co][t'] = sum x[ci][q] dy[co][q + t']: dw[co][ci][t] = D[ci][co][8 - t]
+                const int chunk = co / CI_T;
+                const int col = (co - chunk * CI_T) * KK + (KK - 1 - r);
+                p = part + ((size_t)chunk * CO_PAD + ci) * NCOL + col;
+            }
             step = stride;
             valid = true;
             out_i = i;
@@ -730,9 +737,10 @@ wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ pa
         const int i = (blockIdx.x - nblk_w) * 32 + e;
         if (i < Cout) {
             p = partb + i;
-            step = CO_PAD;
+            step = swapped ? (size_t)Cout : (size_t)CO_PAD;
             valid = true;
             out_i = i;
+            if (swapped) S = SB;  // partial sums of bias_partial_kernel
         }
     }
     if (valid) {
@@ -756,6 +764,47 @@ wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ pa
         if ((int)blockIdx.x < nblk_w) dw[out_i] = t;
         else db[out_i] = t;
     }
+}
+
+// Bias gradient of the role-swapped backward-weight product (below): block (s, c) sums channel c of the images
+// s, s + SB, ... into partb[s][c]; wgrad_reduce_kernel's trailing blocks add the SB partial sums in a fixed order.
+__global__ void __launch_bounds__(256)
+bias_partial_kernel(const float* __restrict__ dy, float* __restrict__ partb, int N, int C, int HW) {
+    __shared__ float red[4];
+    const int c = blockIdx.y, SB = gridDim.x;
+    float a0 = 0.f, a1 = 0.f;
+    for (int n = blockIdx.x; n < N; n += SB) {
+        const float4* pl = reinterpret_cast<const float4*>(dy + ((size_t)n * C + c) * HW);
+        int i = threadIdx.x;
+        for (; i + 256 < HW / 4; i += 512) {
+            const float4 u = pl[i], v = pl[i + 256];
+            a0 += (u.x + u.y) + (u.z + u.w);
+            a1 += (v.x + v.y) + (v.z + v.w);
+        }
+        if (i < HW / 4) {
+            const float4 u = pl[i];
+            a0 += (u.x + u.y) + (u.z + u.w);
+        }
+    }
+    float v = a0 + a1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partb[(size_t)blockIdx.x * C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+constexpr int kBiasSplits = 32;
+
+// One 32-channel tile of Cout against 64..128 input channels: the product is computed with the roles swapped --
+// M = Cin (x rows as the staged operand), N = (Cout, tap) columns built from dy with its zero halo -- because a
+// single M tile reads one LDS operand pair per matrix instruction (measured 128 -> 32 channels at level 14:
+// 2.83 ms as is, 2.08 ms swapped; 64 -> 32: 1.42 / 1.11 ms).
+bool wgrad_swap_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil, int dy_rows, int dy_cols) {
+    if (getenv("AFD_NO_WGRAD_SWAP")) return false;
+    if (K != 3 || pad != 1 || dil != 1 || dy_rows < H || dy_cols < W) return false;
+    if (Cout != 32 || Cin % 32 != 0 || Cin < 64 || Cin > 128 || ((size_t)H * W) % 4 != 0) return false;
+    return afd::wgrad3x3_applicable(Cout, H, W, Cin, K, pad, dil);
 }
 
 int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int pad, int dil) {
@@ -1296,6 +1345,12 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(((size_t)S3 * nch3 * cop3 * ncol3 + (size_t)S3 * cop3) * 4);
         if (b > need) need = b;
     }
+    if (wgrad_swap_applicable(Cin, H, W, Cout, K, pad, dil, Hout, Wout)) {
+        int S3, nch3, ct3, cop3, ncol3;
+        afd::wgrad3x3_geometry(N, Cout, H, W, Cin, H, W, &S3, &nch3, &ct3, &cop3, &ncol3);
+        const size_t b = align_up(((size_t)S3 * nch3 * cop3 * ncol3 + (size_t)S3 * cop3 + (size_t)kBiasSplits * Cout) * 4);
+        if (b > need) need = b;
+    }
     if (afd::dilconv_applicable(Cin, Cout, K, dil)) {
         const size_t b = align_up(afd::dilconv_workspace_bytes(Cin, K));
         if (b > need) need = b;
@@ -1462,6 +1517,28 @@ extern "C" int afd_conv2d_backward_weight_cropped(const float* x, const float* d
         return afd::conv1x1_backward_weight(x, dy, dw, dbias, N, Cin, Cout, (long)H * W, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (wgrad_swap_applicable(Cin, H, W, Cout, K, pad, dil, dy_rows, dy_cols)) {
+        int S3, nch3, ct3, cop3, ncol3;
+        afd::wgrad3x3_geometry(N, Cout, H, W, Cin, H, W, &S3, &nch3, &ct3, &cop3, &ncol3);
+        const size_t slabs = (size_t)S3 * nch3 * cop3 * ncol3;
+        if (!ws || ws_bytes < (slabs + (size_t)S3 * cop3 + (size_t)kBiasSplits * Cout) * 4)
+            return afd::fail(AFD_ERR_WORKSPACE, "conv wgrad: workspace too small");
+        float* part3 = static_cast<float*>(ws);
+        float* partx = part3 + slabs;                  // the kernel's per-row sums (of x here): not used
+        float* partb3 = partx + (size_t)S3 * cop3;
+        rc = afd::wgrad3x3_launch(dy, x, part3, partx, N, Cout, H, W, Cin, H, W, s);
+        if (rc) return rc;
+        if (dbias) {
+            hipLaunchKernelGGL(bias_partial_kernel, dim3(kBiasSplits, Cout), dim3(256), 0, s, dy, partb3, N, Cout, H * W);
+            rc = afd::check_launch("bias_partial_kernel");
+            if (rc) return rc;
+        }
+        const int total3 = Cout * Cin * K * K;
+        const int nblk3 = (total3 + 31) / 32 + (dbias ? (Cout + 31) / 32 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk3), dim3(256), 0, s, part3, partb3, dw, dbias,
+                           Cin, Cout, K * K, ct3, nch3, cop3, ncol3, S3, 1, kBiasSplits);
+        return afd::check_launch("wgrad_reduce_kernel");
+    }
     if (afd::wgrad3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
         int S3, nch3, ct3, cop3, ncol3;
         afd::wgrad3x3_geometry(N, Cin, H, W, Cout, dy_rows, dy_cols, &S3, &nch3, &ct3, &cop3, &ncol3);

@@ -60,6 +60,11 @@ CONV_CASES = [
     (1, 96, 4, 1025, 128, 3, 1, 1),
     (1, 8, 3, 1024, 40, 3, 1, 1),
     (1, 64, 13, 1157, 96, 3, 1, 1),
+    # 32 output channels: backward-weight with the operand roles swapped (interior + edge launches; 96 channels;
+    # an image size the bias kernel's 16-byte loads do not take, i.e. the unswapped path)
+    (2, 128, 6, 2052, 32, 3, 1, 1),
+    (1, 96, 4, 1100, 32, 3, 1, 1),
+    (1, 64, 5, 1301, 32, 3, 1, 1),
     # the same kernels with 32-column tiles (narrow level-8 / STFT / LCNN images): ragged tile rows
     # and columns, 4- and 8-row tiles
     (2, 32, 12, 32, 64, 3, 1, 1),
