@@ -772,21 +772,24 @@ __global__ void __launch_bounds__(256)
 bias_partial_kernel(const float* __restrict__ dy, float* __restrict__ partb, int N, int C, int HW) {
     __shared__ float red[4];
     const int c = blockIdx.y, SB = gridDim.x;
-    float a0 = 0.f, a1 = 0.f;
+    const int nv = HW / 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int n = blockIdx.x; n < N; n += SB) {
         const float4* pl = reinterpret_cast<const float4*>(dy + ((size_t)n * C + c) * HW);
         int i = threadIdx.x;
-        for (; i + 256 < HW / 4; i += 512) {
-            const float4 u = pl[i], v = pl[i + 256];
-            a0 += (u.x + u.y) + (u.z + u.w);
-            a1 += (v.x + v.y) + (v.z + v.w);
+        for (; i + 768 < nv; i += 1024) {  // four 16-byte loads in flight per thread
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = pl[i + 256 * q];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += (v[q].x + v[q].y) + (v[q].z + v[q].w);
         }
-        if (i < HW / 4) {
+        for (; i < nv; i += 256) {
             const float4 u = pl[i];
-            a0 += (u.x + u.y) + (u.z + u.w);
+            a[0] += (u.x + u.y) + (u.z + u.w);
         }
     }
-    float v = a0 + a1;
+    float v = (a[0] + a[1]) + (a[2] + a[3]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -803,7 +806,10 @@ constexpr int kBiasSplits = 32;
 bool wgrad_swap_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil, int dy_rows, int dy_cols) {
     if (getenv("AFD_NO_WGRAD_SWAP")) return false;
     if (K != 3 || pad != 1 || dil != 1 || dy_rows < H || dy_cols < W) return false;
-    if (Cout != 32 || Cin % 32 != 0 || Cin < 64 || Cin > 128 || ((size_t)H * W) % 4 != 0) return false;
+    if (Cin % 32 != 0 || Cin > 128 || Cout % 32 != 0 || ((size_t)H * W) % 4 != 0) return false;
+    // measured: one channel tile of Cout, and 96 -> 128 channels, whose swapped form runs on the 64-channel workgroups
+    const bool pays = (Cout == 32 && Cin >= 64) || (Cin == 96 && Cout == 128 && !getenv("AFD_NO_WGRAD_SWAP4"));
+    if (!pays && !getenv("AFD_WGRAD_SWAP_ALL")) return false;
     return afd::wgrad3x3_applicable(Cout, H, W, Cin, K, pad, dil);
 }
 
