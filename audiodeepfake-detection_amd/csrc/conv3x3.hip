@@ -838,7 +838,9 @@ void wgrad_splits(int N, int tilesY, int nchunks, const WgCols& c, int* S1, int*
         return;
     }
     const long ti = (long)N * tilesY * c.ninner, tb = (long)N * tilesY * c.nborder;
-    long s = 1024 / nchunks;
+    // one to two workgroups per CU over the whole launch: 1024 / nchunks measured the same kernel time with twice
+    // the slabs for the reduction to read
+    long s = 512 / nchunks;
     if (s < 1) s = 1;
     if (s > ti) s = ti;
     *S1 = (int)coprime_splits(s, c.ninner);
