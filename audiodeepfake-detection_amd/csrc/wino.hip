@@ -540,6 +540,7 @@ extern "C" int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int 
     // the backward-data GEMM has the forward's Cout as its input channels; only the wide 32x32x2 Winograd kernel
     // with two or three channel tiles carries the statistics epilogue
     if (getenv("AFD_NO_BWD_BNSTATS")) return 0;
+    if (afd::wino44_applicable(Cout, H, W, Cin)) return 1;
     if (afd::wino16_applicable(Cout, H, W, Cin) || !afd::wino_applicable(Cout, H, W, Cin)) return 0;
     if (getenv("AFD_WINO_NT1")) return 0;
     const int mt = (Cin + 31) / 32;
@@ -548,7 +549,9 @@ extern "C" int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int 
 
 extern "C" size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, int W) {
     const size_t slots = 2 * ((size_t)(Cin + 31) / 32 * 32);
-    return (size_t)wino_stat_rows(N, H, W) * slots * sizeof(float) + (size_t)kStatBlocks * slots * sizeof(double) + 64;
+    long rows = wino_stat_rows(N, H, W);
+    if (afd::wino44_stat_rows(N, H, W) > rows) rows = afd::wino44_stat_rows(N, H, W);
+    return (size_t)rows * slots * sizeof(float) + (size_t)kStatBlocks * slots * sizeof(double) + 64;
 }
 
 extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w, float* dx, const float* xhat,
@@ -564,11 +567,13 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int co_pad = (Cin + 31) / 32 * 32;
     const int slots = 2 * co_pad;
-    const long rows = wino_stat_rows(N, H, W);
+    const bool f44 = afd::wino44_applicable(Cout, H, W, Cin);
+    const long rows = f44 ? afd::wino44_stat_rows(N, H, W) : wino_stat_rows(N, H, W);
     float* part = static_cast<float*>(stat_ws);
     double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
-    int rc = afd::wino_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, nullptr, nullptr, nullptr,
-                           xhat, part);
+    int rc = f44 ? afd::wino44_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, xhat, part)
+                 : afd::wino_run(dy, w, nullptr, dx, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, nullptr, nullptr,
+                                 nullptr, xhat, part);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);

@@ -1,0 +1,422 @@
+// Winograd F(4x4, 3x3) forward / backward-data on the f32 MFMA: 36 multiplies per 4x4 output tile and channel
+// pair instead of 64 for four F(2x2, 3x3) tiles (wino.hip, wino16.hip) or 144 direct; arithmetic fp32 end to end
+// (transform constants up to 8: measured 7e-6 of the largest output against float64 on a block-3 shaped layer,
+// F(2x2): 4e-7).
+//
+// Reference: the cuDNN launches behind nn.Conv2d(k=3, padding=1) of DCNN block 3
+// (src/audiofakedetect/models.py:263-278) and its backward-data pass.
+//
+//   wave      = 16 output channels x 16 tiles x 36 positions on 16x16x4 tiles: 144 accumulator registers; every
+//               (channel, tile) has its 36 positions in one lane, so A^T M A runs in registers (as in wino16.hip)
+//   workgroup = CG waves (Cout / 16) over the same 16 tiles of a tile row (4 output rows x 64 columns); 74 KB of
+//               LDS, two workgroups per CU
+//   chunk     = 16 input channels: thread (channel, tile) of the first 256 threads transforms its 6x6 patch
+//               (B^T d B, compile-time constants) into V[position][lane of the B fragment][k-step]: one
+//               ds_read_b128 per position brings a wave's B operands of all four k-steps
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+constexpr int kCh = 16;     // input channels per chunk = 4 k-steps of 4
+constexpr int kTiles = 16;  // tiles per workgroup
+constexpr int kPos = 36;
+constexpr int kVBuf = kPos * kCh * kTiles;  // floats per V buffer (36 KB)
+
+struct G4 {
+    int N, Cin, Cout, H, W;
+    int rows, cols;
+    int tilesX, tilesY, wgX, wxCount, nchunks;
+    // backward-data launches whose result is the gradient of a BatchNorm output (afd_conv3x3_backward_data_bnstats):
+    // the epilogue also sums, per channel, g and g * xhat over its outputs (xhat = bn_in, the forward convolution's
+    // input): one partial row [sum g | sum g xhat] per workgroup, rows of this launch from part_row0
+    const float* bn_in;
+    float* stat_part;
+    int part_row0;
+};
+
+// U = G g G^T, G (6x3)
+__device__ __forceinline__ float g_row(int i, float a, float b, float c) {
+    switch (i) {
+        case 0: return 0.25f * a;
+        case 1: return (-1.f / 6.f) * (a + b + c);
+        case 2: return (-1.f / 6.f) * (a - b + c);
+        case 3: return (1.f / 24.f) * a + (1.f / 12.f) * b + (1.f / 6.f) * c;
+        case 4: return (1.f / 24.f) * a - (1.f / 12.f) * b + (1.f / 6.f) * c;
+        default: return c;
+    }
+}
+
+// U table: [chunk][position][cg][lane][kstep (4)] = U_p[16 cg + (lane & 15)][16 chunk + 4 kstep + (lane >> 4)]
+__global__ void wino44_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
+                                      int CG, int nchunks, int dgrad) {
+    const int total = nchunks * kPos * CG * 4 * 64;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ks = i & 3;
+        const int lane = (i >> 2) & 63;
+        int r = i >> 8;
+        const int cg = r % CG;
+        r /= CG;
+        const int p = r % kPos;
+        const int chunk = r / kPos;
+        const int co = 16 * cg + (lane & 15);
+        const int ci = kCh * chunk + 4 * ks + (lane >> 4);
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            float g[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    g[ky][kx] = dgrad ? w[((size_t)ci * Cout + co) * 9 + (8 - (ky * 3 + kx))]
+                                      : w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
+            const int xi = p / 6, nu = p - 6 * xi;
+            float t[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) t[kx] = g_row(xi, g[0][kx], g[1][kx], g[2][kx]);
+            v = g_row(nu, t[0], t[1], t[2]);
+        }
+        U[i] = v;
+    }
+}
+
+// B^T d along one axis
+__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                    const float d5, float* t) {
+    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+    const float c = d4 - d2, e = d3 - d1;
+    t[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = fmaf(2.f, e, c);
+    t[4] = fmaf(-2.f, e, c);
+    t[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+}
+
+// A^T m along one axis
+__device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4,
+                                    const float m5, float* y) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y[0] = m0 + s1 + s2;
+    y[1] = fmaf(2.f, d2, d1);
+    y[2] = fmaf(4.f, s2, s1);
+    y[3] = fmaf(8.f, d2, d1) + m5;
+}
+
+template <int CG, bool BORDER, bool BST>
+__global__ void __launch_bounds__(CG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
+                   const float* __restrict__ bias, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float V[];  // [2][36][64 lanes][4 k-steps]
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int id = blockIdx.x;
+    const int wi = id % g.wxCount;
+    id /= g.wxCount;
+    const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
+    const int ty = id % g.tilesY;
+    const int n = id / g.tilesY;
+    const int tx0 = wx * kTiles;
+
+    // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
+    // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
+    const bool xf = tid < kCh * kTiles;
+    const int tl = lane & 15, ksx = lane >> 4;
+    const int ch = 4 * ksx + (wave & 3);
+    const int txp = tx0 + tl;
+    const int iy0 = 4 * ty - 1, ix0 = 4 * txp - 1;
+    const size_t plane = (size_t)g.H * g.W;
+    const float* xn = x + (size_t)n * g.Cin * plane;
+    const bool rows_in = iy0 >= 0 && iy0 + 5 < g.H;  // uniform
+    float d[6][6];
+    auto load_patch = [&](int c) {
+        const float* xc = xn + (size_t)(c * kCh + ch) * plane;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = iy0 + r;
+            const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+            const float* row = xc + (size_t)iyc * g.W;
+            if (!BORDER) {
+                const f4u v = *reinterpret_cast<const f4u*>(row + ix0);
+                const f2u u = *reinterpret_cast<const f2u*>(row + ix0 + 4);
+                d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w; d[r][4] = u.x; d[r][5] = u.y;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int ix = ix0 + j;
+                    d[r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+                }
+            }
+        }
+    };
+    auto store_v = [&](int buf) {
+        if (!rows_in || BORDER) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int iy = iy0 + r, ix = ix0 + j;
+                    const bool ok = iy >= 0 && iy < g.H && (!BORDER || (txp < g.tilesX && ix >= 0 && ix < g.W));
+                    d[r][j] = ok ? d[r][j] : 0.f;
+                }
+        }
+        float t[6][6];  // t = B^T d: column j of d -> column j of t
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float o[6];
+            bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t[r][j] = o[r];
+        }
+        float* vb = V + buf * kVBuf + ((wave & 3) * 16 + tl) * 4 + ksx;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            float o[6];
+            bt6(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vb[(r * 6 + j) * 256] = o[j];
+        }
+    };
+
+    f32x4 acc[kPos];
+#pragma unroll
+    for (int p = 0; p < kPos; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // U fragments of chunk c, position p (four k-steps): Uw[((c * 36 + p) * CG) * 256]
+    const float* Uw = U + (size_t)wave * 256 + lane * 4;
+    if (xf) {
+        load_patch(0);
+        store_v(0);
+    }
+    __syncthreads();
+    // positions in groups of 3: U fragments (L2) are requested two groups ahead of their MFMAs -- the first two groups
+    // of a chunk during the previous chunk's last groups, i.e. before the transform -- and V fragments (LDS) one ahead
+    f32x4 u[3][3], b[2][3];
+    auto load_u = [&](const float* uc, int grp, int slot) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) u[slot][q] = *reinterpret_cast<const f32x4*>(uc + (size_t)(3 * grp + q) * CG * 256);
+    };
+    load_u(Uw, 0, 0);
+    load_u(Uw, 1, 1);
+    for (int c = 0; c < g.nchunks; ++c) {
+        const bool more = c + 1 < g.nchunks;
+        if (xf && more) load_patch(c + 1);
+        const float* uc = Uw + (size_t)c * kPos * CG * 256;
+        const float* un = Uw + (size_t)(more ? c + 1 : c) * kPos * CG * 256;  // (the last chunk re-reads its own)
+        const float* vb = V + (c & 1) * kVBuf + lane * 4;
+        auto load_b = [&](int grp, int slot) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const f32x4*>(vb + (3 * grp + q) * 256);
+        };
+        load_b(0, 0);
+#pragma unroll
+        for (int grp = 0; grp < 12; ++grp) {
+            if (grp + 2 < 12) load_u(uc, grp + 2, (grp + 2) % 3);
+            else load_u(un, grp + 2 - 12, (grp + 2) % 3);
+            if (grp + 1 < 12) load_b(grp + 1, (grp + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int p = 3 * grp + q;
+                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[grp % 3][q][ks], b[grp & 1][q][ks], acc[p], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (xf && more) store_v((c + 1) & 1);
+        __syncthreads();
+    }
+
+    // output transform in registers: Y = A^T M A; D fragment: column (tile) = lane & 15, rows (channels) = 4 (lane >> 4) + j
+    const int kq = lane >> 4;
+    const int oy = 4 * ty;
+    const int txe = tx0 + tl;
+    const int ox = 4 * txe;
+    // BST: the BatchNorm outputs at channel j's output positions, requested one channel ahead from clamped (always
+    // valid) addresses; products are masked where they are used
+    f4u zn[BST ? 4 : 1];
+    auto load_xhat = [&](int j) {
+        const int co = min(16 * wave + 4 * kq + j, g.Cout - 1);
+        const int oxq = min(ox, g.W - 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oyr = min(oy + r, g.H - 1);
+            zn[r] = *reinterpret_cast<const f4u*>(g.bn_in + (((size_t)n * g.Cout + co) * g.H + oyr) * g.W + oxq);
+        }
+    };
+    float sg[BST ? 4 : 1], sgv[BST ? 4 : 1];
+    if constexpr (BST) load_xhat(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = 16 * wave + 4 * kq + j;
+        f4u zq[BST ? 4 : 1];
+        if constexpr (BST) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zq[r] = zn[r];
+            if (j + 1 < 4) load_xhat(j + 1);
+            sg[j] = sgv[j] = 0.f;
+        }
+        float s[4][6];  // A^T M: rows of outputs x 6 position columns
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float o[4];
+            at6(acc[q][j], acc[6 + q][j], acc[12 + q][j], acc[18 + q][j], acc[24 + q][j], acc[30 + q][j], o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r][q] = o[r];
+        }
+        const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        if (co < g.Cout && txe < g.tilesX) {
+            float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float o[4];
+                at6(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o);
+                if (oy + r < g.rows) {
+                    if constexpr (BST) {
+                        // (interior columns: ox + 3 < cols and the clamped column is ox itself; the edge workgroups'
+                        // clamped loads start at W - 4, so output column ox + q sits at element ox + q - (W - 4))
+                        float gq[4], zv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            gq[q] = (!BORDER || ox + q < g.cols) ? o[q] + bv : 0.f;
+                            if (!BORDER) {
+                                zv[q] = zq[r][q];
+                            } else {
+                                const int e = ox + q - min(ox, g.W - 4);
+                                zv[q] = e == 0 ? zq[r][0] : e == 1 ? zq[r][1] : e == 2 ? zq[r][2] : e == 3 ? zq[r][3] : 0.f;
+                            }
+                        }
+                        sg[j] += (gq[0] + gq[1]) + (gq[2] + gq[3]);
+                        sgv[j] += fmaf(gq[0], zv[0], gq[1] * zv[1]) + fmaf(gq[2], zv[2], gq[3] * zv[3]);
+                    }
+                    if (!BORDER || ox + 3 < g.cols) {
+                        f4u v = {o[0] + bv, o[1] + bv, o[2] + bv, o[3] + bv};
+                        *reinterpret_cast<f4u*>(yo + (size_t)r * g.W) = v;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (ox + q < g.cols) yo[(size_t)r * g.W + q] = o[q] + bv;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (BST) {
+        // a channel's outputs of this workgroup sit in the 16 lanes of one quarter wave
+        const int co_pad = (g.Cout + 31) / 32 * 32;
+        float* row = g.stat_part + ((size_t)g.part_row0 + blockIdx.x) * (2 * co_pad);
+        const bool live = txe < g.tilesX;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a1 = live ? sg[j] : 0.f, a2 = live ? sgv[j] : 0.f;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64);
+            }
+            const int co = 16 * wave + 4 * kq + j;
+            if (tl == 0 && co < g.Cout) {
+                row[co] = a1;
+                row[co_pad + co] = a2;
+            }
+        }
+    }
+}
+
+template <int CG, bool BST>
+int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * kVBuf * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    g.wgX = (g.tilesX + kTiles - 1) / kTiles;
+    const long rows = (long)g.N * g.tilesY;
+    // 36 GEMMs [16 CG x Cin] x [Cin x 16 tiles] per workgroup, every tile computed in full
+    afd::timing_annotate(2.0 * kPos * (16.0 * CG) * ((double)kTiles * g.wgX) * (double)rows * g.Cin, -1.0);
+    // interior workgroup columns: every patch column inside the image (6 columns from 4 tx - 1)
+    const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
+    const int edge = g.wgX >= 2 ? 2 : 1;
+    if (rows * (inner > edge ? inner : edge) > 0x7fffffffL)
+        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: grid too large");
+    g.part_row0 = 0;
+    if (inner > 0) {
+        g.wxCount = inner;
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST>), dim3((unsigned)(rows * inner)), dim3(CG * 64), lds, s, g,
+                           x, U, bias, y);
+        g.part_row0 = (int)(rows * inner);
+    }
+    g.wxCount = edge;
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST>), dim3((unsigned)(rows * edge)), dim3(CG * 64), lds, s, g, x, U,
+                       bias, y);
+    return afd::check_launch("wino44_conv_kernel");
+}
+
+}  // namespace
+
+namespace afd {
+
+bool wino44_applicable(int Cin, int H, int W, int Cout) {
+    if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44")) return false;
+    // four waves (64 output channels): block 3's backward-data at level 14, 7.7 -> 5.9 ms; six waves (96 channels)
+    // would leave two SIMDs with one wave.  Rows: ceil(H / 4) * 36 matrix products against ceil(H / 2) * 32
+    if (Cin % kCh != 0 || Cout != 64) return false;
+    if (W < 256 || H < 3) return false;
+    return (size_t)H * W < 0x7fffffffULL;
+}
+
+size_t wino44_workspace_bytes(int Cin, int Cout) {
+    const size_t cg = (size_t)(Cout + 15) / 16;
+    return (size_t)(Cin / kCh) * kPos * cg * 4 * 64 * sizeof(float);
+}
+
+// workgroups (= partial rows of the statistics epilogue) of a launch pair over N images of H x W outputs
+long wino44_stat_rows(int N, int H, int W) {
+    const int tilesX = (W + 3) / 4, tilesY = (H + 3) / 4;
+    return (long)N * tilesY * ((tilesX + kTiles - 1) / kTiles);
+}
+
+int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
+               int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
+               const float* bn_in, float* stat_part) {
+    if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
+        return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
+    G4 g{};
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.H = H; g.W = W;
+    g.rows = out_rows < H ? out_rows : H;
+    g.cols = out_cols < W ? out_cols : W;
+    g.tilesX = (g.cols + 3) / 4;
+    g.tilesY = (g.rows + 3) / 4;
+    g.nchunks = Cin / kCh;
+    g.bn_in = bn_in; g.stat_part = stat_part;
+    if (stat_part && (!bn_in || g.rows != H || g.cols != W))
+        return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: statistics epilogue on a cropped output");
+    const int CG = (Cout + 15) / 16;
+    float* U = static_cast<float*>(ws);
+    const int total = g.nchunks * kPos * CG * 4 * 64;
+    hipLaunchKernelGGL(wino44_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, CG,
+                       g.nchunks, dgrad);
+    int rc = afd::check_launch("wino44_weights_kernel");
+    if (rc) return rc;
+    afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
+    if (CG == 4) return stat_part ? launch44<4, true>(g, x, U, bias, y, s) : launch44<4, false>(g, x, U, bias, y, s);
+    return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: Cout %d", Cout);
+}
+
+}  // namespace afd
