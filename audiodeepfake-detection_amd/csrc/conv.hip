@@ -1440,6 +1440,9 @@ extern "C" int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, co
     if (N < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2) return afd::fail(AFD_ERR_ARG, "conv3x3+pool: bad shape");
     if (!afd_conv3x3_prelu_pool_applicable(Cin, H, W, Cout))
         return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3+pool: layer not on the Winograd kernel");
+    if (afd::wino44_pool_applicable(Cin, H, W, Cout))
+        return afd::wino44_run(x, w, bias, nullptr, N, Cin, H, W, Cout, 0, 2 * (H / 2), 2 * (W / 2), ws, ws_bytes,
+                               static_cast<hipStream_t>(stream), nullptr, nullptr, slope, u, idx);
     return afd::wino_run(x, w, bias, nullptr, N, Cin, H, W, Cout, 0, 2 * (H / 2), 2 * (W / 2), ws, ws_bytes,
                          static_cast<hipStream_t>(stream), slope, u, idx);
 }

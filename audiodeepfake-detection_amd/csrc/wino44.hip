@@ -39,6 +39,11 @@ struct G4 {
     const float* bn_in;
     float* stat_part;
     int part_row0;
+    // pooled epilogue (afd_conv3x3_prelu_pool_forward): PReLU + MaxPool2d(2, 2) of the tile's four windows;
+    // u / idx [N][Cout][rows / 2][cols / 2] are written instead of y
+    const float* slope;
+    float* u;
+    unsigned char* idx;
 };
 
 // U = G g G^T, G (6x3)
@@ -109,7 +114,7 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
     y[3] = fmaf(8.f, d2, d1) + m5;
 }
 
-template <int CG, bool BORDER, bool BST>
+template <int CG, bool BORDER, bool BST, bool POOL = false>
 __global__ void __launch_bounds__(CG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
@@ -274,6 +279,52 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             for (int r = 0; r < 4; ++r) s[r][q] = o[r];
         }
         const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        if constexpr (POOL) {
+            // same order and tie rule as prelu_pool_fwd_kernel (nn.hip): first maximum wins
+            if (co < g.Cout && txe < g.tilesX) {
+                const float a = g.slope[0];
+                auto act = [a](float z) { return z > 0.f ? z : a * z; };
+                const int PH = g.rows >> 1, PW = g.cols >> 1;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    float o0[4], o1[4];
+                    at6(s[2 * pr][0], s[2 * pr][1], s[2 * pr][2], s[2 * pr][3], s[2 * pr][4], s[2 * pr][5], o0);
+                    at6(s[2 * pr + 1][0], s[2 * pr + 1][1], s[2 * pr + 1][2], s[2 * pr + 1][3], s[2 * pr + 1][4],
+                        s[2 * pr + 1][5], o1);
+                    const int py = 2 * ty + pr;
+                    if (py < PH) {
+                        float ub[2];
+                        unsigned cb[2];
+#pragma unroll
+                        for (int pc = 0; pc < 2; ++pc) {
+                            const float y00 = o0[2 * pc] + bv, y01 = o0[2 * pc + 1] + bv;
+                            const float y10 = o1[2 * pc] + bv, y11 = o1[2 * pc + 1] + bv;
+                            float best = act(y00), zb = y00;
+                            unsigned bi = 0;
+                            float v = act(y01);
+                            if (v > best) { best = v; bi = 1; zb = y01; }
+                            v = act(y10);
+                            if (v > best) { best = v; bi = 2; zb = y10; }
+                            v = act(y11);
+                            if (v > best) { best = v; bi = 3; zb = y11; }
+                            ub[pc] = best;
+                            cb[pc] = bi | (zb <= 0.f ? 4u : 0u);
+                        }
+                        const int px = 2 * txe;
+                        const size_t o = (((size_t)n * g.Cout + co) * PH + py) * PW + px;
+                        if (px + 1 < PW) {
+                            f2u uv = {ub[0], ub[1]};
+                            *reinterpret_cast<f2u*>(g.u + o) = uv;
+                            g.idx[o] = (unsigned char)cb[0];
+                            g.idx[o + 1] = (unsigned char)cb[1];
+                        } else if (px < PW) {
+                            g.u[o] = ub[0];
+                            g.idx[o] = (unsigned char)cb[0];
+                        }
+                    }
+                }
+            }
+        } else
         if (co < g.Cout && txe < g.tilesX) {
             float* yo = y + (((size_t)n * g.Cout + co) * g.H + oy) * g.W + ox;
 #pragma unroll
@@ -332,15 +383,15 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     }
 }
 
-template <int CG, bool BST>
+template <int CG, bool BST, bool POOL = false>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * kVBuf * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr = true;
@@ -357,13 +408,13 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.part_row0 = 0;
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST>), dim3((unsigned)(rows * inner)), dim3(CG * 64), lds, s, g,
-                           x, U, bias, y);
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL>), dim3((unsigned)(rows * inner)), dim3(CG * 64), lds,
+                           s, g, x, U, bias, y);
         g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST>), dim3((unsigned)(rows * edge)), dim3(CG * 64), lds, s, g, x, U,
-                       bias, y);
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL>), dim3((unsigned)(rows * edge)), dim3(CG * 64), lds, s, g,
+                       x, U, bias, y);
     return afd::check_launch("wino44_conv_kernel");
 }
 
@@ -380,6 +431,15 @@ bool wino44_applicable(int Cin, int H, int W, int Cout) {
     return (size_t)H * W < 0x7fffffffULL;
 }
 
+// the pooled forward layer with 96 output channels (block 3): six waves, i.e. two SIMDs carry two waves -- still
+// ahead of the F(2x2) kernel there (6.8 -> ? ms at level 14)
+bool wino44_pool_applicable(int Cin, int H, int W, int Cout) {
+    if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44") || getenv("AFD_NO_WINO44_POOL")) return false;
+    if (Cin % kCh != 0 || Cout != 96) return false;
+    if (W < 256 || H < 4) return false;
+    return (size_t)H * W < 0x7fffffffULL;
+}
+
 size_t wino44_workspace_bytes(int Cin, int Cout) {
     const size_t cg = (size_t)(Cout + 15) / 16;
     return (size_t)(Cin / kCh) * kPos * cg * 4 * 64 * sizeof(float);
@@ -393,7 +453,7 @@ long wino44_stat_rows(int N, int H, int W) {
 
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
-               const float* bn_in, float* stat_part) {
+               const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx) {
     if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
     G4 g{};
@@ -404,6 +464,9 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.tilesY = (g.rows + 3) / 4;
     g.nchunks = Cin / kCh;
     g.bn_in = bn_in; g.stat_part = stat_part;
+    g.slope = slope; g.u = u; g.idx = idx;
+    if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx || stat_part))
+        return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv + pool: bad arguments");
     if (stat_part && (!bn_in || g.rows != H || g.cols != W))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: statistics epilogue on a cropped output");
     const int CG = (Cout + 15) / 16;
@@ -416,6 +479,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
     if (CG == 4) return stat_part ? launch44<4, true>(g, x, U, bias, y, s) : launch44<4, false>(g, x, U, bias, y, s);
+    if (CG == 6 && u) return launch44<6, false, true>(g, x, U, bias, y, s);
     return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: Cout %d", Cout);
 }
 
