@@ -18,7 +18,7 @@ Extra objects on the JSON line:
   roofline      the kernel class with the largest share of the step AS TIMED (backward-weight
                 kernels on their second stream), from HIP events on each launch's own stream.
                 MFMA-bound classes: achieved = flops really issued on the matrix cores (tile padding
-                included, Winograd = its 16 GEMMs) / summed launch time, frac = achieved / 157.3 TF/s;
+                included, Winograd = its 16 or 36 GEMMs) / summed launch time, frac = achieved / 157.3 TF/s;
                 the layer's direct-form flops are reported beside it as algorithmic_TFLOPs.
                 HBM-bound front ends: achieved = algorithmic bytes 4 (N + C P T) per frame / launch
                 time over >= 20 timed launches.  traffic = HBM bytes per step of that class from the
@@ -277,7 +277,7 @@ def roofline_of(cls: str, k: dict, steps_timed: int, pmc) -> dict:
              "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
              "algorithmic_TFLOPs": k["work"] / sec / 1e12,
              "note": "achieved = flops issued on the matrix cores (tile padding included; Winograd F(2x2,3x3) "
-                     "= 16 GEMMs per layer) / summed launch time; algorithmic_TFLOPs = the layers' "
+                     "= 16 GEMMs per 2x2 tile, F(4x4,3x3) = 36 per 4x4 tile) / summed launch time; algorithmic_TFLOPs = the layers' "
                      "direct-form flops over the same time"}
         algo_bytes = k["bytes"] / steps_timed
     r["traffic"] = class_traffic(pmc, cls)
