@@ -427,7 +427,8 @@ bool wino44_applicable(int Cin, int H, int W, int Cout) {
     // four waves (64 output channels): block 3's backward-data at level 14, 7.7 -> 5.9 ms; six waves (96 channels)
     // would leave two SIMDs with one wave.  Rows: ceil(H / 4) * 36 matrix products against ceil(H / 2) * 32
     // eight waves (128 output channels): block 4 forward 3.7 -> 2.8 ms, block 5 backward-data 1.6 -> 1.4 ms
-    // (measured on the level-14 coif4 geometry, 6 rows; shorter images stay on the F(2x2) kernels)
+    // (measured on the level-14 coif4 geometry, 6 rows; shorter images stay on the F(2x2) kernels; six waves on
+    // block 4's backward-data, 128 -> 96 channels, measured level: 3.3 ms either way, 3.8 against 3.6 with the sums)
     if (Cin % kCh != 0 || (Cout != 64 && Cout != 128)) return false;
     if (W < 256 || H < (Cout == 128 ? 5 : 3)) return false;
     return (size_t)H * W < 0x7fffffffULL;
