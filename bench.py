@@ -74,7 +74,7 @@ MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv_wgrad_1x1", "
 # rocprof kernel names of each timing class (profiles/r*_pmc_traffic.json is keyed by kernel)
 CLASS_KERNELS = {
     "conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
-    "conv_winograd": ("wino_conv_kernel", "wino16_conv_kernel"),
+    "conv_winograd": ("wino_conv_kernel", "wino16_conv_kernel", "wino44_conv_kernel"),
     "conv_wgrad": ("wgrad3x3_kernel", "wgrad3x3p_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
     "conv_wgrad_1x1": ("conv1x1_wgrad_kernel", "conv1x1_fused_bwd_kernel"),
     "wpt": ("wpt2_deep_mfma_kernel", "wpt2_deep_kernel", "wpt2_top_kernel", "wpt_fused_kernel",

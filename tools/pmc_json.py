@@ -12,7 +12,7 @@ bytes per step = total / steps_in_trace (bench.py's roofline.traffic).
 import collections, csv, glob, json, os, re, sys
 
 workload, batch, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-WIDE = ("wino_conv_kernel", "wino16_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "wgrad3x3p_kernel", "conv1x1_kernel",
+WIDE = ("wino_conv_kernel", "wino16_conv_kernel", "wino44_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "wgrad3x3p_kernel", "conv1x1_kernel",
         "wpt_haar14_kernel", "conv_wgrad2_kernel", "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel",
         "bn_bwd_apply_kernel", "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
 out = {"note": __doc__.strip(), "workload": workload, "batch": batch, "kernels": {}}
