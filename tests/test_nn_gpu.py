@@ -613,6 +613,62 @@ def test_winograd_class_is_what_runs():
     assert cw["bytes"] == 4.0 * (64 + 96) * 6 * 260
 
 
+def _issued_winograd(fn):
+    from audiofakedetect import _native
+
+    _native.timing_reset()
+    _native.timing_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+        cw = _native.timing_collect("conv_winograd")
+    finally:
+        _native.timing_enable(False)
+        _native.timing_reset()
+    return out, cw
+
+
+@pytest.mark.parametrize("case", [
+    # (n, cin, h, w, cout, direction): the layer shapes wino44.hip takes at level 14, with ragged right edges
+    (2, 96, 6, 1101, 128, "fwd"),     # block 4 forward: 8 waves
+    (1, 96, 13, 1030, 64, "dgrad"),   # block 3 backward-data: forward 64 -> 96, the GEMM's output is 64 channels
+    (2, 32, 6, 1027, 128, "dgrad"),   # block 5 backward-data: forward 128 -> 32
+    (1, 96, 3, 300, 64, "dgrad"),     # a single tile row with one row unused
+])
+def test_winograd_f44_layers(case):
+    """wino44.hip, Winograd F(4x4, 3x3): against float64 at the stated bar for that kernel -- 2e-5 of the largest
+    output (measured <= 1.2e-5; the F(2x2) kernels: 4e-7) -- and the issued-flop count says it is the kernel that ran:
+    36 GEMMs per 4x4 tile, 16 tiles per workgroup."""
+    n, cg_in, h, w, cg_out, direction = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    tiles = -(-h // 4) * (-(-(-(-w // 4)) // 16) * 16)
+    if direction == "fwd":
+        x = torch.randn(n, cg_in, h, w, generator=g)
+        wt = torch.randn(cg_out, cg_in, 3, 3, generator=g) / (cg_in * 9) ** 0.5
+        b = torch.randn(cg_out, generator=g)
+        ref = F.conv2d(x.double(), wt.double(), b.double(), padding=1)
+        got, cw = _issued_winograd(lambda: ops.conv2d(x.cuda(), wt.cuda(), b.cuda(), 1, 1))
+    else:
+        # backward-data of a forward layer cg_out -> cg_in channels: dy has cg_in channels, dx has cg_out
+        dy = torch.randn(n, cg_in, h, w, generator=g)
+        wt = torch.randn(cg_in, cg_out, 3, 3, generator=g) / (cg_out * 9) ** 0.5
+        ref = torch.nn.grad.conv2d_input((n, cg_out, h, w), wt.double(), dy.double(), padding=1)
+        lib = _native.load()
+        dx = torch.empty(n, cg_out, h, w, device="cuda")
+        ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cg_out, h, w, cg_in, 3, 1, 1), dtype=torch.uint8, device="cuda")
+        dyc, wc = dy.cuda(), wt.cuda()
+
+        def run():
+            _native.check(lib.afd_conv2d_backward_data(_native.ptr(dyc), _native.ptr(wc), _native.ptr(dx), n, cg_out, h, w,
+                                                       cg_in, 3, 1, 1, _native.ptr(ws), ws.numel(),
+                                                       _native.stream_ptr()), "dgrad")
+            return dx
+        got, cw = _issued_winograd(run)
+    _close(got, ref, 2e-5, f"F(4x4) {direction}")
+    assert cw["launches"] == 1
+    assert cw["issued"] == 2.0 * 36 * cg_out * cg_in * n * tiles
+
+
 @pytest.mark.parametrize("shape", [(1, 64, 7, 1027, 96), (2, 32, 6, 1100, 64), (2, 64, 13, 257, 96)])
 def test_conv_prelu_pool_in_one_launch(shape):
     """conv3x3_prelu_maxpool (the pool folded into the Winograd epilogue, reference models.py:263-265)
