@@ -61,6 +61,7 @@ _SIGNATURES = {
     "afd_conv2d_backward_weight": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     "afd_conv2d_forward_cropped": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
     "afd_conv2d_backward_weight_cropped": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
+    "afd_conv2d_backward_weight_sums": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
     "afd_conv1_pool_workspace_bytes": (c_sz, [c_i] * 5),
     "afd_conv1_pool_forward": (c_i, [c_p] * 6 + [c_i] * 5 + [c_p]),
     "afd_conv1_pool_backward": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p]),
@@ -82,6 +83,7 @@ _SIGNATURES = {
     "afd_bn_apply_forward": (c_i, [c_p] * 7 + [c_i, c_i, c_i, c_p]),
     "afd_bn_backward_stats": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_p]),
     "afd_bn_backward_apply": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_p]),
+    "afd_bn_backward_apply_sums": (c_i, [c_p] * 11 + [c_i, c_i, c_i, c_p]),
     "afd_bn_finalize": (c_i, [c_p, c_i, ctypes.c_double, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "afd_bn_backward_means": (c_i, [c_p, c_i, ctypes.c_double, c_p, c_p, c_p, c_p]),
     "afd_dropout_permute": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_ul, c_i, c_p]),

@@ -95,6 +95,7 @@ class DCNN(nn.Module):
                 pending_bn = link = None
                 continue
             link = None
+            sum_link = None
             in_link, bn_link = bn_link, None
             # from a pool to the BatchNorm right behind it: that BatchNorm's backward runs inside the pool's
             pool_link = {} if (pooled and bn_i is not None and not fold_next) else None
@@ -107,8 +108,11 @@ class DCNN(nn.Module):
                 h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link, pool_link)
                 fused_pool = True
             else:
+                # conv -> (PReLU) -> BatchNorm without a pool in between: the BatchNorm's backward hands the
+                # per-channel sums of its result (this layer's bias gradient) over
+                sum_link = {} if (not pooled and bn_i is not None and conv.bias is not None) else None
                 z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled,
-                               bn_link=in_link)
+                               bn_link=in_link, out_link=sum_link)
             if pooled:
                 if not fused_pool:
                     h = ops.prelu_maxpool2x2(z, slope, pool_link)
@@ -119,7 +123,7 @@ class DCNN(nn.Module):
                     h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link, pool_link)
             else:
                 bn_link = {}
-                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link)
+                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link, sum_link=sum_link)
         # Dropout + [batch, channels, time, packets] -> [batch, time, channels, packets]
         h = ops.dropout_permute(h, cnn[-1].p, self.training)
         dil = self.dil_conv

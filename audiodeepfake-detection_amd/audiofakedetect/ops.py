@@ -216,8 +216,9 @@ def transpose_contiguous(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, pad, dil, pooled, bn_link=None):
+    def forward(ctx, x, w, b, pad, dil, pooled, bn_link=None, out_link=None):
         ctx.bn_link = bn_link
+        ctx.out_link = out_link
         lib = _lib()
         x = _f32c(x)
         w = _f32c(w)
@@ -247,13 +248,15 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
+        # per-channel sums of dy left by its producer (a BatchNorm backward given the same dict as `sum_link`)
+        dy_sums = ctx.out_link.pop("dy_sums", None) if ctx.out_link is not None else None
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dy,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link)
-        return dx, dw, db, None, None, None, None
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link, dy_sums)
+        return dx, dw, db, None, None, None, None, None
 
 
-def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None):
+def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None, dy_sums=None):
     """Backward-data on the current stream; backward-weight on the second stream, added straight into
     the FusedAdam gradient arena, when the parameters live there (see `_Conv2d`).  `bn_link`: when x was the
     output of a training-mode BatchNorm (which set "bn" there), the backward-data launch also produces that
@@ -300,9 +303,9 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
                 dwt = torch.empty_like(w)
                 dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
                 ws2 = _ws(nbytes, x.device, "side")
-                _native.check(lib.afd_conv2d_backward_weight_cropped(
-                    _native.ptr(x), _native.ptr(dy), _native.ptr(dwt), _native.ptr(dbt), n, cin, h,
-                    wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws2), ws2.numel(),
+                _native.check(lib.afd_conv2d_backward_weight_sums(
+                    _native.ptr(x), _native.ptr(dy), _native.ptr(dwt), _native.ptr(dbt), _native.ptr(dy_sums), n,
+                    cin, h, wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws2), ws2.numel(),
                     _native.stream_ptr()), "afd_conv2d_backward_weight")
                 with torch.no_grad():
                     w.grad.add_(dwt)
@@ -310,23 +313,27 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
                         b.grad.add_(dbt)
             x.record_stream(st)
             dy.record_stream(st)
+            if dy_sums is not None:
+                dy_sums.record_stream(st)
             _queue_join(x.device)
         else:
             dw = torch.empty_like(w)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-            _native.check(lib.afd_conv2d_backward_weight_cropped(
-                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
-                cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
+            _native.check(lib.afd_conv2d_backward_weight_sums(
+                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), _native.ptr(dy_sums), n, cin, h,
+                wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
                 _native.stream_ptr()), "afd_conv2d_backward_weight")
     return dx, dw, db
 
 
 def conv2d(x, w, b=None, padding: int = 0, dilation: int = 1, pooled: bool = False,
-           bn_link: Optional[dict] = None):
+           bn_link: Optional[dict] = None, out_link: Optional[dict] = None):
     """``pooled=True``: the result only feeds ``prelu_maxpool2x2`` (whose backward zeroes the
     gradient of an odd last row / column), so those need not be computed.  ``bn_link``: the dict given to the
-    BatchNorm call that produced x (its ONLY consumer being this convolution), see `_conv2d_backward`."""
-    return _Conv2d.apply(x, w, b, int(padding), int(dilation), bool(pooled), bn_link)
+    BatchNorm call that produced x (its ONLY consumer being this convolution), see `_conv2d_backward`.
+    ``out_link``: the dict given as `sum_link` to the BatchNorm call that is the ONLY consumer of the result: its
+    backward leaves the per-channel sums of the output gradient there (the bias gradient)."""
+    return _Conv2d.apply(x, w, b, int(padding), int(dilation), bool(pooled), bn_link, out_link)
 
 
 # --------------------------------------------------------------------------------------
@@ -530,9 +537,10 @@ def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, sync, link=None, prod_link=None):
+                eps, sync, link=None, prod_link=None, sum_link=None):
         ctx.link = link
         ctx.prod_link = prod_link
+        ctx.sum_link = sum_link
         lib = _lib()
         x = _f32c(x)
         n, c = x.shape[0], x.shape[1]
@@ -610,7 +618,7 @@ class _BatchNorm(torch.autograd.Function):
                 neg = x <= 0
                 dslope = (g * x * neg).sum().reshape(1)
                 g = torch.where(neg, g * slope, g)
-            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]
@@ -644,15 +652,19 @@ class _BatchNorm(torch.autograd.Function):
                                                    _native.ptr(mdyx), _native.ptr(coef), c, _native.stream_ptr()),
                           "afd_bn_backward_coef")
             ctx.prod_link["affine_coef"] = coef
-            return dy, None, None, None, None, None, None, None, None, None, None, None, None
+            return dy, None, None, None, None, None, None, None, None, None, None, None, None, None
         dx = torch.empty_like(x)
         dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
-        _native.check(lib.afd_bn_backward_apply(
+        # the per-channel sums of dx for the convolution that produced x (its bias gradient), from the same pass
+        dxs = torch.zeros(c, dtype=torch.float64, device=x.device) if ctx.sum_link is not None else None
+        _native.check(lib.afd_bn_backward_apply_sums(
             _native.ptr(x), _native.ptr(slope), _native.ptr(dy), _native.ptr(mean),
             _native.ptr(invstd), _native.ptr(gamma), _native.ptr(mdy), _native.ptr(mdyx),
-            _native.ptr(dx), _native.ptr(dslope), n, c, hw, _native.stream_ptr()),
+            _native.ptr(dx), _native.ptr(dslope), _native.ptr(dxs), n, c, hw, _native.stream_ptr()),
             "afd_bn_backward_apply")
-        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+        if dxs is not None:
+            ctx.sum_link["dy_sums"] = dxs
+        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
 
 
 def _fold_forward(w2, b, mean, invstd):
@@ -948,18 +960,22 @@ def bn_conv1x1_prelu_bn(u, bn1, w, b, slope, bn2, sync: bool = True, link: Optio
 
 
 def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True,
-               link: Optional[dict] = None, prod_link: Optional[dict] = None):
+               link: Optional[dict] = None, prod_link: Optional[dict] = None, sum_link: Optional[dict] = None):
     """BatchNorm (batch statistics across all ranks when a process group is up) of
     PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats.  `link`: a dict shared with
     the convolution that is the ONLY consumer of the result (its `bn_link`): that layer's backward-data launch
     then also produces this layer's backward sums.  `prod_link`: a dict shared with the PReLU + max-pool call that
     produced x (its `out_link`, this layer being the ONLY consumer of x): in training mode and without affine
-    parameters this layer's backward is then applied inside the pool's backward."""
+    parameters this layer's backward is then applied inside the pool's backward.  `sum_link`: a dict shared with the
+    convolution that produced x (its `out_link`, this layer being the ONLY consumer of x): the backward pass leaves
+    the per-channel sums of its result there -- that convolution's bias gradient."""
     training = bn.training or bn.running_mean is None
     if not training or bn.weight is not None or slope is not None:
         prod_link = None
+    if not training:
+        sum_link = None
     return _BatchNorm.apply(x, slope, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link)
+                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link, sum_link)
 
 
 # --------------------------------------------------------------------------------------

@@ -799,6 +799,12 @@ bias_partial_kernel(const float* __restrict__ dy, float* __restrict__ partb, int
 
 constexpr int kBiasSplits = 32;
 
+// the bias gradient handed over by the producer of dy (afd_bn_backward_apply_sums): double sums -> db
+__global__ void bias_from_sums_kernel(const double* __restrict__ sums, float* __restrict__ db, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) db[i] = (float)sums[i];
+}
+
 // One 32-channel tile of Cout against 64..128 input channels: the product is computed with the roles swapped --
 // M = Cin (x rows as the staged operand), N = (Cout, tap) columns built from dy with its zero halo -- because a
 // single M tile reads one LDS operand pair per matrix instruction (measured 128 -> 32 channels at level 14:
@@ -1516,6 +1522,14 @@ extern "C" int afd_conv2d_backward_weight_cropped(const float* x, const float* d
                                                   int Cout, int K, int pad, int dil, int dy_rows,
                                                   int dy_cols, void* ws, size_t ws_bytes,
                                                   afd_stream_t stream) {
+    return afd_conv2d_backward_weight_sums(x, dy, dw, dbias, nullptr, N, Cin, H, W, Cout, K, pad, dil, dy_rows, dy_cols,
+                                           ws, ws_bytes, stream);
+}
+
+extern "C" int afd_conv2d_backward_weight_sums(const float* x, const float* dy, float* dw, float* dbias,
+                                               const double* dy_sums, int N, int Cin, int H, int W, int Cout,
+                                               int K, int pad, int dil, int dy_rows, int dy_cols, void* ws,
+                                               size_t ws_bytes, afd_stream_t stream) {
     int rc = check_conv_args(x, dy, dw, N, Cin, H, W, Cout, K, pad, dil);
     if (rc) return rc;
     if (dy_rows < 1 || dy_cols < 1) return afd::fail(AFD_ERR_ARG, "conv wgrad: empty crop");
@@ -1537,14 +1551,19 @@ extern "C" int afd_conv2d_backward_weight_cropped(const float* x, const float* d
         float* partb3 = partx + (size_t)S3 * cop3;
         rc = afd::wgrad3x3_launch(dy, x, part3, partx, N, Cout, H, W, Cin, H, W, s);
         if (rc) return rc;
-        if (dbias) {
+        // the bias gradient: per-channel sums of dy from its producer when the caller has them, else a pass over dy
+        float* db_red = dbias;
+        if (dbias && dy_sums) {
+            hipLaunchKernelGGL(bias_from_sums_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, dy_sums, dbias, Cout);
+            db_red = nullptr;
+        } else if (dbias) {
             hipLaunchKernelGGL(bias_partial_kernel, dim3(kBiasSplits, Cout), dim3(256), 0, s, dy, partb3, N, Cout, H * W);
             rc = afd::check_launch("bias_partial_kernel");
             if (rc) return rc;
         }
         const int total3 = Cout * Cin * K * K;
-        const int nblk3 = (total3 + 31) / 32 + (dbias ? (Cout + 31) / 32 : 0);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk3), dim3(256), 0, s, part3, partb3, dw, dbias,
+        const int nblk3 = (total3 + 31) / 32 + (db_red ? (Cout + 31) / 32 : 0);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk3), dim3(256), 0, s, part3, partb3, dw, db_red,
                            Cin, Cout, K * K, ct3, nch3, cop3, ncol3, S3, 1, kBiasSplits);
         return afd::check_launch("wgrad_reduce_kernel");
     }

@@ -376,7 +376,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ mdy, const float* __restrict__ mdyx,
                                     float* __restrict__ dx, float* __restrict__ dslope, int C,
-                                    int HW) {
+                                    int HW, double* __restrict__ dxsum) {
     const size_t plane = blockIdx.y;
     const int c = (int)(plane % C);
     const bool act = slope != nullptr;
@@ -397,6 +397,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
             ds += g * zz;
             g *= a;
         }
+        u0 += g;  // per-channel sum of the result: the bias gradient of the convolution that produced x
         return g;
     };
     plane_loop(base, HW, blockIdx.x, gridDim.x, [&](int i) { op[i] = one(xp[i], gp[i]); },
@@ -406,9 +407,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                    *reinterpret_cast<float4*>(op + i) =
                        make_float4(one(v.x, g.x), one(v.y, g.y), one(v.z, g.z), one(v.w, g.w));
                });
-    if (act) {
+    if (act || dxsum) {
         block_sum3(ds, u0, u1);
-        if (threadIdx.x == 0 && ds != 0.f) atomicAdd(dslope, ds);
+        if (threadIdx.x == 0 && act && ds != 0.f) atomicAdd(dslope, ds);
+        if (threadIdx.x == 0 && dxsum) atomicAdd(dxsum + c, (double)u0);
     }
 }
 
@@ -939,6 +941,15 @@ extern "C" int afd_bn_backward_apply(const float* x, const float* slope, const f
                                      const float* mean, const float* invstd, const float* gamma,
                                      const float* mean_dy, const float* mean_dy_xhat, float* dx,
                                      float* dslope, int N, int C, int HW, afd_stream_t stream) {
+    return afd_bn_backward_apply_sums(x, slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, nullptr, N,
+                                      C, HW, stream);
+}
+
+extern "C" int afd_bn_backward_apply_sums(const float* x, const float* slope, const float* dy,
+                                          const float* mean, const float* invstd, const float* gamma,
+                                          const float* mean_dy, const float* mean_dy_xhat, float* dx,
+                                          float* dslope, double* dx_sums, int N, int C, int HW,
+                                          afd_stream_t stream) {
     if (!x || !dy || !mean || !invstd || !mean_dy || !mean_dy_xhat || !dx || (slope && !dslope))
         return afd::fail(AFD_ERR_ARG, "bn bwd apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn bwd apply: N*C > 65535");
@@ -948,7 +959,7 @@ extern "C" int afd_bn_backward_apply(const float* x, const float* slope, const f
     if (bx < 1) bx = 1;
     if (bx > 16) bx = 16;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx, N * C), dim3(kT), 0, AFD_STREAM, x,
-                       slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, C, HW);
+                       slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, C, HW, dx_sums);
     return afd::check_launch("bn_bwd_apply_kernel");
 }
 

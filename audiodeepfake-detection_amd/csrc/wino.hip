@@ -401,29 +401,41 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
     }
 }
 
-// partial rows [rows][2 co_pad] -> part2 [gridDim.x][2 co_pad] doubles (thread = slot, rows strided over the blocks)
+// partial rows [rows][2 co_pad] -> part2 [gridDim.x][2 co_pad] doubles (thread = slot, rows strided over the blocks;
+// four independent chains per thread)
 __global__ void __launch_bounds__(256)
 wino_bnstats_reduce1_kernel(const float* __restrict__ part, int rows, int slots, double* __restrict__ part2) {
     const int e = threadIdx.x;
     if (e >= slots) return;
-    double s = 0.0;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) s += (double)part[(size_t)r * slots + e];
-    part2[(size_t)blockIdx.x * slots + e] = s;
+    const int G = gridDim.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = blockIdx.x;
+    for (; r + 3 * G < rows; r += 4 * G) {
+        s0 += (double)part[(size_t)r * slots + e];
+        s1 += (double)part[(size_t)(r + G) * slots + e];
+        s2 += (double)part[(size_t)(r + 2 * G) * slots + e];
+        s3 += (double)part[(size_t)(r + 3 * G) * slots + e];
+    }
+    for (; r < rows; r += G) s0 += (double)part[(size_t)r * slots + e];
+    part2[(size_t)blockIdx.x * slots + e] = (s0 + s1) + (s2 + s3);
 }
 
-// sums[c] = sum g, sums[C + c] = sum g xhat: what afd_bn_backward_means takes
+// sums[c] = sum g, sums[C + c] = sum g xhat: what afd_bn_backward_means takes.  Block = 8 slots x 32 row lanes
+// (a single block walking the rows2 rows one after the other took 68 us of load latency)
 __global__ void __launch_bounds__(256)
 wino_bnstats_reduce2_kernel(const double* __restrict__ part2, int rows2, int co_pad, int C,
                             double* __restrict__ sums) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < rows2; ++r) {
-        s1 += part2[(size_t)r * 2 * co_pad + c];
-        s2 += part2[(size_t)r * 2 * co_pad + co_pad + c];
+    const int lane = threadIdx.x & 31;
+    const int slot = blockIdx.x * 8 + (threadIdx.x >> 5);  // 0 .. 2 co_pad - 1
+    double s = 0.0;
+    if (slot < 2 * co_pad)
+        for (int r = lane; r < rows2; r += 32) s += part2[(size_t)r * 2 * co_pad + slot];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0 && slot < 2 * co_pad) {
+        const int c = slot < co_pad ? slot : slot - co_pad;
+        if (c < C) sums[(slot < co_pad ? 0 : C) + c] = s;
     }
-    sums[c] = s1;
-    sums[C + c] = s2;
 }
 
 constexpr int kStatBlocks = 256;
@@ -577,6 +589,7 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
-    hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3(1), dim3(256), 0, s, part2, blocks, co_pad, Cin, sums);
+    hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cin,
+                       sums);
     return afd::check_launch("wino_bnstats_reduce kernels");
 }

@@ -198,6 +198,13 @@ int afd_conv2d_backward_weight_cropped(const float* x, const float* dy, float* d
                                        int N, int Cin, int H, int W, int Cout, int K, int pad,
                                        int dil, int dy_rows, int dy_cols, void* ws,
                                        size_t ws_bytes, afd_stream_t stream);
+/* The same with the per-channel sums of dy (double[Cout], e.g. from afd_bn_backward_apply_sums) when the caller
+ * has them: the bias gradient is then taken from there where the kernel would otherwise make a pass over dy for
+ * it (dy_sums may be NULL: identical to the call above).  Reference: the bias gradient of nn.Conv2d's backward. */
+int afd_conv2d_backward_weight_sums(const float* x, const float* dy, float* dw, float* dbias,
+                                    const double* dy_sums, int N, int Cin, int H, int W, int Cout, int K,
+                                    int pad, int dil, int dy_rows, int dy_cols, void* ws, size_t ws_bytes,
+                                    afd_stream_t stream);
 
 /* First block for single-channel inputs, fused: Conv2d(1 -> Cout, 3x3, pad) + PReLU +
  * MaxPool2d(2,2) (reference models.py:255-259 with args.input_dim[1] == 1).  Forward writes
@@ -293,6 +300,12 @@ int afd_bn_backward_apply(const float* x, const float* slope, const float* dy, c
                           const float* invstd, const float* gamma, const float* mean_dy,
                           const float* mean_dy_xhat, float* dx, float* dslope /* += */, int N,
                           int C, int HW, afd_stream_t stream);
+/* The same, also adding the per-channel sums of dx into dx_sums (double[C], += ; NULL: none): what the convolution
+ * that produced x needs as its bias gradient (SyncBatchNorm / BatchNorm2d backward, models.py:260-289). */
+int afd_bn_backward_apply_sums(const float* x, const float* slope, const float* dy, const float* mean,
+                               const float* invstd, const float* gamma, const float* mean_dy,
+                               const float* mean_dy_xhat, float* dx, float* dslope /* += */,
+                               double* dx_sums /* += */, int N, int C, int HW, afd_stream_t stream);
 
 /* The small per-channel steps between the BatchNorm passes, one launch each instead of a chain of
  * elementwise torch kernels (nn.BatchNorm2d / SyncBatchNorm semantics, models.py:260-289):

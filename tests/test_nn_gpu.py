@@ -529,6 +529,32 @@ def test_backward_data_with_batchnorm_sums(shape, cout, act):
     _close(grads[1], grads[0].cpu(), 2e-6, "linked BatchNorm backward")
 
 
+@pytest.mark.parametrize("shape,cout", [((2, 128, 6, 1028), 32), ((1, 96, 4, 1100), 128), ((2, 16, 9, 70), 24)])
+def test_bias_gradient_from_the_batchnorm_backward(shape, cout):
+    """conv -> PReLU -> BatchNorm with the two calls linked (`out_link` / `sum_link`): the convolution's bias
+    gradient is the per-channel sum the BatchNorm backward accumulates while it writes its result
+    (`afd_bn_backward_apply_sums` -> `afd_conv2d_backward_weight_sums`), equal to the unlinked pass over dy; the
+    first two shapes are the layers whose backward-weight product runs with swapped operands (conv.hip)."""
+    torch.manual_seed(21)
+    n, cin, h, w = shape
+    x = torch.randn(shape, device="cuda")
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    bn = torch.nn.BatchNorm2d(cout, affine=False).cuda().train()
+    slope = torch.full((1,), 0.25, device="cuda", requires_grad=True)
+    dy = torch.randn(n, cout, h, w, device="cuda")
+    grads = []
+    for linked in (False, True):
+        conv.zero_grad()
+        link = {} if linked else None
+        z = ops.conv2d(x, conv.weight, conv.bias, 1, 1, out_link=link)
+        y = ops.batch_norm(z, bn, slope, False, None, sum_link=link)
+        y.backward(dy)
+        grads.append((conv.bias.grad.clone(), conv.weight.grad.clone()))
+        assert not linked or "dy_sums" not in link  # consumed by the convolution's backward
+    _close(grads[1][0], grads[0][0].cpu(), 2e-6, "bias gradient from the BatchNorm backward")
+    assert torch.equal(grads[1][1], grads[0][1])
+
+
 @pytest.mark.parametrize("shape", [(2, 96, 12, 1030), (3, 24, 7, 131)])
 def test_batchnorm_backward_inside_the_pool_backward(shape):
     """PReLU + MaxPool2d(2, 2) -> BatchNorm(affine=False): with the two calls linked the BatchNorm's backward is
