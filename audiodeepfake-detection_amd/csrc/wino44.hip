@@ -114,8 +114,10 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
     y[3] = fmaf(8.f, d2, d1) + m5;
 }
 
-template <int CG, bool BORDER, bool BST, bool POOL = false>
-__global__ void __launch_bounds__(CG * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// HELP = 2 (six matrix waves): waves 6, 7 only load and transform patches, together with waves 2, 3 -- the waves of
+// the two SIMDs that carry one matrix wave each, so the SIMDs with two matrix waves do nothing but multiply
+template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0>
+__global__ void __launch_bounds__((CG + HELP) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float V[];  // [2][36][64 lanes][4 k-steps]
@@ -133,9 +135,12 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 
     // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
     // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
-    const bool xf = tid < kCh * kTiles;
+    static_assert(HELP == 0 || (HELP == 2 && CG == 6), "helper waves: the six-wave form");
+    const bool xf = HELP ? (wave & 2) != 0 : tid < kCh * kTiles;
+    const bool mm = wave < CG;  // matrix wave
+    const int tq = HELP ? (wave & 1) + ((wave >> 2) << 1) : (wave & 3);  // which quarter of a chunk's channels
     const int tl = lane & 15, ksx = lane >> 4;
-    const int ch = 4 * ksx + (wave & 3);
+    const int ch = 4 * ksx + tq;
     const int txp = tx0 + tl;
     const int iy0 = 4 * ty - 1, ix0 = 4 * txp - 1;
     const size_t plane = (size_t)g.H * g.W;
@@ -181,7 +186,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
             for (int r = 0; r < 6; ++r) t[r][j] = o[r];
         }
-        float* vb = V + buf * kVBuf + ((wave & 3) * 16 + tl) * 4 + ksx;
+        float* vb = V + buf * kVBuf + (tq * 16 + tl) * 4 + ksx;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             float o[6];
@@ -209,8 +214,10 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
         for (int q = 0; q < 3; ++q) u[slot][q] = *reinterpret_cast<const f32x4*>(uc + (size_t)(3 * grp + q) * CG * 256);
     };
-    load_u(Uw, 0, 0);
-    load_u(Uw, 1, 1);
+    if (mm) {
+        load_u(Uw, 0, 0);
+        load_u(Uw, 1, 1);
+    }
     for (int c = 0; c < g.nchunks; ++c) {
         const bool more = c + 1 < g.nchunks;
         if (xf && more) load_patch(c + 1);
@@ -221,25 +228,28 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
             for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const f32x4*>(vb + (3 * grp + q) * 256);
         };
-        load_b(0, 0);
+        if (HELP == 0 || mm) {
+            load_b(0, 0);
 #pragma unroll
-        for (int grp = 0; grp < 12; ++grp) {
-            if (grp + 2 < 12) load_u(uc, grp + 2, (grp + 2) % 3);
-            else load_u(un, grp + 2 - 12, (grp + 2) % 3);
-            if (grp + 1 < 12) load_b(grp + 1, (grp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int grp = 0; grp < 12; ++grp) {
+                if (grp + 2 < 12) load_u(uc, grp + 2, (grp + 2) % 3);
+                else load_u(un, grp + 2 - 12, (grp + 2) % 3);
+                if (grp + 1 < 12) load_b(grp + 1, (grp + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int p = 3 * grp + q;
-                    acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[grp % 3][q][ks], b[grp & 1][q][ks], acc[p], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int q = 0; q < 3; ++q) {
+                        const int p = 3 * grp + q;
+                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[grp % 3][q][ks], b[grp & 1][q][ks], acc[p], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (xf && more) store_v((c + 1) & 1);
         __syncthreads();
     }
+    if (HELP && !mm) return;  // helper waves: no accumulators, nothing to write
 
     // output transform in registers: Y = A^T M A; D fragment: column (tile) = lane & 15, rows (channels) = 4 (lane >> 4) + j
     const int kq = lane >> 4;
@@ -383,15 +393,15 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     }
 }
 
-template <int CG, bool BST, bool POOL = false>
+template <int CG, bool BST, bool POOL = false, int HELP = 0>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * kVBuf * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr = true;
@@ -408,12 +418,12 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.part_row0 = 0;
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL>), dim3((unsigned)(rows * inner)), dim3(CG * 64), lds,
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
                            s, g, x, U, bias, y);
         g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL>), dim3((unsigned)(rows * edge)), dim3(CG * 64), lds, s, g,
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
                        x, U, bias, y);
     return afd::check_launch("wino44_conv_kernel");
 }
@@ -484,7 +494,9 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
     if (u) {  // pooled forward: u / idx are written, y is not used
-        if (CG == 6) return launch44<6, false, true>(g, x, U, bias, y, s);
+        if (CG == 6)
+            return getenv("AFD_WINO44_NO_HELP") ? launch44<6, false, true>(g, x, U, bias, y, s)
+                                                : launch44<6, false, true, 2>(g, x, U, bias, y, s);
         if (CG == 4) return launch44<4, false, true>(g, x, U, bias, y, s);
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv + pool: Cout %d", Cout);
     }
