@@ -1,0 +1,54 @@
+import sys, torch, random
+sys.path.insert(0, "audiodeepfake-detection_amd")
+import torch.nn.functional as F
+from audiofakedetect import _native, ops
+lib = _native.load()
+random.seed(7); torch.manual_seed(7)
+bad = 0
+def chk(name, got, ref, tol=2e-5):
+    global bad
+    err = (got.double().cpu() - ref).abs().max().item() / (ref.abs().max().item() + 1e-30)
+    ok = err <= tol and bool(torch.isfinite(got).all())
+    if not ok:
+        bad += 1
+    print(f"{'ok ' if ok else 'BAD'} {name}: {err:.2e}", flush=True)
+for it in range(26):
+    h = random.choice([3, 4, 5, 6, 7, 8, 9, 12, 13, 17])
+    w = random.choice([256, 257, 258, 259, 260, 300, 319, 320, 321, 511, 512, 513, 1023, 1025, 1100])
+    n = random.choice([1, 2, 3])
+    kind = random.choice(["dgrad64", "dgrad64s", "fwd128", "dgrad128", "dgrad128s", "pool96", "pool64"])
+    if kind.startswith("dgrad"):
+        cout_f = {"dgrad64": 96, "dgrad64s": 96, "dgrad128": 32, "dgrad128s": 32}[kind]   # forward Cout (dy channels)
+        cin_f = 64 if "64" in kind else 128
+        if cin_f == 128 and h < 5: h = 6
+        dy = torch.randn(n, cout_f, h, w, device="cuda"); wt = torch.randn(cout_f, cin_f, 3, 3, device="cuda") * 0.05
+        dx = torch.full((n, cin_f, h, w), float("nan"), device="cuda")
+        ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin_f, h, w, cout_f, 3, 1, 1), dtype=torch.uint8, device="cuda")
+        ref = torch.nn.grad.conv2d_input((n, cin_f, h, w), wt.double().cpu(), dy.double().cpu(), padding=1)
+        if kind.endswith("s"):
+            xhat = torch.randn(n, cin_f, h, w, device="cuda"); sums = torch.empty(2 * cin_f, dtype=torch.float64, device="cuda")
+            assert lib.afd_conv3x3_backward_data_bnstats_applicable(cin_f, h, w, cout_f)
+            sws = torch.empty(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin_f, h, w), dtype=torch.uint8, device="cuda")
+            _native.check(lib.afd_conv3x3_backward_data_bnstats(_native.ptr(dy), _native.ptr(wt), _native.ptr(dx), _native.ptr(xhat), _native.ptr(sums), n, cin_f, h, w, cout_f, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "d")
+            r = torch.cat([dx.double().sum((0, 2, 3)), (dx.double() * xhat.double()).sum((0, 2, 3))]).cpu()
+            scale = (dx.double().abs() * xhat.double().abs()).sum((0, 2, 3)).max().item()
+            e = (sums.cpu() - r).abs().max().item() / scale
+            if e > 2e-6: bad += 1
+            print(f"   sums {e:.2e}", flush=True)
+        else:
+            _native.check(lib.afd_conv2d_backward_data(_native.ptr(dy), _native.ptr(wt), _native.ptr(dx), n, cin_f, h, w, cout_f, 3, 1, 1, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "dgrad")
+        chk(f"{kind} n{n} h{h} w{w}", dx, ref)
+    elif kind == "fwd128":
+        if h < 5: h = 6
+        x = torch.randn(n, 96, h, w, device="cuda"); wt = torch.randn(128, 96, 3, 3, device="cuda") * 0.05; b = torch.randn(128, device="cuda")
+        y = ops.conv2d(x, wt, b, 1, 1)
+        chk(f"{kind} n{n} h{h} w{w}", y, F.conv2d(x.double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1))
+    else:
+        cin, cout = (64, 96) if kind == "pool96" else (32, 64)
+        if h < 4: h = 4
+        x = torch.randn(n, cin, h, w, device="cuda"); wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05; b = torch.randn(cout, device="cuda")
+        slope = torch.full((1,), 0.25, device="cuda")
+        u = ops.conv3x3_prelu_maxpool(x, wt, b, slope)
+        z = F.conv2d(x.double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1)
+        chk(f"{kind} n{n} h{h} w{w}", u, F.max_pool2d(torch.where(z > 0, z, 0.25 * z), 2, 2))
+print("BAD COUNT", bad)
