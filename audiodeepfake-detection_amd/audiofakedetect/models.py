@@ -105,12 +105,17 @@ class DCNN(nn.Module):
                 pending_bn = None
             elif pooled and ops.conv3x3_prelu_maxpool_applicable(h, conv):
                 # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue: the conv output is never written
+                if pool_link is not None and self.training:
+                    pool_link["want_stats"] = True  # the BatchNorm behind it takes its batch sums from that launch
                 h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link, pool_link)
                 fused_pool = True
             else:
                 # conv -> (PReLU) -> BatchNorm without a pool in between: the BatchNorm's backward hands the
                 # per-channel sums of its result (this layer's bias gradient) over
                 sum_link = {} if (not pooled and bn_i is not None and conv.bias is not None) else None
+                if sum_link is not None and self.training:
+                    sum_link["want_stats"] = True  # the BatchNorm of PReLU(z) takes its batch sums from this launch
+                    sum_link["stats_slope"] = slope
                 z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled,
                                bn_link=in_link, out_link=sum_link)
             if pooled:

@@ -213,6 +213,19 @@ def transpose_contiguous(x: torch.Tensor) -> torch.Tensor:
     return _Transpose.apply(x)
 
 
+def _conv3x3_forward_stats(lib, x, w, b, slope, y, u, idx, geom, ws, link):
+    """Runs the forward 3x3 convolution through `afd_conv3x3_forward_stats` and leaves the BatchNorm batch sums of
+    its result (packed [sum | sum of squares | count slot], as afd_bn_stats) in link["fwd_sums"]."""
+    n, cin, h, wd, cout = geom
+    sums = torch.empty(2 * cout + 1, dtype=torch.float64, device=x.device)
+    sws = _ws(lib.afd_conv3x3_forward_stats_workspace_bytes(n, h, wd, cout), x.device, "fwdstats")
+    _native.check(lib.afd_conv3x3_forward_stats(
+        _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(y), _native.ptr(u),
+        _native.ptr(idx), _native.ptr(sums), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws),
+        sws.numel(), _native.stream_ptr()), "afd_conv3x3_forward_stats")
+    link["fwd_sums"] = sums
+
+
 # --------------------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
@@ -234,10 +247,16 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
         nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
         ws = _ws(nbytes, x.device)
-        _native.check(lib.afd_conv2d_forward_cropped(
-            _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(y), n, cin, h, wd, cout, k,
-            pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(), _native.stream_ptr()),
-            "afd_conv2d_forward")
+        if (out_link is not None and out_link.get("want_stats") and k == 3 and pad == 1 and dil == 1 and not pooled
+                and x.is_cuda and lib.afd_conv3x3_forward_stats_applicable(cin, h, wd, cout, 0)):
+            # the only consumer is a training-mode BatchNorm of PReLU(y): its batch sums from this launch's epilogue
+            _conv3x3_forward_stats(lib, x, w, b, out_link.get("stats_slope"), y, None, None, (n, cin, h, wd, cout), ws,
+                                   out_link)
+        else:
+            _native.check(lib.afd_conv2d_forward_cropped(
+                _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(y), n, cin, h, wd, cout, k,
+                pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+                "afd_conv2d_forward")
         ctx.save_for_backward(x, w)
         ctx.geom = (n, cin, h, wd, cout, k, pad, dil)
         ctx.crop = crop
@@ -457,10 +476,15 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
         idx = torch.empty((n, cout, h // 2, wd // 2), dtype=torch.uint8, device=x.device)
         nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1)
         ws = _ws(nbytes, x.device)
-        _native.check(lib.afd_conv3x3_prelu_pool_forward(
-            _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
-            _native.ptr(idx), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
-            "afd_conv3x3_prelu_pool_forward")
+        if (out_link is not None and out_link.get("want_stats")
+                and lib.afd_conv3x3_forward_stats_applicable(cin, h, wd, cout, 1)):
+            # the only consumer is a training-mode BatchNorm of u: its batch sums from this launch's epilogue
+            _conv3x3_forward_stats(lib, x, w, b, slope, None, u, idx, (n, cin, h, wd, cout), ws, out_link)
+        else:
+            _native.check(lib.afd_conv3x3_prelu_pool_forward(
+                _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
+                _native.ptr(idx), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
+                "afd_conv3x3_prelu_pool_forward")
         _tap("pool", idx)
         ctx.save_for_backward(x, w, u, idx, slope)
         ctx.geom = (n, cin, h, wd, cout, 3, 1, 1)
@@ -537,7 +561,7 @@ def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, sync, link=None, prod_link=None, sum_link=None):
+                eps, sync, link=None, prod_link=None, sum_link=None, pre_sums=None):
         ctx.link = link
         ctx.prod_link = prod_link
         ctx.sum_link = sum_link
@@ -548,9 +572,12 @@ class _BatchNorm(torch.autograd.Function):
         dev = x.device
         count = float(n * hw)
         if training:
-            sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
-            _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c,
-                                           hw, _native.stream_ptr()), "afd_bn_stats")
+            if pre_sums is not None:
+                sums = pre_sums  # from the producer's epilogue (afd_conv3x3_forward_stats)
+            else:
+                sums = torch.empty(2 * c + 1, dtype=torch.float64, device=dev)
+                _native.check(lib.afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c,
+                                               hw, _native.stream_ptr()), "afd_bn_stats")
             if x.is_cuda:
                 # one kernel for mean / invstd / running statistics / num_batches_tracked
                 dist_on = _dist_on(sync)
@@ -618,7 +645,7 @@ class _BatchNorm(torch.autograd.Function):
                 neg = x <= 0
                 dslope = (g * x * neg).sum().reshape(1)
                 g = torch.where(neg, g * slope, g)
-            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]
@@ -652,7 +679,7 @@ class _BatchNorm(torch.autograd.Function):
                                                    _native.ptr(mdyx), _native.ptr(coef), c, _native.stream_ptr()),
                           "afd_bn_backward_coef")
             ctx.prod_link["affine_coef"] = coef
-            return dy, None, None, None, None, None, None, None, None, None, None, None, None, None
+            return dy, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         dx = torch.empty_like(x)
         dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
         # the per-channel sums of dx for the convolution that produced x (its bias gradient), from the same pass
@@ -664,7 +691,7 @@ class _BatchNorm(torch.autograd.Function):
             "afd_bn_backward_apply")
         if dxs is not None:
             ctx.sum_link["dy_sums"] = dxs
-        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None
+        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _fold_forward(w2, b, mean, invstd):
@@ -970,12 +997,17 @@ def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, syn
     convolution that produced x (its `out_link`, this layer being the ONLY consumer of x): the backward pass leaves
     the per-channel sums of its result there -- that convolution's bias gradient."""
     training = bn.training or bn.running_mean is None
+    # batch sums left by the producer of x (`afd_conv3x3_forward_stats`, asked for through "want_stats")
+    pre = None
+    for lk in (prod_link, sum_link):
+        if lk is not None and "fwd_sums" in lk:
+            pre = lk.pop("fwd_sums")
     if not training or bn.weight is not None or slope is not None:
         prod_link = None
     if not training:
-        sum_link = None
+        sum_link = pre = None
     return _BatchNorm.apply(x, slope, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link, sum_link)
+                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link, sum_link, pre)
 
 
 # --------------------------------------------------------------------------------------

@@ -95,7 +95,7 @@ size_t wino44_workspace_bytes(int Cin, int Cout);
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
                const float* bn_in = nullptr, float* stat_part = nullptr, const float* slope = nullptr,
-               float* u = nullptr, unsigned char* idx = nullptr);
+               float* u = nullptr, unsigned char* idx = nullptr, int fwd_stats = 0);
 long wino44_stat_rows(int N, int H, int W);
 bool wino44_pool_applicable(int Cin, int H, int W, int Cout);
 // wino16.hip: the same with 16x16x4 tiles and a register-only output transform

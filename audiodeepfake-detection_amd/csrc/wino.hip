@@ -593,3 +593,49 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
                        sums);
     return afd::check_launch("wino_bnstats_reduce kernels");
 }
+
+// ---- forward 3x3 convolution whose result feeds a training-mode BatchNorm, with that BatchNorm's batch sums ----
+// (the F(4x4) kernel's epilogue, wino44.hip: block 3's pooled forward and block 4's forward at level 14)
+extern "C" int afd_conv3x3_forward_stats_applicable(int Cin, int H, int W, int Cout, int pooled) {
+    if (getenv("AFD_NO_FWD_STATS")) return 0;
+    if (pooled) return Cout == 96 && H >= 2 && W >= 2 && afd::wino44_pool_applicable(Cin, H, W, Cout) ? 1 : 0;
+    return Cout == 128 && afd::wino44_applicable(Cin, H, W, Cout) ? 1 : 0;
+}
+
+static long fwd_stat_rows(int N, int rows, int cols) {
+    const int tilesX = (cols + 3) / 4, tilesY = (rows + 3) / 4;
+    return (long)N * tilesY * ((tilesX + 15) / 16);
+}
+
+extern "C" size_t afd_conv3x3_forward_stats_workspace_bytes(int N, int H, int W, int Cout) {
+    const size_t slots = 2 * ((size_t)(Cout + 31) / 32 * 32);
+    return (size_t)fwd_stat_rows(N, H, W) * slots * sizeof(float) + (size_t)kStatBlocks * slots * sizeof(double) + 64;
+}
+
+extern "C" int afd_conv3x3_forward_stats(const float* x, const float* w, const float* bias, const float* slope,
+                                         float* y, float* u, uint8_t* idx, double* sums, int N, int Cin, int H,
+                                         int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
+                                         size_t stat_ws_bytes, afd_stream_t stream) {
+    if (!x || !w || !sums || !ws || !stat_ws || (!y && !u) || (u && (!idx || !slope)))
+        return afd::fail(AFD_ERR_ARG, "conv3x3 + bn sums: null pointer");
+    const int pooled = u != nullptr;
+    if (N < 1 || !afd_conv3x3_forward_stats_applicable(Cin, H, W, Cout, pooled))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 + bn sums: layer not on the F(4x4) Winograd kernel");
+    if (stat_ws_bytes < afd_conv3x3_forward_stats_workspace_bytes(N, H, W, Cout))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv3x3 + bn sums: statistics workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows_out = pooled ? 2 * (H / 2) : H, cols_out = pooled ? 2 * (W / 2) : W;
+    const int co_pad = (Cout + 31) / 32 * 32;
+    const int slots = 2 * co_pad;
+    const long rows = fwd_stat_rows(N, rows_out, cols_out);
+    float* part = static_cast<float*>(stat_ws);
+    double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
+    int rc = afd::wino44_run(x, w, bias, y, N, Cin, H, W, Cout, 0, rows_out, cols_out, ws, ws_bytes, s, nullptr, part, slope,
+                             u, idx, 1);
+    if (rc) return rc;
+    const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
+    hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cout,
+                       sums);
+    return afd::check_launch("conv3x3 forward statistics reduce kernels");
+}

@@ -116,7 +116,10 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
 
 // HELP = 2 (six matrix waves): waves 6, 7 only load and transform patches, together with waves 2, 3 -- the waves of
 // the two SIMDs that carry one matrix wave each, so the SIMDs with two matrix waves do nothing but multiply
-template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0>
+// FST (forward launches whose result feeds a training-mode BatchNorm): the epilogue also sums, per channel, v and
+// v^2 over its outputs -- v the pooled value, or PReLU(y) with g.slope (y itself when it is null) -- one partial
+// row [sum v | sum v^2] per workgroup, in the rows the BST form uses
+template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false>
 __global__ void __launch_bounds__((CG + HELP) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
@@ -268,7 +271,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             zn[r] = *reinterpret_cast<const f4u*>(g.bn_in + (((size_t)n * g.Cout + co) * g.H + oyr) * g.W + oxq);
         }
     };
-    float sg[BST ? 4 : 1], sgv[BST ? 4 : 1];
+    static_assert(!(BST && FST), "one statistics epilogue per launch");
+    float sg[(BST || FST) ? 4 : 1], sgv[(BST || FST) ? 4 : 1];
     if constexpr (BST) load_xhat(0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -280,6 +284,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             if (j + 1 < 4) load_xhat(j + 1);
             sg[j] = sgv[j] = 0.f;
         }
+        if constexpr (FST) sg[j] = sgv[j] = 0.f;
         float s[4][6];  // A^T M: rows of outputs x 6 position columns
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -322,6 +327,11 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                         }
                         const int px = 2 * txe;
                         const size_t o = (((size_t)n * g.Cout + co) * PH + py) * PW + px;
+                        if constexpr (FST) {
+                            const float u1 = px + 1 < PW ? ub[1] : 0.f, u0 = px < PW ? ub[0] : 0.f;
+                            sg[j] += u0 + u1;
+                            sgv[j] += fmaf(u0, u0, u1 * u1);
+                        }
                         if (px + 1 < PW) {
                             f2u uv = {ub[0], ub[1]};
                             *reinterpret_cast<f2u*>(g.u + o) = uv;
@@ -359,6 +369,18 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                         sg[j] += (gq[0] + gq[1]) + (gq[2] + gq[3]);
                         sgv[j] += fmaf(gq[0], zv[0], gq[1] * zv[1]) + fmaf(gq[2], zv[2], gq[3] * zv[3]);
                     }
+                    if constexpr (FST) {
+                        const bool act = g.slope != nullptr;
+                        const float a = act ? g.slope[0] : 1.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v = o[q] + bv;
+                            v = (act && v <= 0.f) ? a * v : v;
+                            v = (!BORDER || ox + q < g.cols) ? v : 0.f;
+                            sg[j] += v;
+                            sgv[j] = fmaf(v, v, sgv[j]);
+                        }
+                    }
                     if (!BORDER || ox + 3 < g.cols) {
                         f4u v = {o[0] + bv, o[1] + bv, o[2] + bv, o[3] + bv};
                         *reinterpret_cast<f4u*>(yo + (size_t)r * g.W) = v;
@@ -371,7 +393,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             }
         }
     }
-    if constexpr (BST) {
+    if constexpr (BST || FST) {
         // a channel's outputs of this workgroup sit in the 16 lanes of one quarter wave
         const int co_pad = (g.Cout + 31) / 32 * 32;
         float* row = g.stat_part + ((size_t)g.part_row0 + blockIdx.x) * (2 * co_pad);
@@ -393,15 +415,15 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     }
 }
 
-template <int CG, bool BST, bool POOL = false, int HELP = 0>
+template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * kVBuf * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr = true;
@@ -418,12 +440,12 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.part_row0 = 0;
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
                            s, g, x, U, bias, y);
         g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
                        x, U, bias, y);
     return afd::check_launch("wino44_conv_kernel");
 }
@@ -467,7 +489,7 @@ long wino44_stat_rows(int N, int H, int W) {
 
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
-               const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx) {
+               const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx, int fwd_stats) {
     if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
     G4 g{};
@@ -479,10 +501,12 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.nchunks = Cin / kCh;
     g.bn_in = bn_in; g.stat_part = stat_part;
     g.slope = slope; g.u = u; g.idx = idx;
-    if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx || stat_part))
+    if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx || (stat_part && !fwd_stats)))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv + pool: bad arguments");
-    if (stat_part && (!bn_in || g.rows != H || g.cols != W))
+    if (stat_part && !fwd_stats && (!bn_in || g.rows != H || g.cols != W))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: statistics epilogue on a cropped output");
+    if (fwd_stats && (!stat_part || dgrad || (!u && (g.rows != H || g.cols != W))))
+        return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: forward statistics: bad arguments");
     const int CG = (Cout + 15) / 16;
     if (!x || !w || (!y && !u)) return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: null pointer");
     float* U = static_cast<float*>(ws);
@@ -494,6 +518,8 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
     if (u) {  // pooled forward: u / idx are written, y is not used
+        if (CG == 6 && fwd_stats) return launch44<6, false, true, 2, true>(g, x, U, bias, y, s);
+        if (fwd_stats) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv + pool: statistics for Cout %d", Cout);
         if (CG == 6)
             return getenv("AFD_WINO44_NO_HELP") ? launch44<6, false, true>(g, x, U, bias, y, s)
                                                 : launch44<6, false, true, 2>(g, x, U, bias, y, s);
@@ -501,6 +527,10 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv + pool: Cout %d", Cout);
     }
     if (!y) return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: null output");
+    if (fwd_stats) {
+        if (CG == 8) return launch44<8, false, false, 0, true>(g, x, U, bias, y, s);
+        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: forward statistics for Cout %d", Cout);
+    }
     if (CG == 4) return stat_part ? launch44<4, true>(g, x, U, bias, y, s) : launch44<4, false>(g, x, U, bias, y, s);
     if (CG == 8) return stat_part ? launch44<8, true>(g, x, U, bias, y, s) : launch44<8, false>(g, x, U, bias, y, s);
     return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: Cout %d", Cout);

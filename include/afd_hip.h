@@ -180,6 +180,18 @@ size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, 
 int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w, float* dx, const float* xhat, double* sums,
                                       int N, int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes,
                                       void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
+
+/* Forward 3x3 / pad 1 convolution whose result feeds a training-mode BatchNorm, with that BatchNorm's batch sums from
+ * the kernel's epilogue: sums[c] = sum v, sums[Cout + c] = sum v^2 (the layout afd_bn_stats writes), v = the pooled
+ * value when u / idx are given (Conv2d + PReLU + MaxPool2d(2, 2) as afd_conv3x3_prelu_pool_forward, y unused), else
+ * PReLU(y) with `slope` (y itself for a NULL slope).  Only for the layers the F(4x4) Winograd kernel takes
+ * (afd_conv3x3_forward_stats_applicable); reference: nn.Conv2d -> nn.PReLU [-> nn.MaxPool2d] -> nn.BatchNorm2d of
+ * DCNN blocks 3 and 4 (src/audiofakedetect/models.py:263-270). */
+int afd_conv3x3_forward_stats_applicable(int Cin, int H, int W, int Cout, int pooled);
+size_t afd_conv3x3_forward_stats_workspace_bytes(int N, int H, int W, int Cout);
+int afd_conv3x3_forward_stats(const float* x, const float* w, const float* bias, const float* slope, float* y,
+                              float* u, uint8_t* idx, double* sums, int N, int Cin, int H, int W, int Cout,
+                              void* ws, size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
 int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                float* dbias /* may be NULL */, int N, int Cin, int H, int W,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,

@@ -529,6 +529,49 @@ def test_backward_data_with_batchnorm_sums(shape, cout, act):
     _close(grads[1], grads[0].cpu(), 2e-6, "linked BatchNorm backward")
 
 
+@pytest.mark.parametrize("shape,cout,pooled", [((2, 64, 12, 1030), 96, True), ((1, 64, 13, 259), 96, True),
+                                               ((2, 96, 6, 1101), 128, False)])
+def test_batchnorm_batch_sums_from_the_convolution_epilogue(shape, cout, pooled):
+    """`afd_conv3x3_forward_stats` (the F(4x4) Winograd kernel's statistics epilogue): the convolution output (or
+    pooled value and code) is the plain launch's bit for bit, the sums match float64 sums of PReLU(y) / u, and through
+    autograd conv [-> pool] -> BatchNorm gives the same output and gradients with and without the hand-over."""
+    torch.manual_seed(31)
+    lib = _native.load()
+    n, cin, h, w = shape
+    assert lib.afd_conv3x3_forward_stats_applicable(cin, h, w, cout, int(pooled))
+    x = torch.randn(shape, device="cuda")
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    bn = torch.nn.BatchNorm2d(cout, affine=False).cuda().train()
+    slope = torch.full((1,), 0.25, device="cuda")
+    outs = []
+    for linked in (False, True):
+        bn.reset_running_stats()
+        conv.zero_grad()
+        xg = x.clone().requires_grad_(True)
+        link = {"want_stats": True, "stats_slope": slope} if linked else {}
+        if pooled:
+            u = ops.conv3x3_prelu_maxpool(xg, conv.weight, conv.bias, slope, None, link)
+            y = ops.batch_norm(u, bn, None, False, None, link)
+            mid = u
+        else:
+            z = ops.conv2d(xg, conv.weight, conv.bias, 1, 1, out_link=link)
+            y = ops.batch_norm(z, bn, slope, False, None, sum_link=link)
+            mid = z
+        assert "fwd_sums" not in link  # consumed by the BatchNorm's forward
+        y.backward(torch.ones_like(y) * torch.linspace(-1, 1, y.shape[-1], device="cuda"))
+        outs.append((mid.detach().clone(), y.detach().clone(), xg.grad.clone(), conv.weight.grad.clone(),
+                     bn.running_mean.clone(), bn.running_var.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    _close(outs[1][1], outs[0][1].cpu(), 2e-6, "BatchNorm output")
+    _close(outs[1][2], outs[0][2].cpu(), 1e-5, "input gradient")
+    _close(outs[1][3], outs[0][3].cpu(), 1e-5, "weight gradient")
+    _close(outs[1][4], outs[0][4].cpu(), 2e-6, "running mean")
+    _close(outs[1][5], outs[0][5].cpu(), 2e-6, "running variance")
+    v = outs[0][0].double() if pooled else torch.where(outs[0][0] > 0, outs[0][0], 0.25 * outs[0][0]).double()
+    mean_ref = v.mean((0, 2, 3))
+    _close(outs[1][4] / 0.1, mean_ref.cpu(), 1e-5, "batch mean against float64")
+
+
 @pytest.mark.parametrize("shape,cout", [((2, 128, 6, 1028), 32), ((1, 96, 4, 1100), 128), ((2, 16, 9, 70), 24)])
 def test_bias_gradient_from_the_batchnorm_backward(shape, cout):
     """conv -> PReLU -> BatchNorm with the two calls linked (`out_link` / `sum_link`): the convolution's bias
