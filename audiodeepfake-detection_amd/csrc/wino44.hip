@@ -459,10 +459,11 @@ bool wino44_applicable(int Cin, int H, int W, int Cout) {
     // four waves (64 output channels): block 3's backward-data at level 14, 7.7 -> 5.9 ms; six waves (96 channels)
     // would leave two SIMDs with one wave.  Rows: ceil(H / 4) * 36 matrix products against ceil(H / 2) * 32
     // eight waves (128 output channels): block 4 forward 3.7 -> 2.8 ms, block 5 backward-data 1.6 -> 1.4 ms
-    // (measured on the level-14 coif4 geometry, 6 rows; shorter images stay on the F(2x2) kernels; six waves on
-    // block 4's backward-data, 128 -> 96 channels, measured level: 3.3 ms either way, 3.8 against 3.6 with the sums)
-    if (Cin % kCh != 0 || (Cout != 64 && Cout != 128)) return false;
-    if (W < 256 || H < (Cout == 128 ? 5 : 3)) return false;
+    // (measured on the level-14 coif4 geometry, 6 rows; shorter images stay on the F(2x2) kernels)
+    // 96 channels (block 4's backward-data; conv3x3_run sends forward layers of that width elsewhere): six matrix
+    // waves + two helper waves, 3.57 -> 3.38 ms with the BatchNorm sums (level without the helpers)
+    if (Cin % kCh != 0 || (Cout != 64 && Cout != 96 && Cout != 128)) return false;
+    if (W < 256 || H < (Cout == 64 ? 3 : 5)) return false;
     return (size_t)H * W < 0x7fffffffULL;
 }
 
@@ -532,6 +533,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: forward statistics for Cout %d", Cout);
     }
     if (CG == 4) return stat_part ? launch44<4, true>(g, x, U, bias, y, s) : launch44<4, false>(g, x, U, bias, y, s);
+    if (CG == 6) return stat_part ? launch44<6, true, false, 2>(g, x, U, bias, y, s) : launch44<6, false, false, 2>(g, x, U, bias, y, s);
     if (CG == 8) return stat_part ? launch44<8, true>(g, x, U, bias, y, s) : launch44<8, false>(g, x, U, bias, y, s);
     return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: Cout %d", Cout);
 }

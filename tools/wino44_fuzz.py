@@ -16,11 +16,11 @@ for it in range(26):
     h = random.choice([3, 4, 5, 6, 7, 8, 9, 12, 13, 17])
     w = random.choice([256, 257, 258, 259, 260, 300, 319, 320, 321, 511, 512, 513, 1023, 1025, 1100])
     n = random.choice([1, 2, 3])
-    kind = random.choice(["dgrad64", "dgrad64s", "fwd128", "dgrad128", "dgrad128s", "pool96", "pool64"])
+    kind = random.choice(["dgrad64", "dgrad64s", "fwd128", "dgrad128", "dgrad128s", "pool96", "pool64", "dgrad96s"])
     if kind.startswith("dgrad"):
-        cout_f = {"dgrad64": 96, "dgrad64s": 96, "dgrad128": 32, "dgrad128s": 32}[kind]   # forward Cout (dy channels)
-        cin_f = 64 if "64" in kind else 128
-        if cin_f == 128 and h < 5: h = 6
+        cout_f = {"dgrad64": 96, "dgrad64s": 96, "dgrad128": 32, "dgrad128s": 32, "dgrad96s": 128}[kind]   # forward Cout (dy channels)
+        cin_f = 64 if "64" in kind else (96 if "96" in kind else 128)
+        if cin_f != 64 and h < 5: h = 6
         dy = torch.randn(n, cout_f, h, w, device="cuda"); wt = torch.randn(cout_f, cin_f, 3, 3, device="cuda") * 0.05
         dx = torch.full((n, cin_f, h, w), float("nan"), device="cuda")
         ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin_f, h, w, cout_f, 3, 1, 1), dtype=torch.uint8, device="cuda")
