@@ -58,20 +58,20 @@ __device__ __forceinline__ float g_row(int i, float a, float b, float c) {
     }
 }
 
-// U table: [chunk][position][cg][lane][kstep (4)] = U_p[16 cg + (lane & 15)][16 chunk + 4 kstep + (lane >> 4)]
+// U table: [chunk][position][cg][lane][kstep (KS)] = U_p[16 cg + (lane & 15)][4 KS chunk + 4 kstep + (lane >> 4)]
 __global__ void wino44_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
-                                      int CG, int nchunks, int dgrad) {
-    const int total = nchunks * kPos * CG * 4 * 64;
+                                      int CG, int nchunks, int dgrad, int KS) {
+    const int total = nchunks * kPos * CG * KS * 64;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int ks = i & 3;
-        const int lane = (i >> 2) & 63;
-        int r = i >> 8;
+        const int ks = i % KS;
+        const int lane = (i / KS) & 63;
+        int r = i / (64 * KS);
         const int cg = r % CG;
         r /= CG;
         const int p = r % kPos;
         const int chunk = r / kPos;
         const int co = 16 * cg + (lane & 15);
-        const int ci = kCh * chunk + 4 * ks + (lane >> 4);
+        const int ci = 4 * KS * chunk + 4 * ks + (lane >> 4);
         float v = 0.f;
         if (co < Cout && ci < Cin) {
             float g[3][3];
@@ -119,7 +119,9 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
 // FST (forward launches whose result feeds a training-mode BatchNorm): the epilogue also sums, per channel, v and
 // v^2 over its outputs -- v the pooled value, or PReLU(y) with g.slope (y itself when it is null) -- one partial
 // row [sum v | sum v^2] per workgroup, in the rows the BST form uses
-template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false>
+// KS = k-steps of 4 input channels per chunk: 4, or 2 for the two-wave form (32 output channels: 128 threads
+// transform the 128 patches of an 8-channel chunk; 37 KB of LDS, four workgroups per CU)
+template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4>
 __global__ void __launch_bounds__((CG + HELP) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
@@ -139,11 +141,20 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
     // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
     static_assert(HELP == 0 || (HELP == 2 && CG == 6), "helper waves: the six-wave form");
-    const bool xf = HELP ? (wave & 2) != 0 : tid < kCh * kTiles;
+    constexpr int CHK = 4 * KS;          // input channels per chunk
+    constexpr int PS = 64 * KS;          // floats per position of a V image / U fragment block
+    constexpr int VB = kPos * PS;        // floats per V buffer
+    typedef float vk __attribute__((ext_vector_type(KS)));
+    static_assert(KS == 4 || (KS == 2 && CG == 2 && HELP == 0), "two k-steps per chunk: the two-wave form");
+    const bool xf = HELP ? (wave & 2) != 0 : tid < CHK * kTiles;
     const bool mm = wave < CG;  // matrix wave
     const int tq = HELP ? (wave & 1) + ((wave >> 2) << 1) : (wave & 3);  // which quarter of a chunk's channels
-    const int tl = lane & 15, ksx = lane >> 4;
-    const int ch = 4 * ksx + tq;
+    const int tl = lane & 15;
+    // the patch of channel 4 ks_t + kq_t of the chunk: KS = 4: wave = kq_t, lane = (ks_t, tile); KS = 2: wave = ks_t,
+    // lane = (kq_t, tile)
+    const int kq_t = KS == 4 ? tq : (lane >> 4);
+    const int ksx = KS == 4 ? (lane >> 4) : (wave & 1);
+    const int ch = 4 * ksx + kq_t;
     const int txp = tx0 + tl;
     const int iy0 = 4 * ty - 1, ix0 = 4 * txp - 1;
     const size_t plane = (size_t)g.H * g.W;
@@ -151,7 +162,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const bool rows_in = iy0 >= 0 && iy0 + 5 < g.H;  // uniform
     float d[6][6];
     auto load_patch = [&](int c) {
-        const float* xc = xn + (size_t)(c * kCh + ch) * plane;
+        const float* xc = xn + (size_t)(c * CHK + ch) * plane;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int iy = iy0 + r;
@@ -189,13 +200,13 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
             for (int r = 0; r < 6; ++r) t[r][j] = o[r];
         }
-        float* vb = V + buf * kVBuf + (tq * 16 + tl) * 4 + ksx;
+        float* vb = V + buf * VB + (kq_t * 16 + tl) * KS + ksx;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             float o[6];
             bt6(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vb[(r * 6 + j) * 256] = o[j];
+            for (int j = 0; j < 6; ++j) vb[(r * 6 + j) * PS] = o[j];
         }
     };
 
@@ -204,7 +215,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     for (int p = 0; p < kPos; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // U fragments of chunk c, position p (four k-steps): Uw[((c * 36 + p) * CG) * 256]
-    const float* Uw = U + (size_t)wave * 256 + lane * 4;
+    const float* Uw = U + (size_t)wave * PS + lane * KS;
     if (xf) {
         load_patch(0);
         store_v(0);
@@ -212,10 +223,10 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     __syncthreads();
     // positions in groups of 3: U fragments (L2) are requested two groups ahead of their MFMAs -- the first two groups
     // of a chunk during the previous chunk's last groups, i.e. before the transform -- and V fragments (LDS) one ahead
-    f32x4 u[3][3], b[2][3];
+    vk u[3][3], b[2][3];
     auto load_u = [&](const float* uc, int grp, int slot) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) u[slot][q] = *reinterpret_cast<const f32x4*>(uc + (size_t)(3 * grp + q) * CG * 256);
+        for (int q = 0; q < 3; ++q) u[slot][q] = *reinterpret_cast<const vk*>(uc + (size_t)(3 * grp + q) * CG * PS);
     };
     if (mm) {
         load_u(Uw, 0, 0);
@@ -224,12 +235,12 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     for (int c = 0; c < g.nchunks; ++c) {
         const bool more = c + 1 < g.nchunks;
         if (xf && more) load_patch(c + 1);
-        const float* uc = Uw + (size_t)c * kPos * CG * 256;
-        const float* un = Uw + (size_t)(more ? c + 1 : c) * kPos * CG * 256;  // (the last chunk re-reads its own)
-        const float* vb = V + (c & 1) * kVBuf + lane * 4;
+        const float* uc = Uw + (size_t)c * kPos * CG * PS;
+        const float* un = Uw + (size_t)(more ? c + 1 : c) * kPos * CG * PS;  // (the last chunk re-reads its own)
+        const float* vb = V + (c & 1) * VB + lane * KS;
         auto load_b = [&](int grp, int slot) {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const f32x4*>(vb + (3 * grp + q) * 256);
+            for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const vk*>(vb + (3 * grp + q) * PS);
         };
         if (HELP == 0 || mm) {
             load_b(0, 0);
@@ -240,7 +251,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                 if (grp + 1 < 12) load_b(grp + 1, (grp + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
                         const int p = 3 * grp + q;
@@ -415,15 +426,15 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     }
 }
 
-template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false>
+template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * kVBuf * sizeof(float);
+    constexpr size_t lds = (size_t)2 * kPos * 64 * KS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr = true;
@@ -440,12 +451,12 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.part_row0 = 0;
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
                            s, g, x, U, bias, y);
         g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
                        x, U, bias, y);
     return afd::check_launch("wino44_conv_kernel");
 }
@@ -462,7 +473,9 @@ bool wino44_applicable(int Cin, int H, int W, int Cout) {
     // (measured on the level-14 coif4 geometry, 6 rows; shorter images stay on the F(2x2) kernels)
     // 96 channels (block 4's backward-data; conv3x3_run sends forward layers of that width elsewhere): six matrix
     // waves + two helper waves, 3.57 -> 3.38 ms with the BatchNorm sums (level without the helpers)
-    if (Cin % kCh != 0 || (Cout != 64 && Cout != 96 && Cout != 128)) return false;
+    // 32 channels (block 5 forward, block 6 backward-data): two waves, 8-channel chunks: 1.52 -> 1.38 and 0.86 -> 0.78 ms
+    const bool c32 = Cout == 32 && Cin % 8 == 0;
+    if (!c32 && (Cin % kCh != 0 || (Cout != 64 && Cout != 96 && Cout != 128))) return false;
     if (W < 256 || H < (Cout == 64 ? 3 : 5)) return false;
     return (size_t)H * W < 0x7fffffffULL;
 }
@@ -479,7 +492,7 @@ bool wino44_pool_applicable(int Cin, int H, int W, int Cout) {
 
 size_t wino44_workspace_bytes(int Cin, int Cout) {
     const size_t cg = (size_t)(Cout + 15) / 16;
-    return (size_t)(Cin / kCh) * kPos * cg * 4 * 64 * sizeof(float);
+    return (size_t)(Cin / 4) * kPos * cg * 64 * sizeof(float);  // (either chunk depth)
 }
 
 // workgroups (= partial rows of the statistics epilogue) of a launch pair over N images of H x W outputs
@@ -499,7 +512,8 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.cols = out_cols < W ? out_cols : W;
     g.tilesX = (g.cols + 3) / 4;
     g.tilesY = (g.rows + 3) / 4;
-    g.nchunks = Cin / kCh;
+    const int KS = Cout <= 32 ? 2 : 4;
+    g.nchunks = Cin / (4 * KS);
     g.bn_in = bn_in; g.stat_part = stat_part;
     g.slope = slope; g.u = u; g.idx = idx;
     if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx || (stat_part && !fwd_stats)))
@@ -511,9 +525,9 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     const int CG = (Cout + 15) / 16;
     if (!x || !w || (!y && !u)) return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: null pointer");
     float* U = static_cast<float*>(ws);
-    const int total = g.nchunks * kPos * CG * 4 * 64;
+    const int total = g.nchunks * kPos * CG * KS * 64;
     hipLaunchKernelGGL(wino44_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, CG,
-                       g.nchunks, dgrad);
+                       g.nchunks, dgrad, KS);
     int rc = afd::check_launch("wino44_weights_kernel");
     if (rc) return rc;
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
@@ -532,6 +546,9 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
         if (CG == 8) return launch44<8, false, false, 0, true>(g, x, U, bias, y, s);
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: forward statistics for Cout %d", Cout);
     }
+    if (CG == 2)
+        return stat_part ? launch44<2, true, false, 0, false, 2>(g, x, U, bias, y, s)
+                         : launch44<2, false, false, 0, false, 2>(g, x, U, bias, y, s);
     if (CG == 4) return stat_part ? launch44<4, true>(g, x, U, bias, y, s) : launch44<4, false>(g, x, U, bias, y, s);
     if (CG == 6) return stat_part ? launch44<6, true, false, 2>(g, x, U, bias, y, s) : launch44<6, false, false, 2>(g, x, U, bias, y, s);
     if (CG == 8) return stat_part ? launch44<8, true>(g, x, U, bias, y, s) : launch44<8, false>(g, x, U, bias, y, s);

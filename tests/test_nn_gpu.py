@@ -703,6 +703,9 @@ def _issued_winograd(fn):
     (1, 96, 13, 1030, 64, "dgrad"),   # block 3 backward-data: forward 64 -> 96, the GEMM's output is 64 channels
     (2, 32, 6, 1027, 128, "dgrad"),   # block 5 backward-data: forward 128 -> 32
     (1, 96, 3, 300, 64, "dgrad"),     # a single tile row with one row unused
+    (1, 128, 6, 1030, 96, "dgrad"),   # block 4 backward-data: six matrix waves + two helper waves
+    (2, 128, 6, 1027, 32, "fwd"),     # block 5 forward: two waves, 8-channel chunks
+    (2, 64, 7, 300, 32, "dgrad"),     # block 6 backward-data
 ])
 def test_winograd_f44_layers(case):
     """wino44.hip, Winograd F(4x4, 3x3): against float64 at the stated bar for that kernel -- 2e-5 of the largest

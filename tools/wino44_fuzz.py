@@ -12,14 +12,14 @@ def chk(name, got, ref, tol=2e-5):
     if not ok:
         bad += 1
     print(f"{'ok ' if ok else 'BAD'} {name}: {err:.2e}", flush=True)
-for it in range(26):
+for it in range(40):
     h = random.choice([3, 4, 5, 6, 7, 8, 9, 12, 13, 17])
     w = random.choice([256, 257, 258, 259, 260, 300, 319, 320, 321, 511, 512, 513, 1023, 1025, 1100])
     n = random.choice([1, 2, 3])
-    kind = random.choice(["dgrad64", "dgrad64s", "fwd128", "dgrad128", "dgrad128s", "pool96", "pool64", "dgrad96s"])
+    kind = random.choice(["dgrad64", "dgrad64s", "fwd128", "dgrad128", "dgrad128s", "pool96", "pool64", "dgrad96s", "fwd32", "dgrad32s"])
     if kind.startswith("dgrad"):
-        cout_f = {"dgrad64": 96, "dgrad64s": 96, "dgrad128": 32, "dgrad128s": 32, "dgrad96s": 128}[kind]   # forward Cout (dy channels)
-        cin_f = 64 if "64" in kind else (96 if "96" in kind else 128)
+        cout_f = {"dgrad64": 96, "dgrad64s": 96, "dgrad128": 32, "dgrad128s": 32, "dgrad96s": 128, "dgrad32s": 64}[kind]   # forward Cout (dy channels)
+        cin_f = 64 if "64" in kind else (96 if "96" in kind else (32 if "32" in kind else 128))
         if cin_f != 64 and h < 5: h = 6
         dy = torch.randn(n, cout_f, h, w, device="cuda"); wt = torch.randn(cout_f, cin_f, 3, 3, device="cuda") * 0.05
         dx = torch.full((n, cin_f, h, w), float("nan"), device="cuda")
@@ -38,9 +38,10 @@ for it in range(26):
         else:
             _native.check(lib.afd_conv2d_backward_data(_native.ptr(dy), _native.ptr(wt), _native.ptr(dx), n, cin_f, h, w, cout_f, 3, 1, 1, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "dgrad")
         chk(f"{kind} n{n} h{h} w{w}", dx, ref)
-    elif kind == "fwd128":
+    elif kind in ("fwd128", "fwd32"):
         if h < 5: h = 6
-        x = torch.randn(n, 96, h, w, device="cuda"); wt = torch.randn(128, 96, 3, 3, device="cuda") * 0.05; b = torch.randn(128, device="cuda")
+        ci_, co_ = (96, 128) if kind == "fwd128" else (random.choice([128, 40, 8]), 32)
+        x = torch.randn(n, ci_, h, w, device="cuda"); wt = torch.randn(co_, ci_, 3, 3, device="cuda") * 0.05; b = torch.randn(co_, device="cuda")
         y = ops.conv2d(x, wt, b, 1, 1)
         chk(f"{kind} n{n} h{h} w{w}", y, F.conv2d(x.double().cpu(), wt.double().cpu(), b.double().cpu(), padding=1))
     else:
