@@ -599,7 +599,7 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
 extern "C" int afd_conv3x3_forward_stats_applicable(int Cin, int H, int W, int Cout, int pooled) {
     if (getenv("AFD_NO_FWD_STATS")) return 0;
     if (pooled) return Cout == 96 && H >= 2 && W >= 2 && afd::wino44_pool_applicable(Cin, H, W, Cout) ? 1 : 0;
-    return Cout == 128 && afd::wino44_applicable(Cin, H, W, Cout) ? 1 : 0;
+    return (Cout == 128 || Cout == 32) && afd::wino44_applicable(Cin, H, W, Cout) ? 1 : 0;
 }
 
 static long fwd_stat_rows(int N, int rows, int cols) {

@@ -544,6 +544,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     if (!y) return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: null output");
     if (fwd_stats) {
         if (CG == 8) return launch44<8, false, false, 0, true>(g, x, U, bias, y, s);
+        if (CG == 2) return launch44<2, false, false, 0, true, 2>(g, x, U, bias, y, s);
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: forward statistics for Cout %d", Cout);
     }
     if (CG == 2)

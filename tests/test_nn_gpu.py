@@ -530,7 +530,7 @@ def test_backward_data_with_batchnorm_sums(shape, cout, act):
 
 
 @pytest.mark.parametrize("shape,cout,pooled", [((2, 64, 12, 1030), 96, True), ((1, 64, 13, 259), 96, True),
-                                               ((2, 96, 6, 1101), 128, False)])
+                                               ((2, 96, 6, 1101), 128, False), ((2, 128, 6, 1027), 32, False)])
 def test_batchnorm_batch_sums_from_the_convolution_epilogue(shape, cout, pooled):
     """`afd_conv3x3_forward_stats` (the F(4x4) Winograd kernel's statistics epilogue): the convolution output (or
     pooled value and code) is the plain launch's bit for bit, the sums match float64 sums of PReLU(y) / u, and through
