@@ -470,13 +470,13 @@ bool wino44_applicable(int Cin, int H, int W, int Cout) {
     // four waves (64 output channels): block 3's backward-data at level 14, 7.7 -> 5.9 ms; six waves (96 channels)
     // would leave two SIMDs with one wave.  Rows: ceil(H / 4) * 36 matrix products against ceil(H / 2) * 32
     // eight waves (128 output channels): block 4 forward 3.7 -> 2.8 ms, block 5 backward-data 1.6 -> 1.4 ms
-    // (measured on the level-14 coif4 geometry, 6 rows; shorter images stay on the F(2x2) kernels)
+    // (measured on the level-14 geometries: coif4, 13 / 6 rows, and sym5, 6 / 3 rows -- the sym5 step 33.3 -> 30.8 ms)
     // 96 channels (block 4's backward-data; conv3x3_run sends forward layers of that width elsewhere): six matrix
     // waves + two helper waves, 3.57 -> 3.38 ms with the BatchNorm sums (level without the helpers)
     // 32 channels (block 5 forward, block 6 backward-data): two waves, 8-channel chunks: 1.52 -> 1.38 and 0.86 -> 0.78 ms
     const bool c32 = Cout == 32 && Cin % 8 == 0;
     if (!c32 && (Cin % kCh != 0 || (Cout != 64 && Cout != 96 && Cout != 128))) return false;
-    if (W < 256 || H < (Cout == 64 ? 3 : 5)) return false;
+    if (W < 256 || H < 3) return false;
     return (size_t)H * W < 0x7fffffffULL;
 }
 

@@ -634,10 +634,11 @@ WIDE3X3 = [(2, 32, 6, 1100, 64), (1, 96, 4, 1025, 128), (1, 64, 13, 1157, 96), (
 @pytest.mark.parametrize("shape", WIDE3X3)
 @pytest.mark.parametrize("winograd", [True, False])
 def test_3x3_layers_on_both_kernels(shape, winograd, monkeypatch):
-    """The 3x3 / pad 1 layers with more than 32 output channels run on the Winograd F(2x2,3x3)
-    kernel (wino.hip); AFD_NO_WINOGRAD=1 keeps them on the direct implicit GEMM (conv3x3.hip).
-    Both against float64, forward and backward-data, and against each other: the transform adds
-    rounding (inputs and filters are combined before the products) but stays inside the same bar."""
+    """The 3x3 / pad 1 layers with more than 32 output channels run on a Winograd kernel -- F(2x2,3x3)
+    (wino.hip), or F(4x4,3x3) (wino44.hip) on images at least 256 wide; AFD_NO_WINOGRAD=1 keeps them on the
+    direct implicit GEMM (conv3x3.hip).  Both against float64, forward and backward-data: the F(2x2) transform adds
+    rounding (inputs and filters are combined before the products) but stays inside the direct kernel's 1e-5 bar;
+    the F(4x4) kernels' stated bar is 2e-5 (transform constants up to 8; test_winograd_f44_layers)."""
     if not winograd:
         monkeypatch.setenv("AFD_NO_WINOGRAD", "1")
     n, cin, h, w, cout = shape
@@ -652,8 +653,9 @@ def test_3x3_layers_on_both_kernels(shape, winograd, monkeypatch):
     xg, wg, bg = (t.cuda().requires_grad_() for t in (x, wt, b))
     yg = ops.conv2d(xg, wg, bg, 1, 1)
     yg.backward(dy.cuda())
-    _close(yg, yr.detach(), 1e-5, "fwd")
-    _close(xg.grad, xr.grad, 1e-5, "dgrad")
+    bar = 2e-5 if (winograd and w >= 256) else 1e-5
+    _close(yg, yr.detach(), bar, "fwd")
+    _close(xg.grad, xr.grad, bar, "dgrad")
     _close(wg.grad, wr.grad, 3e-5, "wgrad")
 
 
