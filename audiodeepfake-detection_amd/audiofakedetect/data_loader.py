@@ -307,13 +307,21 @@ class NativeFrameLoader:
         return {self.ds.key: torch.stack([it[self.ds.key] for it in items]).to(self.device, non_blocking=True),
                 "label": torch.stack([it["label"] for it in items]).to(self.device)}
 
-    def _pinned(self, n: int, win: int) -> torch.Tensor:
+    def _pinned(self, n: int, win: int):
+        """A pinned staging buffer of this shape that no copy is reading: two per shape, used alternately,
+        each with the event recorded behind its last host-to-device copy -- the file read of batch k + 1
+        waits for the COPY of batch k - 1 only, never for the training step that consumes batch k."""
         key = ("pin", n, win)
-        buf = self._banks.get(key)
-        if buf is None:
-            buf = torch.empty((n, win), dtype=torch.int16).pin_memory()
-            self._banks[key] = buf
-        return buf
+        ring = self._banks.get(key)
+        if ring is None:
+            ring = {"bufs": [torch.empty((n, win), dtype=torch.int16).pin_memory() for _ in range(2)],
+                    "events": [None, None], "next": 0}
+            self._banks[key] = ring
+        slot = ring["next"]
+        ring["next"] = 1 - slot
+        if ring["events"][slot] is not None:
+            ring["events"][slot].synchronize()
+        return ring, slot
 
     def __iter__(self):
         import ctypes
@@ -338,8 +346,8 @@ class NativeFrameLoader:
                 pos = np.nonzero(wins == win)[0]
                 m = len(pos)
                 win = int(win)
-                stream.synchronize()  # the pinned buffer of this shape may still feed the previous batch's copy
-                pcm = self._pinned(m, win)
+                ring, slot = self._pinned(m, win)
+                pcm = ring["bufs"][slot]
                 rates = (ctypes.c_int * m)()
                 paths = (ctypes.c_char_p * m)(*[os.fsencode(str(p)) for p in batch[pos, 0]])
                 offs = (ctypes.c_longlong * m)(*[int(f) * win for f in batch[pos, 1]])
@@ -357,6 +365,9 @@ class NativeFrameLoader:
                     ok = False
                     break
                 dev_pcm = pcm.to(self.device, non_blocking=True)
+                ev = ring["events"][slot] or torch.cuda.Event()
+                ev.record(stream)
+                ring["events"][slot] = ev
                 bank, width = (None, 0) if orig == new else self._bank(orig, new)
                 part = out if m == n else torch.empty((m, 1, n_out), dtype=torch.float32, device=self.device)
                 _native.check(lib.afd_pcm16_resample(_native.ptr(dev_pcm), m, win, orig, new, width, _native.ptr(bank),

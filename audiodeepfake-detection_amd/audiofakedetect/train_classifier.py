@@ -96,7 +96,7 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
 def _loader(args: DotDict, ds, train: bool):
     """Only the training split drops its ragged tail (sampler and loader); validation / test see every
     sample, the DistributedSampler padding a shard by wrapping around (reference :118-158)."""
-    if args.native_loader and isinstance(ds, CustomDataset):
+    if args.native_loader and type(ds) is CustomDataset:  # the Detailed variant carries per-item fields the batch reader drops
         rank = dist.get_rank() if dist.is_initialized() else 0
         world = dist.get_world_size() if dist.is_initialized() else 1
         return NativeFrameLoader(ds, args.batch_size, torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))),
@@ -117,6 +117,14 @@ def start_gradient_allreduce(optimizer) -> None:
     queued; `sync_gradients` picks the handle up."""
     if not (dist.is_initialized() and dist.get_world_size() > 1 and isinstance(optimizer, ops.FusedAdam)):
         return
+    # a backward pass that raised never ran its end-of-backward callbacks: drop a hook it left queued (two
+    # hooks would issue two all-reduces over the arena, of which only one is waited for and scaled) and
+    # finish a collective it may have started
+    ops._end_of_backward.clear()
+    stale = getattr(optimizer, "_pending_allreduce", None)
+    if stale is not None:
+        optimizer._pending_allreduce = None
+        stale.wait()
 
     def fire() -> None:
         if optimizer.flat_grad.is_cuda:
@@ -491,15 +499,23 @@ class Trainer:
 
 
 def snapshot_name(args: DotDict, model) -> str:
-    """Snapshot file stem with the reference's fields (:1222-1271): transform, wavelet, features, STFT /
-    packet geometry, optimiser settings, model name, sign channel, power, source, frame length, seed."""
+    """Snapshot file stem exactly as the reference composes it (:1162, :1221-1267), so that `--only-testing` /
+    `--only-ig` find files written by the reference or by earlier runs: `path_name = basename(data_prefix).split("_")`
+    gives the leading field (`path_name[0]`) and the field after f_min-f_max (`path_name[3]`, the train ratio of
+    the reference's prepared folders, e.g. `fake_22050_22050_0.7_fbmelgan`); the source is `only_use[1]`; the
+    augmentation flags are written as given.  Where the reference would raise IndexError (a prefix with fewer
+    than four fields, fewer than two sources) the field is left out / the last source is used."""
     tr = "stft" if args.transform == "stft" else "packets" + str(args.wavelet)
     name = model.get_name() if hasattr(model, "get_name") else "customModel"
-    src = (args.only_use or ["all"])[-1]
-    return (f"fake_{tr}_{args.features}_{args.hop_length}_{args.sample_rate}_{args.window_size}_"
-            f"{args.num_of_scales}_{int(args.f_min or 0)}-{int(args.f_max or 0)}_{args.learning_rate}_"
+    path_name = str(args.data_prefix or "fake").rstrip("/").split("/")[-1].split("_")
+    only_use = list(args.only_use or ["all"])
+    src = only_use[1] if len(only_use) > 1 else only_use[-1]
+    ratio = f"{path_name[3]}_" if len(path_name) > 3 else ""
+    loss_less = False if args.loss_less == "False" else True
+    return (f"{path_name[0]}_{tr}_{args.features}_{args.hop_length}_{args.sample_rate}_{args.window_size}_"
+            f"{args.num_of_scales}_{int(args.f_min or 0)}-{int(args.f_max or 0)}_{ratio}{args.learning_rate}_"
             f"{args.weight_decay}_{args.batch_size}_{args.nclasses}_{args.epochs}e_{name}_"
-            f"signs{args.loss_less == 'True'}_augc{bool(args.aug_contrast)}_augn{bool(args.aug_noise)}_"
+            f"signs{loss_less}_augc{args.aug_contrast}_augn{args.aug_noise}_"
             f"power{args.power}_{src}_{args.seconds}secs_{args.seed}")
 
 

@@ -15,6 +15,7 @@
 #include "../../include/afd_hip.h"
 
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <atomic>
@@ -27,7 +28,8 @@
 namespace {
 
 struct WavInfo {
-    int channels = 0, rate = 0, bits = 0, format = 0;
+    int channels = 0, rate = 0, bits = 0, format = 0, block_align = 0;
+    bool pcm_subformat = true;  // WAVE_FORMAT_EXTENSIBLE: the sub-format GUID starts with the PCM tag
     long long data_off = -1, data_bytes = 0;
 };
 
@@ -50,12 +52,22 @@ int parse_wav(int fd, WavInfo& w) {
             w.format = (int)rd16(f);
             w.channels = (int)rd16(f + 2);
             w.rate = (int)rd32(f + 4);
+            w.block_align = (int)rd16(f + 12);
             w.bits = (int)rd16(f + 14);
+            if (w.format == 0xFFFE) {  // extensible: cbSize(2) validBits(2) channelMask(4) SubFormat GUID(16)
+                unsigned char g[2];
+                w.pcm_subformat = size >= 40 && pread(fd, g, 2, pos + 8 + 24) == 2 && rd16(g) == 1;
+            }
             have_fmt = true;
         } else if (!memcmp(c, "data", 4)) {
             if (!have_fmt) return -1;
             w.data_off = pos + 8;
-            w.data_bytes = size;
+            // the chunk size of a truncated or streamed file (0, 0xFFFFFFFF) is not to be trusted: the data end
+            // where the file ends
+            struct stat st;
+            long long have = fstat(fd, &st) == 0 ? (long long)st.st_size - w.data_off : (long long)size;
+            if (have < 0) have = 0;
+            w.data_bytes = (size == 0 || size == 0xFFFFFFFFu || (long long)size > have) ? have : (long long)size;
             return 0;
         }
         pos += 8 + (long long)size + (size & 1);
@@ -63,15 +75,31 @@ int parse_wav(int fd, WavInfo& w) {
     return -1;
 }
 
-// window `i`: frames [offset, offset + win) of channel 0 -> out[i * win ..]; 0 = ok, 1 = io, 2 = format
+// pread until `bytes` are in or the file ends; returns the bytes read (-1 on an I/O error)
+long long pread_all(int fd, void* dst, size_t bytes, long long off) {
+    size_t got = 0;
+    while (got < bytes) {
+        const ssize_t r = pread(fd, (char*)dst + got, bytes - got, off + (long long)got);
+        if (r < 0) return -1;
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    return (long long)got;
+}
+
+// window `i`: frames [offset, offset + win) of channel 0 -> out[i * win ..]; 0 = ok, 1 = io, 2 = format,
+// 3 = negative frame offset.  Frames past the end of the data (also of a file shorter than its header says)
+// are zero-filled.
 int read_one(const char* path, long long offset, int win, int16_t* out, int* rate) {
+    if (offset < 0) return 3;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return 1;
     WavInfo w;
     int rc = 0;
     if (parse_wav(fd, w)) {
         rc = 2;
-    } else if ((w.format != 1 && w.format != 0xFFFE) || w.bits != 16 || w.channels < 1 || w.channels > 8) {
+    } else if ((w.format != 1 && w.format != 0xFFFE) || !w.pcm_subformat || w.bits != 16 || w.channels < 1 ||
+               w.channels > 8 || w.block_align != 2 * w.channels) {
         rc = 2;
     } else {
         *rate = w.rate;
@@ -81,10 +109,12 @@ int read_one(const char* path, long long offset, int win, int16_t* out, int* rat
         if (avail > win) avail = win;
         const size_t bytes = (size_t)avail * 2 * w.channels;
         if (w.channels == 1) {
-            if (bytes && pread(fd, out, bytes, w.data_off + offset * 2) != (ssize_t)bytes) rc = 1;
+            const long long got = bytes ? pread_all(fd, out, bytes, w.data_off + offset * 2) : 0;
+            if (got < 0) rc = 1; else avail = got / 2;
         } else {
             std::vector<int16_t> tmp((size_t)avail * w.channels);
-            if (bytes && pread(fd, tmp.data(), bytes, w.data_off + offset * 2 * w.channels) != (ssize_t)bytes) rc = 1;
+            const long long got = bytes ? pread_all(fd, tmp.data(), bytes, w.data_off + offset * 2 * w.channels) : 0;
+            if (got < 0) rc = 1; else avail = got / (2LL * w.channels);
             for (long long j = 0; j < avail; ++j) out[j] = tmp[(size_t)j * w.channels];
         }
         for (long long j = avail; j < win; ++j) out[j] = 0;
@@ -142,9 +172,11 @@ extern "C" int afd_wav_read_windows(const char* const* paths, const long long* f
     work();
     for (auto& t : pool) t.join();
     const int fb = first_bad.load();
-    if (fb >= 0)
-        return afd::fail(bad_code.load() == 2 ? AFD_ERR_UNSUPPORTED : AFD_ERR_ARG, "wav reader: %s: %s", paths[fb],
-                         bad_code.load() == 2 ? "not a 16-bit PCM WAV file" : "cannot read");
+    if (fb >= 0) {
+        const int bc = bad_code.load();
+        return afd::fail(bc == 2 ? AFD_ERR_UNSUPPORTED : AFD_ERR_ARG, "wav reader: %s: %s", paths[fb],
+                         bc == 2 ? "not a 16-bit PCM WAV file" : bc == 3 ? "negative frame offset" : "cannot read");
+    }
     return AFD_OK;
 }
 

@@ -44,6 +44,13 @@ def cpu_sync(rank, world):
     full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     assert torch.allclose(opt.flat_grad * scale, full, atol=1e-6), "all-reduced grads != full-batch grads"
 
+    # a backward pass that raised leaves its one-shot hook queued: the next step must not inherit it
+    from audiofakedetect.train_classifier import start_gradient_allreduce
+    start_gradient_allreduce(opt)
+    start_gradient_allreduce(opt)
+    assert len(ops._end_of_backward) == 1, "stale end-of-backward hook survived"
+    ops._end_of_backward.clear()
+
     # packed BN statistics: [sum | sumsq | count] all-reduce -> global mean / biased var
     c = 3
     data = torch.randn(8, c, 5, generator=torch.Generator().manual_seed(9)).double()
@@ -96,7 +103,8 @@ def gpu_dcnn(rank, world):
     opt.zero_grad()
     out = wrapped(x[rank * 4:(rank + 1) * 4])
     loss = ops.CrossEntropyLoss()(out, y[rank * 4:(rank + 1) * 4])
-    start_gradient_allreduce(opt)  # the all-reduce is issued by the end-of-backward hook
+    start_gradient_allreduce(opt)  # as left behind by a step whose backward raised before its callbacks ran
+    start_gradient_allreduce(opt)  # the all-reduce is issued (once) by the end-of-backward hook
     loss.backward()
     assert getattr(opt, "_pending_allreduce", None) is not None
     scale = sync_gradients(wrapped, opt)

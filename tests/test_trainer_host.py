@@ -230,3 +230,53 @@ def test_native_wav_window_reader(tmp_path):
         f.write(b"RIFF\x00\x00\x00\x00WAVEjunk")
     bad = (ctypes.c_char_p * 1)(str(tmp_path / "bad.wav").encode())
     assert lib.afd_wav_read_windows(bad, offs, 1, win, out.ctypes.data_as(ctypes.c_void_p), rates, 1) != 0
+    # a negative frame offset is an argument error (it used to read header bytes as samples)
+    one = (ctypes.c_char_p * 1)(str(tmp_path / "a.wav").encode())
+    neg = (ctypes.c_longlong * 1)(-5)
+    assert lib.afd_wav_read_windows(one, neg, 1, win, out.ctypes.data_as(ctypes.c_void_p), rates, 1) != 0
+    assert b"negative" in lib.afd_last_error()
+    # a file cut short of what its header promises, and a streamed file whose data size reads 0xFFFFFFFF:
+    # what is there, then zeros
+    raw = open(tmp_path / "a.wav", "rb").read()
+    data_at = raw.index(b"data") + 8
+    keep = 1000  # frames
+    with open(tmp_path / "cut.wav", "wb") as f:
+        f.write(raw[:data_at + 2 * keep])
+    with open(tmp_path / "stream.wav", "wb") as f:
+        f.write(raw[:data_at - 4] + b"\xff\xff\xff\xff" + raw[data_at:data_at + 2 * keep])
+    full = np.frombuffer(raw[data_at:data_at + 2 * keep], dtype=np.int16)
+    for name in ("cut.wav", "stream.wav"):
+        one = (ctypes.c_char_p * 1)(str(tmp_path / name).encode())
+        zero = (ctypes.c_longlong * 1)(0)
+        out[0] = 77
+        assert lib.afd_wav_read_windows(one, zero, 1, win, out.ctypes.data_as(ctypes.c_void_p), rates, 1) == 0, name
+        assert np.array_equal(out[0, :keep], full) and not out[0, keep:].any(), name
+    # block_align that contradicts channels * 2 is refused
+    fmt_at = raw.index(b"fmt ") + 8
+    with open(tmp_path / "align.wav", "wb") as f:
+        f.write(raw[:fmt_at + 12] + b"\x04\x00" + raw[fmt_at + 14:])
+    one = (ctypes.c_char_p * 1)(str(tmp_path / "align.wav").encode())
+    assert lib.afd_wav_read_windows(one, (ctypes.c_longlong * 1)(0), 1, win, out.ctypes.data_as(ctypes.c_void_p), rates, 1) != 0
+
+
+def test_snapshot_name_reproduces_the_reference_file_names():
+    """The stem composed from the grid-search settings (scripts/gridsearch_config.py, scripts/train.sh) is the
+    file name of the checkpoints the reference ships under models/ (train_classifier.py:1162, :1221-1267)."""
+    from audiofakedetect.train_classifier import snapshot_name
+    from audiofakedetect.utils import DotDict
+
+    class M:
+        def get_name(self):
+            return "DCNN"
+
+    a = DotDict(transform="packets", wavelet="sym5", features="none", hop_length=220, sample_rate=22050,
+                window_size=22050, num_of_scales=256, f_min=1, f_max=11025, learning_rate=0.0004,
+                weight_decay=0.001, batch_size=128, nclasses=2, epochs=10, loss_less="False", aug_contrast=False,
+                aug_noise=False, power=2.0, only_use=["ljspeech", "fbmelgan"], seconds=1, seed=0,
+                data_prefix="/p/data/model_22050_22050_0.7_fbmelgan")
+    assert snapshot_name(a, M()) == ("model_packetssym5_none_220_22050_22050_256_1-11025_0.7_0.0004_0.001_128_2_10e_"
+                                     "DCNN_signsFalse_augcFalse_augnFalse_power2.0_fbmelgan_1secs_0")
+    a.transform = "stft"
+    assert snapshot_name(a, M()).startswith("model_stft_none_220_")
+    a.data_prefix, a.only_use = "../data/fake", None  # the defaults: fields the reference could not index are left out
+    assert snapshot_name(a, M()).startswith("fake_stft_none_220_22050_22050_256_1-11025_0.0004_")
