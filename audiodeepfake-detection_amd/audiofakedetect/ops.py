@@ -47,55 +47,12 @@ def _ws(nbytes: int, device, lane: str = "main") -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------
-# Weight gradients on a side stream.  A conv's backward-weight kernel (MFMA-bound, little HBM
-# traffic) depends only on the layer's input and its output gradient; the main chain meanwhile
-# runs the BatchNorm / pool backward passes (HBM-bound, no matrix work) and the next backward-data
-# kernel.  When the parameter's gradient lives in a FusedAdam arena the kernel is issued on a
-# second HIP stream and adds its result into the arena view there; an end-of-backward callback
-# joins the streams before anything reads the arena.
-_side_streams: dict = {}
-_side_pending: set = set()
+# Every kernel of a step runs on the caller's stream.  Rounds 1-2 issued the convolutions' backward-weight kernels
+# on a second HIP stream; measured at the end of round 2 it bought 0.7 ms of a 63.6 ms step while its MFMA-bound
+# and HBM-bound partners queued on CU residency (launch durations stretched 4-10x), and streams confined to disjoint
+# CU partitions (hipExtStreamCreateWithCUMask) were 1.4-3x slower -- profiles/r03_stream_modes.json.  Removed.
 
-
-def _side_enabled() -> bool:
-    return os.environ.get("AFD_WGRAD_STREAM", "1") != "0"
-
-
-def _side_stream(device) -> "torch.cuda.Stream":
-    st = _side_streams.get(device.index)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _side_streams[device.index] = st
-    return st
-
-
-def _join_side(device_index: int) -> None:
-    _side_pending.discard(device_index)
-    torch.cuda.current_stream(device_index).wait_stream(_side_streams[device_index])
-
-
-def join_side_stream(device=None) -> None:
-    """Make the current stream wait for everything queued on the weight-gradient stream.  Idempotent and
-    unconditional: called by everything that reads or rewrites the gradient arena (the gradient
-    all-reduce, FusedAdam.step / zero_grad), so a backward pass that raised before its end-of-backward
-    callback ran cannot leave later steps racing the side stream."""
-    idx = device.index if isinstance(device, torch.device) else (torch.cuda.current_device() if device is None else device)
-    st = _side_streams.get(idx)
-    if st is not None:
-        _side_pending.discard(idx)
-        torch.cuda.current_stream(idx).wait_stream(st)
-
-
-def _queue_join(device) -> None:
-    if device.index in _side_pending:
-        return
-    _side_pending.add(device.index)
-    idx = device.index
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: _join_side(idx))
-
-
-# One-shot hook run by the autograd engine at the very end of the next backward pass (after the weight-
-# gradient stream has been joined): the data-parallel step starts its gradient all-reduce from here, without
+# One-shot hook run by the autograd engine at the very end of the next backward pass: the data-parallel step starts its gradient all-reduce from here, without
 # a trip back through the Python step code (train_classifier.sync_gradients then only waits for it).
 _end_of_backward: list = []
 
@@ -303,45 +260,12 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
             _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
             _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv2d_backward_data")
     if need_dw or need_db:
-        # only for parameters whose .grad is a FusedAdam arena view (flagged by the optimizer):
-        # there the gradient is wanted in .grad, as loss.backward() leaves it; a caller of
-        # torch.autograd.grad(.., weights) on such a model must set AFD_WGRAD_STREAM=0
-        side = (_side_enabled() and x.is_cuda and w.grad is not None
-                and getattr(w, "_afd_arena", False)
-                and (not has_bias or (b is not None and b.grad is not None
-                                      and getattr(b, "_afd_arena", False))))
-        if side:
-            # The side stream waits for the main stream AFTER this layer's backward-data launch: the weight-
-            # gradient kernel then runs beside the BatchNorm / pool backward passes that follow (HBM-bound),
-            # not beside the backward-data kernel (both MFMA-bound: measured 77.0-78.3 ms/step with an event
-            # recorded before the backward-data launch against 75.8-77.0 ms this way).
-            main = torch.cuda.current_stream(x.device)
-            st = _side_stream(x.device)
-            st.wait_stream(main)  # dy (and the zeroed arena) are ready
-            with torch.cuda.stream(st):
-                dwt = torch.empty_like(w)
-                dbt = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-                ws2 = _ws(nbytes, x.device, "side")
-                _native.check(lib.afd_conv2d_backward_weight_sums(
-                    _native.ptr(x), _native.ptr(dy), _native.ptr(dwt), _native.ptr(dbt), _native.ptr(dy_sums), n,
-                    cin, h, wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws2), ws2.numel(),
-                    _native.stream_ptr()), "afd_conv2d_backward_weight")
-                with torch.no_grad():
-                    w.grad.add_(dwt)
-                    if dbt is not None:
-                        b.grad.add_(dbt)
-            x.record_stream(st)
-            dy.record_stream(st)
-            if dy_sums is not None:
-                dy_sums.record_stream(st)
-            _queue_join(x.device)
-        else:
-            dw = torch.empty_like(w)
-            db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-            _native.check(lib.afd_conv2d_backward_weight_sums(
-                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), _native.ptr(dy_sums), n, cin, h,
-                wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
-                _native.stream_ptr()), "afd_conv2d_backward_weight")
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        _native.check(lib.afd_conv2d_backward_weight_sums(
+            _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), _native.ptr(dy_sums), n, cin, h,
+            wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
+            _native.stream_ptr()), "afd_conv2d_backward_weight")
     return dx, dw, db
 
 
@@ -1129,7 +1053,7 @@ class _CrossEntropy(torch.autograd.Function):
         (dl,) = ctx.saved_tensors
         if _end_of_backward:
             # the loss is the first node of every backward pass: callbacks queued here run once the
-            # engine has finished the whole graph, after those queued by the layers (side-stream join)
+            # engine has finished the whole graph
             torch.autograd.Variable._execution_engine.queue_callback(_run_end_of_backward)
         return dl * dloss, None
 
@@ -1181,8 +1105,6 @@ class FusedAdam(torch.optim.Optimizer):
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False):  # keep the arena views alive
-        if self.flat_grad.is_cuda:
-            join_side_stream(self.flat_grad.device)
         self.flat_grad.zero_()
         self._relink()
 
@@ -1191,13 +1113,10 @@ class FusedAdam(torch.optim.Optimizer):
         for p, off in zip(self._params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
                 p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
-            p._afd_arena = True  # ops._Conv2d may add its weight gradient into the view directly
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         g = self.param_groups[0]
-        if self.flat_grad.is_cuda:
-            join_side_stream(self.flat_grad.device)
         self.step_count += 1
         _native.check(_lib().afd_adam_step(
             _native.ptr(self.flat), _native.ptr(self.flat_grad), _native.ptr(self.m),

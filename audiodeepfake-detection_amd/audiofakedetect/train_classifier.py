@@ -82,8 +82,6 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
             work.wait()
             return 1.0 / world
         ops._end_of_backward.clear()  # a hook whose backward never reached the loss node (foreign loss function)
-        if optimizer.flat_grad.is_cuda:
-            ops.join_side_stream(optimizer.flat_grad.device)
         dist.all_reduce(optimizer.flat_grad)
         return 1.0 / world
     for p in model.parameters():
@@ -127,8 +125,6 @@ def start_gradient_allreduce(optimizer) -> None:
         stale.wait()
 
     def fire() -> None:
-        if optimizer.flat_grad.is_cuda:
-            ops.join_side_stream(optimizer.flat_grad.device)
         optimizer._pending_allreduce = dist.all_reduce(optimizer.flat_grad, async_op=True)
 
     ops.at_end_of_backward(fire)

@@ -15,8 +15,8 @@ batch 128 per GPU, fp32.  ``--workload haar-l14-frontend`` (BASELINE configs[3],
 the batch); ``stft-lcnn-eval`` is configs[4]'s evaluation forward.
 
 Extra objects on the JSON line:
-  roofline      the kernel class with the largest share of the step AS TIMED (backward-weight
-                kernels on their second stream), from HIP events on each launch's own stream.
+  roofline      the kernel class with the largest share of the step, from HIP events around every launch
+                (all kernels run on the caller's stream: a launch's duration is the kernel's own time).
                 MFMA-bound classes: achieved = flops really issued on the matrix cores (tile padding
                 included, Winograd = its 16 or 36 GEMMs) / summed launch time, frac = achieved / 157.3 TF/s;
                 the layer's direct-form flops are reported beside it as algorithmic_TFLOPs.
@@ -174,37 +174,61 @@ def cpu_model() -> str:
     return "unknown CPU"
 
 
-def cpu_baseline(workload: str, frames: int, steps: int = 2):
-    """The reference's algorithm on torch CPU (oracle 'port') on a bounded sample of the workload.
+def host_cores() -> int:
+    """Physical cores this process may run on (the GPU box gives one GPU's share of the node's cores)."""
+    allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        import psutil
 
-    Front end: `frames` full frames through the per-node pad + conv1d recursion with the per-node
+        physical = psutil.cpu_count(logical=False) or allowed
+    except Exception:  # noqa: BLE001 - psutil is optional
+        physical = allowed
+    return max(1, min(allowed, physical))
+
+
+def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 10):
+    """The reference's algorithm on torch CPU (oracle 'port') on a bounded sample of the workload, by the
+    protocol of BASELINE.md section 3: all physical cores this process may use, >= 10 timed front-end batches
+    and 1 untimed + >= 3 timed train steps, medians; frames/s = B_cpu / (front end + step).
+
+    Front end: batches of `frames` full frames through the per-node pad + conv1d recursion with the per-node
     Welford updates left on, as the reference runs it (wavelet_math.py:182-206), + log + normalise.
-    Train workloads add the FULL-WIDTH DCNN step (forward, cross entropy, backward, Adam with coupled
-    L2) on those frames: one untimed step, then `steps` timed ones.  BASELINE.md section 3 asks for
-    B = 128 and >= 3 steps; one level-14 frame is 64 GFLOP of fp32 convolutions plus 16 384
-    pad/conv/Welford node updates (~2.5 s per frame on 16 threads), so the sample is cut to
-    `frames` frames to keep the default bench run within minutes -- the figure is frames/s either way.
+    Train workloads add the FULL-WIDTH DCNN step (forward, cross entropy, backward, Adam with coupled L2).
+    BASELINE.md asks for B = 128; one level-14 frame is 64 GFLOP of fp32 convolutions plus 16 384
+    pad/conv/Welford node updates (~2.5 s per frame on 16 threads, linear in the frames), so the batch is cut
+    to `frames` of 128 frames to keep the default bench run within minutes -- the figure is frames/s either way.
     """
+    import statistics
+
     from oracle import torch_ref, wpt_oracle
 
     transform, wavelet, scales, add, kind = WORKLOADS[workload][:5]
-    cores = min(os.cpu_count() or 1, 16)  # the GPU box's CPU share for one GPU
+    cores = host_cores()
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(99)
     x = (0.1 * torch.randn(frames, 1, 22050, generator=g)).clamp_(-1, 1)
     labels = torch.randint(0, 2, (frames,), generator=g)
     level = scales.bit_length() - 1
-    t0 = time.perf_counter()
-    if transform == "packets":
-        feats, _ = torch_ref.packets_torch(x, wpt_oracle.TAPS[wavelet], level, log_scale=True,
-                                           compute_welford=True, per_node=True)
-    else:
-        feats = torch_ref.stft_torch(x, 2 * scales - 1, 220, log_scale=True)
-    feats = torch_ref.normalize_torch(feats, 0.0, 1.0)
-    t_fe = time.perf_counter() - t0
-    log(f"cpu baseline: front end {t_fe:.2f} s for {frames} frames ({cores} threads)")
-    sample = (f"{frames} frame(s) of the same workload on {cpu_model()}, {cores} torch threads: front end "
-              f"{t_fe:.2f} s (per-node pad+conv1d recursion, Welford on)")
+
+    def front_end():
+        if transform == "packets":
+            feats, _ = torch_ref.packets_torch(x, wpt_oracle.TAPS[wavelet], level, log_scale=True,
+                                               compute_welford=True, per_node=True)
+        else:
+            feats = torch_ref.stft_torch(x, 2 * scales - 1, 220, log_scale=True)
+        return torch_ref.normalize_torch(feats, 0.0, 1.0)
+
+    fe_times = []
+    for _ in range(fe_batches):
+        t0 = time.perf_counter()
+        feats = front_end()
+        fe_times.append(time.perf_counter() - t0)
+    t_fe = statistics.median(fe_times)
+    log(f"cpu baseline: front end {t_fe:.2f} s per batch of {frames} frame(s) ({cores} threads, {fe_batches} batches)")
+    sample = (f"B = {frames} of 128 frames of the same workload on {cpu_model()}, {cores} torch threads "
+              f"(= the physical cores this process may use; os.cpu_count() = {os.cpu_count()}): front end "
+              f"{t_fe:.2f} s per batch (median of {fe_batches} timed batches; per-node pad+conv1d recursion, "
+              f"Welford on)")
     total = t_fe
     if kind == "train" and "lcnn" not in workload:
         packets = feats.shape[2]
@@ -213,13 +237,15 @@ def cpu_baseline(workload: str, frames: int, steps: int = 2):
         net.train()
         fc = feats.contiguous()
         torch_ref.train_step_torch(net, opt, fc, labels)  # untimed: allocator / oneDNN primitive warm-up
-        t1 = time.perf_counter()
+        st_times = []
         for _ in range(steps):
+            t1 = time.perf_counter()
             torch_ref.train_step_torch(net, opt, fc, labels)
-        t_step = (time.perf_counter() - t1) / steps
+            st_times.append(time.perf_counter() - t1)
+        t_step = statistics.median(st_times)
         total += t_step
         sample += (f" + full-width DCNN forward/backward/Adam {t_step:.2f} s per step "
-                   f"(mean of {steps} timed steps after 1 untimed)")
+                   f"(median of {steps} timed steps after 1 untimed)")
     elif kind != "frontend":
         sample += "; model step not timed on the CPU for this workload"
     return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
@@ -297,7 +323,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default 128; 4096 for haar-l14-frontend)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=1, help="CPU baseline batch, B_cpu of 128 frames (0 = skip)")
     ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through a child torch.distributed.run even for --gpus 1")
@@ -383,10 +409,10 @@ def main() -> None:
     step_ms = 1e3 * elapsed / a.steps
     log(f"timed {a.steps} steps: {step_ms:.3f} ms/step")
 
-    # ---- per-kernel-class timing (HIP events on each launch's own stream), after the timed region:
-    # the step as it is timed above (one step; >= 20 for the front-end workloads, whose class is one
-    # or two launches per step)
-    timed_steps = max(20, a.steps) if kind == "frontend" else 1
+    # ---- per-kernel-class timing (HIP events around every launch, on the stream it is issued on), after the
+    # timed region: three steps as they are timed above (>= 20 for the front-end workloads, whose class is one or
+    # two launches per step).  Every kernel runs on the caller's stream, so a launch's duration is the kernel's own.
+    timed_steps = max(20, a.steps) if kind == "frontend" else 3
     _native.timing_reset()
     _native.timing_enable(True)
     for _ in range(timed_steps):
@@ -395,24 +421,6 @@ def main() -> None:
     _native.timing_enable(False)
     kernels = collect(_native)
     _native.timing_reset()
-    # the same step once more with the backward-weight kernels on the main stream: each kernel's own
-    # time, with no other stream's kernels sharing the CUs (reported as roofline["serial"])
-    serial = {}
-    if kind == "train":
-        prev = os.environ.get("AFD_WGRAD_STREAM")
-        os.environ["AFD_WGRAD_STREAM"] = "0"
-        try:
-            _native.timing_enable(True)
-            step()
-            torch.cuda.synchronize()
-            _native.timing_enable(False)
-            serial = collect(_native)
-        finally:
-            _native.timing_reset()
-            if prev is None:
-                os.environ.pop("AFD_WGRAD_STREAM", None)
-            else:
-                os.environ["AFD_WGRAD_STREAM"] = prev
 
     pmc = load_pmc(a.workload, batch_size)
     roofline = None
@@ -424,12 +432,7 @@ def main() -> None:
         roofline = roofline_of(dom, kernels[dom], timed_steps, pmc)
         roofline["share_of_step"] = kernels[dom]["total_ms"] / timed_steps / step_ms
         roofline["timing"] = (f"HIP events around every launch of the class in {timed_steps} step(s) run as the "
-                              "timed steps are (backward-weight kernels on their second stream)")
-        if dom in serial:
-            s = roofline_of(dom, serial[dom], 1, None)
-            roofline["serial"] = {"achieved": s["achieved"], "frac": s["frac"], "avg_launch_ms": s["avg_launch_ms"],
-                                  "note": "the same launches with AFD_WGRAD_STREAM=0: no second stream's kernels "
-                                          "share the CUs (a kernel's own time)"}
+                              "timed steps are (one stream: a launch's duration is the kernel's own time)")
     classes = {}
     for name, k in kernels.items():
         c = {"launches_per_step": k["launches"] / timed_steps, "ms_per_step": k["total_ms"] / timed_steps,
@@ -441,10 +444,6 @@ def main() -> None:
             c["mfma_frac"] = c["issued_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
         else:
             c["achieved_GBps"] = c["algorithmic_bytes_per_step"] / (c["ms_per_step"] * 1e-3) / 1e9 if c["ms_per_step"] else None
-        if name in serial:
-            c["ms_per_step_serial"] = serial[name]["total_ms"]
-            if serial[name]["issued"]:
-                c["mfma_frac_serial"] = serial[name]["issued"] / (serial[name]["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
         classes[name] = c
     frontend = None
     if "wpt" in kernels:
@@ -488,7 +487,7 @@ def main() -> None:
             "world": {"size": world, "backend": "rccl (torch.distributed nccl)" if ddp else None,
                       "rccl_version": rccl, "devices": devices,
                       "collectives": "gradient arena all-reduce + packed SyncBN statistics" if ddp and kind == "train" else None},
-            "classes": classes, "last_loss": loss,
+            "classes": classes, "class_timing_steps": timed_steps, "last_loss": loss,
         }
         print(json.dumps(line), flush=True)
     if ddp:

@@ -41,8 +41,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 # steps the trace covers: warm-up + timed + the instrumented ones bench.py adds after the timed region
 steps = None
 if line:
-    kind_extra = 20 if "front end only" in line["config"]["workload"] else (1 if "eval" in line["config"]["workload"] else 2)
-    steps = line["warmup"] + line["steps"] + max(kind_extra, line["steps"] if kind_extra == 20 else 0)
+    # bench.py reports how many instrumented steps it ran after the timed region (`class_timing_steps`)
+    steps = line["warmup"] + line["steps"] + line["class_timing_steps"]
     out["bench_line"] = {k: line[k] for k in ("value", "ms_per_step", "steps", "warmup")}
 out["steps_in_trace"] = steps
 json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
