@@ -174,8 +174,11 @@ def cpu_model() -> str:
     return "unknown CPU"
 
 
+CPU_SHARE_PER_GPU = 16  # host cores of the GPU node per GPU (8 GPUs on 2 x 64 cores)
+
+
 def host_cores() -> int:
-    """Physical cores this process may run on (the GPU box gives one GPU's share of the node's cores)."""
+    """Physical cores this process may run on."""
     allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         import psutil
@@ -186,10 +189,14 @@ def host_cores() -> int:
     return max(1, min(allowed, physical))
 
 
-def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 10):
+def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 10, threads: int = 0):
     """The reference's algorithm on torch CPU (oracle 'port') on a bounded sample of the workload, by the
-    protocol of BASELINE.md section 3: all physical cores this process may use, >= 10 timed front-end batches
-    and 1 untimed + >= 3 timed train steps, medians; frames/s = B_cpu / (front end + step).
+    protocol of BASELINE.md section 3: >= 10 timed front-end batches and 1 untimed + >= 3 timed train steps,
+    medians; frames/s = B_cpu / (front end + step).  Threads: `threads`, default one GPU's share of the node's
+    physical cores (16 of 128 on the MI355X box -- the job is one of eight per node).  All 128 cores were
+    measured SLOWER on this workload (round 3, B = 1: front end 20.5 s against 2.6 s per frame with 16 threads --
+    16 383 pad / conv1d / Welford node updates on tensors of 24-11 036 floats are bound by per-op overhead, which
+    grows with the thread-pool size; `--cpu-threads 0` uses every physical core).
 
     Front end: batches of `frames` full frames through the per-node pad + conv1d recursion with the per-node
     Welford updates left on, as the reference runs it (wavelet_math.py:182-206), + log + normalise.
@@ -203,7 +210,8 @@ def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 1
     from oracle import torch_ref, wpt_oracle
 
     transform, wavelet, scales, add, kind = WORKLOADS[workload][:5]
-    cores = host_cores()
+    physical = host_cores()
+    cores = physical if threads == 0 else max(1, min(threads, physical))
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(99)
     x = (0.1 * torch.randn(frames, 1, 22050, generator=g)).clamp_(-1, 1)
@@ -226,7 +234,8 @@ def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 1
     t_fe = statistics.median(fe_times)
     log(f"cpu baseline: front end {t_fe:.2f} s per batch of {frames} frame(s) ({cores} threads, {fe_batches} batches)")
     sample = (f"B = {frames} of 128 frames of the same workload on {cpu_model()}, {cores} torch threads "
-              f"(= the physical cores this process may use; os.cpu_count() = {os.cpu_count()}): front end "
+              f"(one GPU's share of the host's {physical} physical cores; all {physical} measured slower, "
+              f"see bench.py cpu_baseline): front end "
               f"{t_fe:.2f} s per batch (median of {fe_batches} timed batches; per-node pad+conv1d recursion, "
               f"Welford on)")
     total = t_fe
@@ -324,6 +333,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default 128; 4096 for haar-l14-frontend)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
     ap.add_argument("--cpu-frames", type=int, default=1, help="CPU baseline batch, B_cpu of 128 frames (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=CPU_SHARE_PER_GPU,
+                    help="torch threads of the CPU baseline (0 = every physical core)")
     ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through a child torch.distributed.run even for --gpus 1")
@@ -332,7 +343,7 @@ def main() -> None:
     kind = WORKLOADS[a.workload][4]
 
     if a.cpu_only:
-        print(json.dumps(cpu_baseline(a.workload, max(1, a.cpu_frames))), flush=True)
+        print(json.dumps(cpu_baseline(a.workload, max(1, a.cpu_frames), threads=a.cpu_threads)), flush=True)
         return
     launched = "WORLD_SIZE" in os.environ  # under torch.distributed.run (the driver's N > 1 form)
     if not launched and (a.gpus > 1 or a.spawn):
@@ -457,7 +468,7 @@ def main() -> None:
     cpu = None
     log(f"kernel classes (ms/step): { {k: round(v['ms_per_step'], 3) for k, v in classes.items()} }")
     if rank == 0 and world == 1 and a.cpu_frames > 0 and kind != "eval":
-        cpu = cpu_baseline(a.workload, a.cpu_frames)
+        cpu = cpu_baseline(a.workload, a.cpu_frames, threads=a.cpu_threads)
         log(f"cpu baseline: {cpu['value']:.4f} frames/s")
 
     devices = [torch.cuda.get_device_name(device)]

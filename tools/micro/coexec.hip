@@ -21,7 +21,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int KS = 22;
 
-enum Role { R_NONE = 0, R_M, R_E, R_V, R_S, R_P, R_F };
+enum Role { R_NONE = 0, R_M, R_E, R_V, R_S, R_P, R_F, R_M2 };
 
 __device__ __forceinline__ void quad_transpose4(float& v0, float& v1, float& v2, float& v3, int lane) {
     const bool b0 = lane & 1, b1 = lane & 2;
@@ -76,6 +76,17 @@ struct Window {
             w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
         }
     }
+    // the same dot product as 24 plain v_fma_f32 in two chains (inline asm: hipcc -O3 SLP-packs fmaf pairs)
+    template <int O>
+    __device__ __forceinline__ float dot_scalar(const float* taps) const {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int t = 0; t < L / 2; ++t) {
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a0) : "v"(w[2 * t + 2 * O]), "s"(taps[2 * t]));
+            asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a1) : "v"(w[2 * t + 1 + 2 * O]), "s"(taps[2 * t + 1]));
+        }
+        return a0 + a1;
+    }
     template <int O>
     __device__ __forceinline__ float dot(const float* taps) const {
         f2 acc = {0.f, 0.f};
@@ -91,9 +102,10 @@ struct Window {
 
 struct Taps { float lo[24], hi[24]; };
 
-template <int ROLE_A, int ROLE_B>
+template <int ROLE_A, int ROLE_B, int PRIO_B = 0, bool SCALAR_FMA = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k(const float* __restrict__ tab, float* __restrict__ out, int tiles, size_t wave_stride, const Taps tp) {
+k(const float* __restrict__ tab, float* __restrict__ out, int tiles, size_t wave_stride, const Taps tp,
+  unsigned long long* __restrict__ stamps) {
     __shared__ __attribute__((aligned(16))) float lds[8 * 2048];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -101,6 +113,10 @@ k(const float* __restrict__ tab, float* __restrict__ out, int tiles, size_t wave
     for (int i = threadIdx.x; i < 8 * 2048; i += 512) lds[i] = tab[i & 4095];
     __syncthreads();
     if (role == R_NONE) return;
+    if (PRIO_B > 0 && wave >= 4) __builtin_amdgcn_s_setprio(PRIO_B);
+    // diagnostic stamps (their own buffer; no output depends on them): shader clock, 100 MHz wall clock, HW_ID
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | 4);
     float* o = out + ((size_t)blockIdx.x * 8 + wave) * wave_stride;
     const float eps = 1e-12f, k1 = 0.69314718f, k0 = 0.1f;
     if (role == R_M || role == R_F) {
@@ -118,6 +134,23 @@ k(const float* __restrict__ tab, float* __restrict__ out, int tiles, size_t wave
             } else {
                 asm volatile("" ::"v"(acc));
             }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else if (role == R_M2) {
+        // two independent accumulator chains interleaved in one wave (half the tiles each pass does two)
+        float a[KS], b[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) { a[s] = tab[s * 64 + lane]; b[s] = tab[(KS + s) * 64 + lane]; }
+        for (int t = 0; t < tiles; t += 2) {
+            f16v acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b[s], a[s], acc1, 0, 0, 0);
+            }
+            asm volatile("" ::"v"(acc0), "v"(acc1));
             __builtin_amdgcn_sched_barrier(0);
         }
     } else if (role == R_E || role == R_V || role == R_S) {
@@ -139,28 +172,40 @@ k(const float* __restrict__ tab, float* __restrict__ out, int tiles, size_t wave
             for (int it = 0; it < 4; ++it) {
                 Window<24> win;
                 win.load(mine + 4 * lane + 64 * it);
-                const float ca0 = win.dot<0>(tp.lo), cd0 = win.dot<0>(tp.hi);
-                const float ca1 = win.dot<1>(tp.lo), cd1 = win.dot<1>(tp.hi);
+                const float ca0 = SCALAR_FMA ? win.dot_scalar<0>(tp.lo) : win.dot<0>(tp.lo);
+                const float cd0 = SCALAR_FMA ? win.dot_scalar<0>(tp.hi) : win.dot<0>(tp.hi);
+                const float ca1 = SCALAR_FMA ? win.dot_scalar<1>(tp.lo) : win.dot<1>(tp.lo);
+                const float cd1 = SCALAR_FMA ? win.dot_scalar<1>(tp.hi) : win.dot<1>(tp.hi);
                 *reinterpret_cast<f2*>(mine + 1024 + 2 * lane + 128 * (it & 1)) = f2{ca0, ca1};
                 *reinterpret_cast<f2*>(mine + 1024 + 512 + 2 * lane + 128 * (it & 1)) = f2{cd0, cd1};
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (lane == 0) {
+        unsigned long long* st = stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+        st[0] = __builtin_amdgcn_s_memtime() - t0;
+        st[1] = __builtin_amdgcn_s_memrealtime() - r0;
+        st[2] = hwid;
+        st[3] = role;
+    }
 }
 
-template <int A, int B>
+template <int A, int B, int PRIO_B = 0, bool SCALAR_FMA = false>
 double run(const char* name, const float* tab, float* out, int tiles, size_t wave_stride, double mfma_waves, double epi_waves) {
     Taps tp;
     for (int i = 0; i < 24; ++i) { tp.lo[i] = 0.01f * (i + 1); tp.hi[i] = (i & 1) ? -0.02f * i : 0.02f * i; }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<A, B>), dim3(256), dim3(512), 0, 0, tab, out, 8, wave_stride, tp);
+    static unsigned long long* stamps = nullptr;
+    if (!stamps) (void)hipMalloc(&stamps, 256 * 8 * 4 * 8);
+    (void)hipMemset(stamps, 0, 256 * 8 * 4 * 8);
+    hipLaunchKernelGGL((k<A, B, PRIO_B, SCALAR_FMA>), dim3(256), dim3(512), 0, 0, tab, out, 8, wave_stride, tp, stamps);
     (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL((k<A, B>), dim3(256), dim3(512), 0, 0, tab, out, tiles, wave_stride, tp);
+        hipLaunchKernelGGL((k<A, B, PRIO_B, SCALAR_FMA>), dim3(256), dim3(512), 0, 0, tab, out, tiles, wave_stride, tp, stamps);
         (void)hipEventRecord(e1);
         (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -171,6 +216,29 @@ double run(const char* name, const float* tab, float* out, int tiles, size_t wav
     if (mfma_waves > 0) printf("  matrix: %5.1f cyc/MFMA/SIMD @2.4GHz", best * 1e-3 * 2.4e9 / (tiles * KS * mfma_waves / 4.0));
     if (epi_waves > 0) printf("  stores: %5.2f TB/s", 256.0 * epi_waves * tiles * 4096.0 / (best * 1e-3) / 1e12);
     printf("\n");
+    {
+        static unsigned long long h[256 * 8 * 4];
+        (void)hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+        // block 0's waves: SIMD of each wave, shader cycles per tile, clock = cycles / wall
+        printf("      block 0:");
+        for (int w = 0; w < 8; ++w) {
+            const unsigned long long* st = h + w * 4;
+            if (!st[3]) { printf(" [w%d -]", w); continue; }
+            printf(" [w%d simd%llu cu%llu %.0f cyc/tile %.2f GHz]", w, (st[2] >> 4) & 3, (st[2] >> 8) & 15,
+                   (double)st[0] / tiles, st[1] ? (double)st[0] / (double)st[1] * 0.1 : 0.0);
+        }
+        // distinct (se, sh, cu) triples over all blocks = CUs in use
+        int used = 0; static bool seen[1 << 16];
+        for (int i = 0; i < (1 << 16); ++i) seen[i] = false;
+        for (int b = 0; b < 256; ++b)
+            for (int w = 0; w < 8; ++w) {
+                const unsigned long long* st = h + ((size_t)b * 8 + w) * 4;
+                if (!st[3]) continue;
+                const unsigned key = (unsigned)((st[2] >> 8) & 0xFF) | (unsigned)(b % 8) << 8;  // cu/sh/se bits + XCD slot
+                if (!seen[key]) { seen[key] = true; ++used; }
+            }
+        printf("  distinct CUs (by HW_ID bits 8-15 x XCD slot): %d\n", used);
+    }
     return best;
 }
 
@@ -188,6 +256,8 @@ int main(int argc, char** argv) {
     printf("tiles per wave %d; a tile = 22 MFMA 32x32x2 f32 (1408 cycles at the pipe rate) / 16 outputs per lane\n", tiles);
     run<R_M, R_NONE>("M  -   matrix, 1 wave/SIMD", tab, out, tiles, wave_stride, 4, 0);
     run<R_M, R_M>("M  M   matrix, 2 waves/SIMD", tab, out, tiles, wave_stride, 8, 0);
+    run<R_M2, R_NONE>("M2 -   matrix, 2 chains in 1 wave", tab, out, tiles, wave_stride, 4, 0);
+    run<R_M2, R_M2>("M2 M2  2 chains x 2 waves/SIMD", tab, out, tiles, wave_stride, 8, 0);
     run<R_NONE, R_E>("-  E   epilogue, 1 wave/SIMD", tab, out, tiles, wave_stride, 0, 4);
     run<R_E, R_E>("E  E   epilogue, 2 waves/SIMD", tab, out, tiles, wave_stride, 0, 8);
     run<R_NONE, R_V>("-  V   epilogue arithmetic only", tab, out, tiles, wave_stride, 0, 0);
@@ -201,5 +271,16 @@ int main(int argc, char** argv) {
     run<R_NONE, R_P>("-  P   packed FMA, 1 wave/SIMD", tab, out, tiles, wave_stride, 0, 0);
     run<R_P, R_P>("P  P   packed FMA, 2 waves/SIMD", tab, out, tiles, wave_stride, 0, 0);
     run<R_M, R_P>("M  P   matrix beside packed FMA", tab, out, tiles, wave_stride, 4, 0);
+    printf("-- waves 4-7 at s_setprio 3 --\n");
+    run<R_M, R_E, 3>("M  E^  matrix beside epilogue", tab, out, tiles, wave_stride, 4, 4);
+    run<R_M, R_V, 3>("M  V^  matrix beside arithmetic", tab, out, tiles, wave_stride, 4, 0);
+    run<R_M, R_S, 3>("M  S^  matrix beside stores", tab, out, tiles, wave_stride, 4, 4);
+    run<R_M, R_M, 3>("M  M^  matrix, 2 waves/SIMD", tab, out, tiles, wave_stride, 8, 0);
+    run<R_F, R_F, 3>("F  F^  fused, 2 waves/SIMD (2x work)", tab, out, tiles, wave_stride, 8, 8);
+    run<R_M, R_P, 3>("M  P^  matrix beside packed FMA", tab, out, tiles, wave_stride, 4, 0);
+    printf("-- plain v_fma_f32 instead of v_pk_fma_f32 --\n");
+    run<R_NONE, R_P, 0, true>("-  Ps  scalar FMA, 1 wave/SIMD", tab, out, tiles, wave_stride, 0, 0);
+    run<R_P, R_P, 0, true>("Ps Ps  scalar FMA, 2 waves/SIMD", tab, out, tiles, wave_stride, 0, 0);
+    run<R_M, R_P, 3, true>("M  Ps^ matrix beside scalar FMA", tab, out, tiles, wave_stride, 4, 0);
     return 0;
 }
