@@ -51,11 +51,13 @@ struct HaarParams {
     float scale2, k1, k0;  // scale^2; ln 2 / std (or scale / std without the log); -mean / std
 };
 
-// (1/sqrt 2)^14 scale, log(v^2 + eps) and (x - mean) / std in three instructions per coefficient:
-// log2((v s^2) v + eps) * (ln 2 / std) - mean / std -- the kernel is bound by its vector instructions
-// (75 % issue occupancy measured), not by HBM
+// (1/sqrt 2)^14 scale, log(v^2 + eps) and (x - mean) / std in three instructions per coefficient.  With
+// s^2 = 2^-14 exactly, log((v s)^2 + eps) = ln 2 (log2(v v + eps 2^14) - 14): one FMA, v_log_f32, one FMA with
+// k0 = -mean / std - 14 k1 (the kernel is bound by its vector instructions, not by HBM; the epilogue mode is a
+// template parameter so that no per-element select is left)
+template <bool LOG>
 __device__ __forceinline__ float haar_epilogue(float v, const HaarParams& p) {
-    if (p.flags & AFD_WPT_LOG) return fmaf(__builtin_amdgcn_logf(fmaf(v * p.scale2, v, p.eps)), p.k1, p.k0);
+    if (LOG) return fmaf(__builtin_amdgcn_logf(fmaf(v, v, p.eps)), p.k1, p.k0);
     return fmaf(v, p.k1, p.k0);
 }
 
@@ -87,30 +89,32 @@ struct Sub<2, POS> {
     }
 };
 
-// v = four float4 per lane; on return float4 k of lane q (inside its quad) is what float4 q of
-// lane k was.  Two exchange stages (lane ^ 1, lane ^ 2) over DPP quad permutes.
-template <int S>
-__device__ __forceinline__ void quad_exchange(float& keep0, float& keep1, bool hi) {
-    // lanes with the bit clear hand over register j1 and take the partner's j0; the others
-    // hand over j0 and take j1
-    const float send = hi ? keep0 : keep1;
-    constexpr int ctrl = (S == 1) ? 0xB1 : 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
-    const float recv = __builtin_bit_cast(
-        float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, send), ctrl, 0xF, 0xF, true));
-    if (hi) keep0 = recv; else keep1 = recv;
+// v = four float4 per lane.  4 x 4 transpose of float4s among the lanes {l, l + 16, l + 32, l + 48} of a wave
+// (l = lane & 15, k = lane >> 4): on return float4 j of lane (l, k) is what float4 k of lane (l, j) was.
+// gfx950's v_permlane16_swap_b32 exchanges the odd 16-lane rows of its first operand with the even rows of its
+// second -- a 2 x 2 block exchange between lanes 16 apart in ONE instruction, no select and no DPP wait states
+// (the quad-permute form of round 2 took a v_mov_dpp, three v_cndmask and s_nops per exchange);
+// v_permlane32_swap_b32 does the same between the wave's halves.
+// Inline assembly, not __builtin_amdgcn_permlane16_swap: hipcc 7.2 loses the second result of the builtin when
+// swaps are chained (it stored one register group four times -- tools/micro/pl_chain.hip reproduces it).
+template <int DIST>
+__device__ __forceinline__ void lane_swap(float& a, float& b) {
+    if (DIST == 16) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    else asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
-__device__ __forceinline__ void quad_transpose(float (&v)[16], int lane) {
-    const bool h1 = lane & 1, h2 = lane & 2;
+__device__ __forceinline__ void row_transpose(float (&v)[16]) {
+    // a vector-ALU result read by v_permlane*_swap needs two wait states (the compiler cannot see into the asm)
+    asm volatile("s_nop 1");
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        quad_exchange<1>(v[0 + c], v[4 + c], h1);
-        quad_exchange<1>(v[8 + c], v[12 + c], h1);
+        lane_swap<16>(v[0 + c], v[4 + c]);
+        lane_swap<16>(v[8 + c], v[12 + c]);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        quad_exchange<2>(v[0 + c], v[8 + c], h2);
-        quad_exchange<2>(v[4 + c], v[12 + c], h2);
+        lane_swap<32>(v[0 + c], v[8 + c]);
+        lane_swap<32>(v[4 + c], v[12 + c]);
     }
 }
 
@@ -263,10 +267,11 @@ __device__ __forceinline__ void write_level2(float* buf, int tid, const float2 (
     }
 }
 
+template <bool LOG, bool SIGN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) wpt_haar14_kernel(const HaarParams p) {
     extern __shared__ __attribute__((aligned(16))) float buf[];
     const int tid = threadIdx.x;
-    const bool sign_ch = p.flags & AFD_WPT_SIGN;
+    constexpr bool sign_ch = SIGN;
     const size_t P = 16384;
     const size_t frame_out = (size_t)(sign_ch ? 2 : 1) * 2 * P;
 
@@ -330,24 +335,24 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
         // ---- levels 11-14 in registers, then the thread's 2 x 16 outputs ----
         float out[2][16];
         Sub<22, 0>::run(v10, (lt & 1) ? -1.f : 1.f, out);
-        // A thread's 16 packets of one time row are one 64-byte segment.  Transpose 4 x 4
-        // float4 inside each lane quad, so that a store instruction has the quad write one
-        // whole segment (thread 4m+k's row) instead of four quarter segments.
+        // A thread's 16 packets of one time row are one 64-byte segment.  Transpose 4 x 4 float4 among the
+        // lanes {l, l + 16, l + 32, l + 48}: lane (l, k) then holds quarter k of the segments of threads
+        // 16 j + l (j = register group), so a store instruction writes 16 consecutive whole segments (1 KB).
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            quad_transpose(out[t], lt);
+            row_transpose(out[t]);
         }
-        float* ob = p.out + (size_t)b * frame_out + 8192 * half + 16 * (lt & ~3) + 4 * (lt & 3);
+        float* ob = p.out + (size_t)b * frame_out + 8192 * half + 16 * ((lt & ~63) + (lt & 15)) + 4 * ((lt >> 4) & 3);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float4 r;
-                r.x = haar_epilogue(out[t][4 * k], p);
-                r.y = haar_epilogue(out[t][4 * k + 1], p);
-                r.z = haar_epilogue(out[t][4 * k + 2], p);
-                r.w = haar_epilogue(out[t][4 * k + 3], p);
-                *reinterpret_cast<float4*>(ob + (size_t)t * P + 16 * k) = r;
+                r.x = haar_epilogue<LOG>(out[t][4 * k], p);
+                r.y = haar_epilogue<LOG>(out[t][4 * k + 1], p);
+                r.z = haar_epilogue<LOG>(out[t][4 * k + 2], p);
+                r.w = haar_epilogue<LOG>(out[t][4 * k + 3], p);
+                *reinterpret_cast<float4*>(ob + (size_t)t * P + 256 * k) = r;
             }
         }
         if (sign_ch) {
@@ -360,7 +365,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
                     sgn.y = out[t][4 * k + 1] < 0.f ? p.sgn_neg : p.sgn_pos;
                     sgn.z = out[t][4 * k + 2] < 0.f ? p.sgn_neg : p.sgn_pos;
                     sgn.w = out[t][4 * k + 3] < 0.f ? p.sgn_neg : p.sgn_pos;
-                    *reinterpret_cast<float4*>(ob + (size_t)(2 + t) * P + 16 * k) = sgn;
+                    *reinterpret_cast<float4*>(ob + (size_t)(2 + t) * P + 256 * k) = sgn;
                 }
             }
         }
@@ -381,8 +386,13 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     if (fabsf(dec_lo[0] - s) > 1e-6f || fabsf(dec_lo[1] - s) > 1e-6f) return 1;
     static int n_cu = 0;
     if (!n_cu) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt_haar14_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFloats * 4);
+        hipError_t e = hipSuccess;
+        const void* kerns[4] = {reinterpret_cast<const void*>(&wpt_haar14_kernel<false, false>),
+                                reinterpret_cast<const void*>(&wpt_haar14_kernel<false, true>),
+                                reinterpret_cast<const void*>(&wpt_haar14_kernel<true, false>),
+                                reinterpret_cast<const void*>(&wpt_haar14_kernel<true, true>)};
+        for (const void* kf : kerns)
+            if (e == hipSuccess) e = hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFloats * 4);
         int dev = 0;
         if (e == hipSuccess) e = hipGetDevice(&dev);
         int cus = 0;
@@ -404,9 +414,12 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     {
         const bool norm = flags & AFD_WPT_NORM;
         const double inv = norm ? 1.0 / (double)(std == 0.f ? 1.f : std) : 1.0;
+        const bool lg = flags & AFD_WPT_LOG;
         p.scale2 = p.scale * p.scale;  // exact: a power of two
-        p.k1 = (float)(((flags & AFD_WPT_LOG) ? 0.6931471805599453 : (double)p.scale) * inv);
-        p.k0 = norm ? (float)(-(double)mean * inv) : 0.f;
+        p.eps = lg ? eps * 16384.0f : eps;  // eps / s^2, exact
+        const double k1 = (lg ? 0.6931471805599453 : (double)p.scale) * inv;
+        p.k1 = (float)k1;
+        p.k0 = (float)((norm ? -(double)mean * inv : 0.0) - (lg ? 14.0 * k1 : 0.0));
     }
     afd::ScopedTiming timing(AFD_K_WPT, 4.0 * B * ((double)N + ((flags & AFD_WPT_SIGN) ? 2.0 : 1.0) * 32768.0), stream);
     // two workgroups (frame halves) per CU, 16 per XCD pair up on a frame; the grid is a
@@ -414,7 +427,14 @@ int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L,
     int pairs = B < n_cu ? B : n_cu;
     pairs = (pairs + 7) / 8 * 8;
     const int grid = 2 * pairs;
-    hipLaunchKernelGGL(wpt_haar14_kernel, dim3(grid), dim3(kThreads), (size_t)kLdsFloats * 4, stream, p);
+    const bool lg = flags & AFD_WPT_LOG, sg = flags & AFD_WPT_SIGN;
+    auto launch = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), (size_t)kLdsFloats * 4, stream, p);
+    };
+    if (lg && sg) launch(wpt_haar14_kernel<true, true>);
+    else if (lg) launch(wpt_haar14_kernel<true, false>);
+    else if (sg) launch(wpt_haar14_kernel<false, true>);
+    else launch(wpt_haar14_kernel<false, false>);
     return afd::check_launch("wpt_haar14_kernel");
 }
 
