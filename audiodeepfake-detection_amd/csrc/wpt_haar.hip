@@ -230,6 +230,7 @@ __device__ __forceinline__ void lds_pass8(float* buf, int tid) {
 template <int R0, int R1>
 __device__ __forceinline__ void load_items(const float* xb, int tid, float2 (&lo)[kLoadItems],
                                            float2 (&hi)[kLoadItems]) {
+    static_assert((kLoadItems - 1) * kThreads < kLen[2] && kLoadItems * kThreads >= kLen[2], "only the last round is ragged");
 #pragma unroll
     for (int r = R0; r < R1; ++r) {
         int i = r * kThreads + tid;
@@ -241,26 +242,39 @@ __device__ __forceinline__ void load_items(const float* xb, int tid, float2 (&lo
     }
 }
 
-// ... and their element i of the level-2 nodes 2h, 2h + 1 (h = level-1 half: 0 low-pass,
-// 1 high-pass)
+// ... and their element i of the level-2 nodes 2h, 2h + 1 (h = level-1 half: 0 low-pass, 1 high-pass;
+// s = +1 / -1 is uniform over the workgroup).  Only this half's level-1 child is formed: a = x0 + s x1,
+// a' = x2 + s x3, then (a + s a', a - s a') -- the children of an odd-frequency node come (difference, sum).
+template <int R0, int R1, int H>
+__device__ __forceinline__ void level2_items_h(const float2 (&lo)[kLoadItems], const float2 (&hi)[kLoadItems],
+                                               int tid, float2 (&g)[kLoadItems]) {
+    constexpr float s = H ? -1.f : 1.f;
+#pragma unroll
+    for (int r = R0; r < R1; ++r) {
+        float2 p0 = lo[r], p1 = hi[r];
+        if (r == kLoadItems - 1) {
+            const bool tail = r * kThreads + tid == kLen[2] - 1;
+            p0 = tail ? hi[r] : lo[r];
+            p1 = tail ? lo[r] : hi[r];
+        }
+        const float a0 = fmaf(s, p0.y, p0.x), a1 = fmaf(s, p1.y, p1.x);
+        g[r] = make_float2(fmaf(s, a1, a0), fmaf(-s, a1, a0));
+    }
+}
+
 template <int R0, int R1>
 __device__ __forceinline__ void level2_items(const float2 (&lo)[kLoadItems], const float2 (&hi)[kLoadItems],
                                              int tid, int h, float2 (&g)[kLoadItems]) {
-#pragma unroll
-    for (int r = R0; r < R1; ++r) {
-        const bool tail = r * kThreads + tid == kLen[2] - 1;
-        const float4 v = tail ? make_float4(hi[r].x, hi[r].y, lo[r].x, lo[r].y)
-                              : make_float4(lo[r].x, lo[r].y, hi[r].x, hi[r].y);
-        const float4 f = butterfly4(v, false);
-        g[r] = h ? make_float2(f.z, f.w) : make_float2(f.x, f.y);
-    }
+    // uniform branch: with a literal sign the products fold into adds / subtracts
+    if (h) level2_items_h<R0, R1, 1>(lo, hi, tid, g);
+    else level2_items_h<R0, R1, 0>(lo, hi, tid, g);
 }
 
 __device__ __forceinline__ void write_level2(float* buf, int tid, const float2 (&g)[kLoadItems]) {
 #pragma unroll
     for (int r = 0; r < kLoadItems; ++r) {
         const int i = r * kThreads + tid;
-        if (i < kLen[2]) {
+        if (r < kLoadItems - 1 || i < kLen[2]) {
             buf[i] = g[r].x;
             buf[kCap2 + i] = g[r].y;
         }
@@ -352,7 +366,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4
                 r.y = haar_epilogue<LOG>(out[t][4 * k + 1], p);
                 r.z = haar_epilogue<LOG>(out[t][4 * k + 2], p);
                 r.w = haar_epilogue<LOG>(out[t][4 * k + 3], p);
-                *reinterpret_cast<float4*>(ob + (size_t)t * P + 256 * k) = r;
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v rv = {r.x, r.y, r.z, r.w};
+                __builtin_nontemporal_store(rv, reinterpret_cast<f4v*>(ob + (size_t)t * P + 256 * k));
             }
         }
         if (sign_ch) {
