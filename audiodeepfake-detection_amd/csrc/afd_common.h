@@ -104,6 +104,13 @@ size_t wino16_workspace_bytes(int Cin, int Cout);
 int wino16_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s);
 
+// wino44_wgrad.hip: 3x3 / pad 1 backward-weight in the Winograd F(4x4, 3x3) domain
+bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
+bool wino44_wgrad_crop_ok(int H, int W, int dy_rows, int dy_cols);
+size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols);
+int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
+                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s);
+
 bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int dz_cols, int* S,
                        int* nchunks, int* CI_T, int* CO_PAD, int* NCOL);

@@ -819,6 +819,14 @@ bool wgrad_swap_applicable(int Cin, int H, int W, int Cout, int K, int pad, int 
     return afd::wgrad3x3_applicable(Cout, H, W, Cin, K, pad, dil);
 }
 
+// The Winograd-domain backward-weight (wino44_wgrad.hip) where it is the faster form: the wide level-14 images
+// (measured, round 3); AFD_WINO44_WGRAD=1 sends every applicable 3x3 layer there.
+bool wino_wgrad_pays(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
+    if (!afd::wino44_wgrad_applicable(Cin, H, W, Cout, K, pad, dil)) return false;
+    if (getenv("AFD_WINO44_WGRAD")) return true;
+    return W >= 256;
+}
+
 int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int pad, int dil) {
     ConvGeom& g = wg.c;
     const int Hout = H + 2 * pad - dil * (K - 1);
@@ -1357,6 +1365,11 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(((size_t)S3 * nch3 * cop3 * ncol3 + (size_t)S3 * cop3) * 4);
         if (b > need) need = b;
     }
+    if (wino_wgrad_pays(Cin, H, W, Cout, K, pad, dil)) {
+        // (the split count does not grow when the caller crops dy)
+        const size_t b = align_up(afd::wino44_wgrad_workspace_floats(N, Cin, H, W, Cout, Hout, Wout) * 4);
+        if (b > need) need = b;
+    }
     if (wgrad_swap_applicable(Cin, H, W, Cout, K, pad, dil, Hout, Wout)) {
         int S3, nch3, ct3, cop3, ncol3;
         afd::wgrad3x3_geometry(N, Cout, H, W, Cin, H, W, &S3, &nch3, &ct3, &cop3, &ncol3);
@@ -1540,6 +1553,17 @@ extern "C" int afd_conv2d_backward_weight_sums(const float* x, const float* dy, 
         return afd::conv1x1_backward_weight(x, dy, dw, dbias, N, Cin, Cout, (long)H * W, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (wino_wgrad_pays(Cin, H, W, Cout, K, pad, dil) && afd::wino44_wgrad_crop_ok(H, W, dy_rows, dy_cols)) {
+        // the bias gradient: from the producer of dy when the caller has its sums, else from the dy-transform lanes
+        rc = afd::wino44_wgrad_run(x, dy, dw, (dbias && !dy_sums) ? dbias : nullptr, N, Cin, H, W, Cout, dy_rows, dy_cols,
+                                   ws, ws_bytes, s);
+        if (rc) return rc;
+        if (dbias && dy_sums) {
+            hipLaunchKernelGGL(bias_from_sums_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, dy_sums, dbias, Cout);
+            return afd::check_launch("bias_from_sums_kernel");
+        }
+        return AFD_OK;
+    }
     if (wgrad_swap_applicable(Cin, H, W, Cout, K, pad, dil, dy_rows, dy_cols)) {
         int S3, nch3, ct3, cop3, ncol3;
         afd::wgrad3x3_geometry(N, Cout, H, W, Cin, H, W, &S3, &nch3, &ct3, &cop3, &ncol3);

@@ -1,0 +1,505 @@
+// Backward-weight of the 3x3 / pad 1 convolutions in the Winograd F(4x4, 3x3) domain on the f32 MFMA.
+//
+// Reference: the cuDNN backward-filter launches behind nn.Conv2d(k=3, padding=1) of DCNN blocks 3-6
+// (src/audiofakedetect/models.py:263-276).
+//
+// With the forward's matrices (wino44.hip: Y = A^T [(G g G^T) . (B^T d B)] A per 4x4 output tile),
+//     dW[co][ci] = G^T [ sum over tiles  (A dY_tile A^T) . (B^T X_tile B) ] G        (. = element-wise, 6x6)
+// so per transform position p (36 of them) the sum over tiles is a GEMM  M_p[co][ci] = sum_t DY_p[co][t] X_p[ci][t]
+// with K = the 4x4 tiles of the batch: 36 MACs per (co, ci, tile) = 2.25 per output pixel against 9 in direct form.
+//
+//   wave      = one 16 (co) x 16 (ci) block of all 36 positions on v_mfma_f32_16x16x4_f32: 144 accumulator
+//               registers; a k-step is 4 tiles, lane = (channel = lane & 15, tile = lane >> 4) for both operands
+//   workgroup = 8 waves = COB x CIB blocks (2 x 4: 32 co x 64 ci, or 4 x 2: 64 co x 32 ci), one per CU
+//   round     = 2 k-steps (8 tiles).  Transform phase: the 2 (COB + CIB) operand sets of the round (a set = one
+//               16-channel block of one k-step: 64 (channel, tile) pairs, one per lane) are dealt over the waves
+//               -- every wave transforms at most one x patch (B^T d B, 6x6 from 6 rows x 24 bytes) and one dy tile
+//               (A dy A^T, 4x4 -> 6x6) -- and written to LDS as [set][position group of 4][lane][4]: the
+//               producer's lane layout IS the MFMA operand layout, so a consumer reads its own lane's 16 bytes.
+//               Matrix phase: per k-step and position group one ds_read_b128 per operand, four MFMAs.
+//               110 KB of LDS, single-buffered (f32 matrix instructions and vector instructions do not overlap on
+//               a SIMD -- tools/micro/coexec.hip -- so running the phases back to back costs nothing extra);
+//               the next round's patches are requested from memory before the matrix phase.
+//   grid      = (channel groups) x S splits of the tile sequence (n, column group, tile row), tile row fastest so
+//               that consecutive k-steps share their two halo rows in L1 / L2; every workgroup writes its partial
+//               M [36][co][ci] to a slab; wino44_wgrad_reduce_kernel sums the splits (fixed order: deterministic)
+//               and wino44_wgrad_g_kernel applies G^T . G.
+// Bias gradient: the dy-transform lanes also sum their 16 values; one partial per split (channel group 0 only).
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+constexpr int kPos = 36;
+constexpr int kSetFloats = 9 * 64 * 4;  // one operand set: [position group][lane][4]
+constexpr int kThreadsW = 512;
+
+struct GW {
+    int N, Cin, Cout, H, W;
+    int rows, cols;             // valid region of dy (a crop of H x W)
+    int tilesX, tilesY, groupsX;  // groupsX = k-step groups (4 tiles) per tile row
+    long units;                 // N * groupsX * tilesY k-steps, ordered (n, column group, tile row)
+    int S;                      // splits of the unit sequence
+    long units_per_split;       // even
+    int cig;                    // channel groups along Cin
+    float* slab;                // [S][36][Cout][Cin]
+    float* partb;               // [S][Cout] (bias partials) or null
+};
+
+// B^T d along one axis (wino44.hip)
+__device__ __forceinline__ void bt6w(const float d0, const float d1, const float d2, const float d3, const float d4,
+                                     const float d5, float* t) {
+    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
+    const float c = d4 - d2, e = d3 - d1;
+    t[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+    t[1] = a + b;
+    t[2] = a - b;
+    t[3] = fmaf(2.f, e, c);
+    t[4] = fmaf(-2.f, e, c);
+    t[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+}
+
+// A y along one axis: A = (A^T)^T of wino44.hip's at6, rows [1 0 0 0], [1 1 1 1], [1 -1 1 -1], [1 2 4 8],
+// [1 -2 4 -8], [0 0 0 1]
+__device__ __forceinline__ void a6w(const float y0, const float y1, const float y2, const float y3, float* t) {
+    const float s02 = y0 + y2, s13 = y1 + y3;
+    const float e = fmaf(4.f, y2, y0), o = fmaf(4.f, y3, y1);
+    t[0] = y0;
+    t[1] = s02 + s13;
+    t[2] = s02 - s13;
+    t[3] = fmaf(2.f, o, e);
+    t[4] = fmaf(-2.f, o, e);
+    t[5] = y3;
+}
+
+struct Unit {
+    int n, xg, ty;
+    bool live;
+};
+
+// (uniform arguments: the compiler keeps the result in scalar registers; units < 2^31, checked by the host)
+__device__ __forceinline__ Unit decode_unit(long u, long end, const GW& g) {
+    Unit r;
+    r.live = u < end;
+    const unsigned uu = r.live ? (unsigned)u : 0u;
+    const unsigned q = uu / (unsigned)g.tilesY;
+    r.ty = (int)(uu - q * (unsigned)g.tilesY);
+    const unsigned n = q / (unsigned)g.groupsX;
+    r.xg = (int)(q - n * (unsigned)g.groupsX);
+    r.n = (int)n;
+    return r;
+}
+
+template <int COB, int CIB>
+__global__ void __launch_bounds__(kThreadsW) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dy) {
+    static_assert(COB * CIB == 8, "eight waves");
+    extern __shared__ __attribute__((aligned(16))) float sets[];  // [2 (CIB + COB)][9][64][4]
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = wave / CIB, wb = wave % CIB;  // this wave's (co block, ci block)
+    const int cgroups = g.cig * (g.Cout / (16 * COB));
+    const int cg = blockIdx.x % cgroups;
+    const int split = blockIdx.x / cgroups;
+    const int co0 = (cg / g.cig) * 16 * COB, ci0 = (cg % g.cig) * 16 * CIB;
+    const long u_begin = (long)split * g.units_per_split;
+    long u_end = u_begin + g.units_per_split;
+    u_end = u_end < g.units ? u_end : g.units;
+
+    // transform jobs of this wave: at most one x patch set and one dy tile set per round
+    //   2 x 4: x sets 8 (every wave: block w & 3 of k-step w >> 2), dy sets 4 (waves 4-7: block (w - 4) & 1 of k-step (w - 4) >> 1)
+    //   4 x 2: x sets 4 (waves 0-3: block w & 1 of k-step w >> 1), dy sets 8 (every wave: block w & 3 of k-step w >> 2)
+    constexpr bool kAllX = CIB == 4;
+    const bool has_x = kAllX || wave < 4;
+    const bool has_d = !kAllX || wave >= 4;
+    const int xb = kAllX ? (wave & 3) : (wave & 1), xks = kAllX ? (wave >> 2) : (wave >> 1);
+    const int db_ = kAllX ? ((wave - 4) & 1) : (wave & 3), dks = kAllX ? ((wave - 4) >> 1) : (wave >> 2);
+    // set indices: x sets [ks][b] first, then dy sets [ks][a]
+    float* my_xset = sets + (size_t)(xks * CIB + xb) * kSetFloats + lane * 4;
+    float* my_dset = sets + (size_t)(2 * CIB + dks * COB + db_) * kSetFloats + lane * 4;
+
+    const int lc = lane & 15, lt = lane >> 4;
+    const size_t plane = (size_t)g.H * g.W;
+    // every address is (uniform part: image, channel block, row, column group) + one loop-invariant lane offset
+    // (channel lc of the block, tile lt of the k-step): scalar registers do the bookkeeping
+    const unsigned loff = (unsigned)lc * (unsigned)plane + 4u * (unsigned)lt;
+    const float* xblk = x + (size_t)(ci0 + 16 * xb) * plane;    // + n * Cin * plane
+    const float* dblk = dy + (size_t)(co0 + 16 * db_) * plane;  // + n * Cout * plane
+
+    float d[6][6];   // x patch of the coming round
+    float e[4][4];   // dy tile of the coming round
+    bool x_edge = false, d_edge = false;
+    Unit ux{}, ud{};
+    // Image borders.  Rows: a patch row outside the image is loaded from a clamped (valid) row and zeroed before
+    // the transform -- per row and uniform over the wave.  Columns: only the first column group holds a patch
+    // that starts one column left of the image, and (the host checks 4 tilesX <= W) a patch can pass the right
+    // border by one column at most; in those groups (uniform branch) the two loads of a row start one column
+    // in / one column early and the six values are picked by lane selects.  Tiles past tilesX (ragged last
+    // group) read tile 0 of their group and are zeroed.
+    auto load_x = [&](long u0) {
+        ux = decode_unit(u0 + xks, u_end, g);
+        const int iy0 = 4 * ux.ty - 1;
+        x_edge = ux.xg == 0 || 16 * ux.xg + 17 > g.W || 4 * ux.xg + 3 >= g.tilesX;
+        const float* xc = xblk + (size_t)ux.n * g.Cin * plane + (16 * ux.xg - 1);
+        if (!x_edge) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iy = iy0 + r;
+                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+                const float* row = xc + (size_t)iyc * g.W;  // uniform
+                const f4u v = *reinterpret_cast<const f4u*>(row + loff);
+                const f2u w2 = *reinterpret_cast<const f2u*>(row + loff + 4);
+                d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w; d[r][4] = w2.x; d[r][5] = w2.y;
+            }
+        } else {
+            const int tx = 4 * ux.xg + lt;
+            const bool tile_ok = tx < g.tilesX;
+            const int ix0 = tile_ok ? 4 * tx - 1 : 16 * ux.xg - 1;
+            const bool L = ix0 < 0, R = ix0 + 5 >= g.W;
+            const unsigned o1 = (unsigned)lc * (unsigned)plane + (unsigned)(ix0 - (16 * ux.xg - 1) + (L ? 1 : 0));
+            const unsigned o2 = (unsigned)lc * (unsigned)plane + (unsigned)(ix0 - (16 * ux.xg - 1) + 4 - (R ? 1 : 0));
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iy = iy0 + r;
+                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+                const float* row = xc + (size_t)iyc * g.W;
+                const f4u v = *reinterpret_cast<const f4u*>(row + o1);
+                const f2u w2 = *reinterpret_cast<const f2u*>(row + o2);
+                d[r][0] = L ? 0.f : v.x;
+                d[r][1] = L ? v.x : v.y;
+                d[r][2] = L ? v.y : v.z;
+                d[r][3] = L ? v.z : v.w;
+                d[r][4] = R ? w2.y : w2.x;
+                d[r][5] = R ? 0.f : w2.y;
+                if (!tile_ok) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) d[r][j] = 0.f;
+                }
+            }
+        }
+    };
+    auto load_d = [&](long u0) {
+        ud = decode_unit(u0 + dks, u_end, g);
+        const int oy0 = 4 * ud.ty;
+        d_edge = 16 * ud.xg + 16 > g.cols;
+        const float* dc = dblk + (size_t)ud.n * g.Cout * plane + 16 * ud.xg;
+        if (!d_edge) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oy0 + r < g.H ? oy0 + r : g.H - 1;
+                const float* row = dc + (size_t)oy * g.W;  // uniform
+                const f4u v = *reinterpret_cast<const f4u*>(row + loff);
+                e[r][0] = v.x; e[r][1] = v.y; e[r][2] = v.z; e[r][3] = v.w;
+            }
+        } else {
+            const int tx = 4 * ud.xg + lt;
+            const bool tile_ok = tx < g.tilesX;
+            const unsigned o1 = (unsigned)lc * (unsigned)plane + (tile_ok ? 4u * (unsigned)lt : 0u);
+            const int left = tile_ok ? g.cols - 4 * tx : 0;  // valid columns of this tile
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oy0 + r < g.H ? oy0 + r : g.H - 1;
+                const float* row = dc + (size_t)oy * g.W;
+                const f4u v = *reinterpret_cast<const f4u*>(row + o1);
+                e[r][0] = left > 0 ? v.x : 0.f;
+                e[r][1] = left > 1 ? v.y : 0.f;
+                e[r][2] = left > 2 ? v.z : 0.f;
+                e[r][3] = left > 3 ? v.w : 0.f;
+            }
+        }
+    };
+    float bsum = 0.f;  // bias partial of this lane's channel (dy lanes)
+    auto transform_x = [&]() {
+        const int iy0 = 4 * ux.ty - 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = iy0 + r;
+            if (!ux.live || iy < 0 || iy >= g.H) {  // uniform
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d[r][j] = 0.f;
+            }
+        }
+        float t[6][6];  // t = B^T d
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float o[6];
+            bt6w(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t[r][j] = o[r];
+        }
+        // second pass two rows at a time: 12 positions = three 16-byte stores, so only 12 results are live
+#pragma unroll
+        for (int r2 = 0; r2 < 3; ++r2) {
+            float v[12];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * r2 + h;
+                float o[6];
+                bt6w(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[6 * h + j] = o[j];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<f32x4*>(my_xset + (3 * r2 + q) * 256) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto transform_d = [&](bool want_bias) {
+        const int oy0 = 4 * ud.ty;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!ud.live || oy0 + r >= g.rows) {  // uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[r][j] = 0.f;
+            }
+        }
+        if (want_bias) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += (e[r][0] + e[r][1]) + (e[r][2] + e[r][3]);
+            bsum += s;
+        }
+        float t[6][4];  // t = A e
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float o[6];
+            a6w(e[0][j], e[1][j], e[2][j], e[3][j], o);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t[r][j] = o[r];
+        }
+#pragma unroll
+        for (int r2 = 0; r2 < 3; ++r2) {
+            float v[12];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int r = 2 * r2 + h;
+                float o[6];
+                a6w(t[r][0], t[r][1], t[r][2], t[r][3], o);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v[6 * h + j] = o[j];
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<f32x4*>(my_dset + (3 * r2 + q) * 256) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x4 acc[kPos];
+#pragma unroll
+    for (int p = 0; p < kPos; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const bool want_bias = g.partb != nullptr && (cg % g.cig) == 0;
+    if (has_x) load_x(u_begin);
+    for (long u0 = u_begin; u0 < u_end; u0 += 2) {
+        // the dy tile (four 16-byte loads) is requested here and arrives during the x transform; only the x patch
+        // (36 registers) is held across the matrix phase -- with the dy tile too the kernel spilled
+        if (has_d) load_d(u0);
+        if (has_x) transform_x();
+        if (has_d) transform_d(want_bias);
+        __syncthreads();
+        // the coming round's patch travels during the matrix phase
+        if (has_x && u0 + 2 < u_end) load_x(u0 + 2);
+        // operands of position group pg + 1 are requested before the four matrix instructions of group pg
+        const float* as0 = sets + (size_t)(2 * CIB + wa) * kSetFloats + lane * 4;
+        const float* bs0 = sets + (size_t)wb * kSetFloats + lane * 4;
+        f32x4 av = *reinterpret_cast<const f32x4*>(as0), bv = *reinterpret_cast<const f32x4*>(bs0);
+#pragma unroll
+        for (int it = 0; it < 18; ++it) {
+            const int ks = it / 9, pg = it % 9;
+            f32x4 an = av, bn = bv;
+            if (it + 1 < 18) {
+                const int ks1 = (it + 1) / 9, pg1 = (it + 1) % 9;
+                an = *reinterpret_cast<const f32x4*>(as0 + (size_t)ks1 * COB * kSetFloats + pg1 * 256);
+                bn = *reinterpret_cast<const f32x4*>(bs0 + (size_t)ks1 * CIB * kSetFloats + pg1 * 256);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[4 * pg + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[4 * pg + q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            av = an;
+            bv = bn;
+            (void)ks;
+        }
+        __syncthreads();
+    }
+
+    // partial M of this workgroup: acc[p][j] = M_p[co0 + 16 wa + 4 (lane >> 4) + j][ci0 + 16 wb + (lane & 15)]
+    float* sl = g.slab + (size_t)split * kPos * g.Cout * g.Cin;
+    const int co = co0 + 16 * wa + 4 * lt, ci = ci0 + 16 * wb + lc;
+#pragma unroll
+    for (int p = 0; p < kPos; ++p)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[((size_t)p * g.Cout + co + j) * g.Cin + ci] = acc[p][j];
+    if (want_bias && has_d) {
+        // this wave summed dy over the tiles (lane >> 4) of its k-steps for channel lane & 15 of block db_;
+        // the partials of the waves holding the same block (other k-step) are added by the reduce kernel
+        float s = bsum;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        if (lt == 0) g.partb[((size_t)split * 2 + dks) * g.Cout + co0 + 16 * db_ + lc] = s;
+    }
+}
+
+// sum of the S partial slabs, element-wise: red[i] = sum_s slab[s][i], i over 36 * Cout * Cin (fixed order)
+__global__ void __launch_bounds__(256) wino44_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ red,
+                                                                  long total, int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < S; s += 4) {
+        const float v0 = slab[(size_t)s * total + i], v1 = slab[(size_t)(s + 1) * total + i];
+        const float v2 = slab[(size_t)(s + 2) * total + i], v3 = slab[(size_t)(s + 3) * total + i];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; s < S; ++s) a0 += slab[(size_t)s * total + i];
+    red[i] = (a0 + a1) + (a2 + a3);
+}
+
+// dW = G^T M G per (co, ci); G (6x3) of wino44.hip.  Also the bias gradient from the per-split partials.
+__global__ void __launch_bounds__(256) wino44_wgrad_g_kernel(const float* __restrict__ red, const float* __restrict__ partb,
+                                                             float* __restrict__ dw, float* __restrict__ db, int Cout,
+                                                             int Cin, int S2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int pairs = Cout * Cin;
+    if (i < pairs) {
+        float m[6][6];
+#pragma unroll
+        for (int p = 0; p < kPos; ++p) m[p / 6][p % 6] = red[(size_t)p * pairs + i];
+        // t = G^T m (3x6): G^T rows: [1/4 -1/6 -1/6 1/24 1/24 0], [0 -1/6 1/6 1/12 -1/12 0], [0 -1/6 -1/6 1/6 1/6 1]
+        float t[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float s12 = m[1][j] + m[2][j], d12 = m[1][j] - m[2][j];
+            const float s34 = m[3][j] + m[4][j], d34 = m[3][j] - m[4][j];
+            t[0][j] = 0.25f * m[0][j] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+            t[1][j] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+            t[2][j] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + m[5][j];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float s12 = t[r][1] + t[r][2], d12 = t[r][1] - t[r][2];
+            const float s34 = t[r][3] + t[r][4], d34 = t[r][3] - t[r][4];
+            dw[(size_t)i * 9 + r * 3 + 0] = 0.25f * t[r][0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+            dw[(size_t)i * 9 + r * 3 + 1] = -(1.f / 6.f) * d12 + (1.f / 12.f) * d34;
+            dw[(size_t)i * 9 + r * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[r][5];
+        }
+    }
+    if (db && partb && i < Cout) {
+        float a = 0.f;
+        for (int s = 0; s < S2; ++s) a += partb[(size_t)s * Cout + i];
+        db[i] = a;
+    }
+}
+
+int pick_shape(int Cin, int Cout) {
+    if (Cout % 64 == 0 && Cin % 32 == 0) return 42;
+    if (Cout % 32 == 0 && Cin % 64 == 0) return 24;
+    return 0;
+}
+
+void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols) {
+    g.N = N; g.Cin = Cin; g.Cout = Cout; g.H = H; g.W = W;
+    g.rows = dy_rows < H ? dy_rows : H;
+    g.cols = dy_cols < W ? dy_cols : W;
+    g.tilesX = (g.cols + 3) / 4;
+    g.tilesY = (g.rows + 3) / 4;
+    g.groupsX = (g.tilesX + 3) / 4;
+    g.units = (long)N * g.groupsX * g.tilesY;
+    const int shape = pick_shape(Cin, Cout);
+    const int cob = shape / 10, cib = shape % 10;
+    g.cig = Cin / (16 * cib);
+    const int cgroups = g.cig * (Cout / (16 * cob));
+    // about three workgroups per CU in all (one is resident per CU: 110 KB of LDS), at least 16 rounds each
+    long S = 768 / cgroups;
+    const long max_s = g.units / 32 > 0 ? g.units / 32 : 1;
+    S = S < max_s ? S : max_s;
+    S = S < 1 ? 1 : S;
+    long ups = (g.units + S - 1) / S;
+    ups += ups & 1;
+    g.units_per_split = ups;
+    g.S = (int)((g.units + ups - 1) / ups);
+}
+
+}  // namespace
+
+namespace afd {
+
+// the crop of dy decides the right border: a patch may pass it by one column at most (load_x)
+bool wino44_wgrad_crop_ok(int H, int W, int dy_rows, int dy_cols) {
+    const int cols = dy_cols < W ? dy_cols : W;
+    const int rows = dy_rows < H ? dy_rows : H;
+    return rows >= 1 && cols >= 1 && 4 * ((cols + 3) / 4) <= W;
+}
+
+bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
+    if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44_WGRAD")) return false;
+    if (K != 3 || pad != 1 || dil != 1) return false;
+    if (!pick_shape(Cin, Cout)) return false;
+    if (W < 8 || H < 2) return false;
+    return (size_t)H * W * 16 < 0x7fffffffULL;  // 32-bit lane offsets inside a 16-channel block
+}
+
+// floats: S slabs + the reduced M + bias partials
+size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols) {
+    GW g{};
+    plan(g, N, Cin, H, W, Cout, dy_rows, dy_cols);
+    const size_t m = (size_t)kPos * Cout * Cin;
+    return (size_t)g.S * m + m + (size_t)g.S * 2 * Cout;
+}
+
+int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
+                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s) {
+    GW g{};
+    plan(g, N, Cin, H, W, Cout, dy_rows, dy_cols);
+    if (!wino44_wgrad_crop_ok(H, W, dy_rows, dy_cols) || g.units >= 0x7fffffffL)
+        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd backward-weight: image %d x %d, crop %d x %d", H, W, dy_rows, dy_cols);
+    const size_t m = (size_t)kPos * Cout * Cin;
+    if (!ws || ws_bytes < wino44_wgrad_workspace_floats(N, Cin, H, W, Cout, dy_rows, dy_cols) * sizeof(float))
+        return afd::fail(AFD_ERR_WORKSPACE, "winograd backward-weight: workspace too small");
+    g.slab = static_cast<float*>(ws);
+    float* red = g.slab + (size_t)g.S * m;
+    g.partb = dbias ? red + m : nullptr;
+    const int shape = pick_shape(Cin, Cout);
+    const int cgroups = g.cig * (Cout / (16 * (shape / 10)));
+    const size_t lds = (size_t)12 * kSetFloats * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<2, 4>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<4, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd backward-weight: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
+    // 36 GEMMs [Cout x Cin] with K = every tile of every k-step (tile padding included)
+    timing.issued(2.0 * kPos * (double)Cout * Cin * 4.0 * (double)g.units);
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
+    const unsigned grid = (unsigned)(cgroups * g.S);
+    if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+    else hipLaunchKernelGGL((wino44_wgrad_kernel<4, 2>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+    int rc = afd::check_launch("wino44_wgrad_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(wino44_wgrad_reduce_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, g.slab, red, (long)m, g.S);
+    rc = afd::check_launch("wino44_wgrad_reduce_kernel");
+    if (rc) return rc;
+    const int pairs = Cout * Cin;
+    hipLaunchKernelGGL(wino44_wgrad_g_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, red, g.partb, dw, dbias, Cout, Cin,
+                       2 * g.S);
+    return afd::check_launch("wino44_wgrad_g_kernel");
+}
+
+}  // namespace afd

@@ -6,6 +6,8 @@ and backward); tolerances are relative to the largest reference magnitude:
   elementwise / pooling / batch-norm                                 : 1e-5
 """
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -774,3 +776,61 @@ def test_conv_prelu_pool_in_one_launch(shape):
         _close(two, yg.detach().double().cpu(), 2e-5, "one launch against two")
     else:
         assert torch.equal(two, yg.detach())
+
+
+def _issued_class(fn, name):
+    _native.timing_reset()
+    _native.timing_enable(True)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        _native.timing_enable(False)
+    c = _native.timing_collect(name)
+    _native.timing_reset()
+    return out, c
+
+
+@pytest.mark.parametrize("case", [
+    # n, cin, h, w, cout, crop rows, crop cols      (level-14 block shapes at reduced width)
+    (2, 64, 13, 1029, 96, 12, 1028),   # block 3: 2 x 4 blocks, pooled crop, three tile rows, first / last column groups
+    (1, 96, 6, 1024, 128, 6, 1024),    # block 4: 4 x 2 blocks, a half-used second tile row, right border by one column
+    (2, 128, 6, 516, 32, 6, 516),      # block 5: ragged last column group (129 tiles)
+    (3, 32, 6, 260, 64, 6, 260),       # block 6
+    (2, 64, 27, 64, 96, 26, 64),       # a level-8 shape: 16 tiles per row, seven tile rows (one ragged)
+    (1, 64, 3, 1029, 64, 2, 1028),     # the sym5 level-14 geometry: one tile row, two live rows
+])
+@pytest.mark.parametrize("with_sums", [False, True])
+def test_winograd_domain_backward_weight(case, with_sums):
+    """wino44_wgrad.hip: dW = G^T [sum over tiles (A dy A^T) . (B^T x B)] G against float64, 3e-5 of the largest
+    entry (the bar of the direct kernels).  dy holds garbage outside the crop (a pooled layer's odd last row /
+    column): the kernel must not read it into the sums.  The issued-flop count says which kernel ran."""
+    n, cin, h, w, cout, rows, cols = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, cin, h, w, generator=g)
+    dy = torch.randn(n, cout, h, w, generator=g)
+    dyz = torch.zeros_like(dy)
+    dyz[:, :, :rows, :cols] = dy[:, :, :rows, :cols]
+    ref_w = torch.nn.grad.conv2d_weight(x.double(), (cout, cin, 3, 3), dyz.double(), padding=1)
+    ref_b = dyz.double().sum((0, 2, 3))
+    lib = _native.load()
+    xc, dyc = x.cuda(), dy.cuda()
+    dw = torch.empty(cout, cin, 3, 3, device="cuda")
+    db = torch.empty(cout, device="cuda")
+    sums = ref_b.cuda() if with_sums else None
+    ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin, h, w, cout, 3, 1, 1), dtype=torch.uint8, device="cuda")
+    os.environ["AFD_WINO44_WGRAD"] = "1"  # also on the narrow shapes (the default sends only wide images there)
+    try:
+        def run():
+            _native.check(lib.afd_conv2d_backward_weight_sums(
+                _native.ptr(xc), _native.ptr(dyc), _native.ptr(dw), _native.ptr(db), _native.ptr(sums), n, cin, h, w,
+                cout, 3, 1, 1, rows, cols, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "wgrad")
+            return dw
+        _, c = _issued_class(run, "conv_wgrad")
+    finally:
+        os.environ.pop("AFD_WINO44_WGRAD", None)
+    _close(dw, ref_w, 3e-5, "winograd-domain wgrad")
+    _close(db, ref_b, 2e-5, "dbias")
+    groups = -(-(-(-cols // 4)) // 4)
+    assert c["launches"] == 1
+    assert c["issued"] == 2.0 * 36 * cout * cin * 4 * n * groups * -(-rows // 4)
