@@ -819,12 +819,11 @@ bool wgrad_swap_applicable(int Cin, int H, int W, int Cout, int K, int pad, int 
     return afd::wgrad3x3_applicable(Cout, H, W, Cin, K, pad, dil);
 }
 
-// The Winograd-domain backward-weight (wino44_wgrad.hip) where it is the faster form: the wide level-14 images
-// (measured, round 3); AFD_WINO44_WGRAD=1 sends every applicable 3x3 layer there.
+// The Winograd-domain backward-weight (wino44_wgrad.hip) wherever it applies: measured faster than the direct
+// kernels on the level-14 images (block 3: 10.9 -> 6.8 ms) and on the level-8 / STFT ones (backward-weight class
+// 2.0-2.2 -> 1.5-1.6 ms per step); AFD_NO_WINO44_WGRAD=1 puts the direct kernels back.
 bool wino_wgrad_pays(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
-    if (!afd::wino44_wgrad_applicable(Cin, H, W, Cout, K, pad, dil)) return false;
-    if (getenv("AFD_WINO44_WGRAD")) return true;
-    return W >= 256;
+    return afd::wino44_wgrad_applicable(Cin, H, W, Cout, K, pad, dil);
 }
 
 int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int pad, int dil) {

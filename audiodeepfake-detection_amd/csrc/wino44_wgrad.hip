@@ -25,6 +25,15 @@
 //               M [36][co][ci] to a slab; wino44_wgrad_reduce_kernel sums the splits (fixed order: deterministic)
 //               and wino44_wgrad_g_kernel applies G^T . G.
 // Bias gradient: the dy-transform lanes also sum their 16 values; one partial per split (channel group 0 only).
+//
+// What bounds it (round 3, block 3 at level 14: 6.8-8.6 ms by box against 2.6 ms of matrix instructions): the patch
+// loads.  Ablations: without the x loads 4.2-4.8 ms; the six 8-byte halo loads of a patch cost as much as the six
+// 16-byte loads (2.5 ms each class), also with 48 of their 64 lanes switched off -- a load costs by the instruction /
+// the cache lines it asks for, not by its bytes; TCP_PENDING_STALL_CYCLES 39 % of the kernel's cycles, average
+// L1 -> L2 read latency 540 cycles, L2 hit rate 71 %, HBM traffic 7.5 GB (about the tensors once).  Tried and
+// measured level or slower: the dy tile requested a round ahead, channel groups of a split on one XCD, quads /
+// octets of lanes on consecutive addresses (jobs of 8 channels x 8 tiles), all 16-byte loads before the 8-byte
+// ones, touching the lines two rounds ahead with dummy loads.
 #include "afd_common.h"
 #include "../../include/afd_hip.h"
 
@@ -396,10 +405,17 @@ __global__ void __launch_bounds__(256) wino44_wgrad_g_kernel(const float* __rest
             dw[(size_t)i * 9 + r * 3 + 2] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + t[r][5];
         }
     }
-    if (db && partb && i < Cout) {
+    // bias gradient: the last Cout blocks sum one channel's partials each (a tree over the block: fixed order)
+    if (db && partb && (int)blockIdx.x >= (pairs + 255) / 256) {
+        const int c = blockIdx.x - (pairs + 255) / 256;
         float a = 0.f;
-        for (int s = 0; s < S2; ++s) a += partb[(size_t)s * Cout + i];
-        db[i] = a;
+        for (int s = threadIdx.x; s < S2; s += 256) a += partb[(size_t)s * Cout + c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        __shared__ float red4[4];
+        if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) db[c] = (red4[0] + red4[1]) + (red4[2] + red4[3]);
     }
 }
 
@@ -451,12 +467,16 @@ bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, in
     return (size_t)H * W * 16 < 0x7fffffffULL;  // 32-bit lane offsets inside a 16-channel block
 }
 
-// floats: S slabs + the reduced M + bias partials
+// floats: S slabs + the reduced M + bias partials.  An upper bound over every crop of dy (the split count of a
+// cropped launch can come out a few higher than the uncropped one's through the rounding of units per split).
 size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols) {
-    GW g{};
-    plan(g, N, Cin, H, W, Cout, dy_rows, dy_cols);
+    (void)N; (void)H; (void)W; (void)dy_rows; (void)dy_cols;
+    const int shape = pick_shape(Cin, Cout);
+    if (!shape) return 0;
+    const int cgroups = (Cin / (16 * (shape % 10))) * (Cout / (16 * (shape / 10)));
+    const size_t smax = (size_t)(768 / cgroups > 0 ? 768 / cgroups : 1);
     const size_t m = (size_t)kPos * Cout * Cin;
-    return (size_t)g.S * m + m + (size_t)g.S * 2 * Cout;
+    return smax * m + m + smax * 2 * Cout;
 }
 
 int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
@@ -497,8 +517,8 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     rc = afd::check_launch("wino44_wgrad_reduce_kernel");
     if (rc) return rc;
     const int pairs = Cout * Cin;
-    hipLaunchKernelGGL(wino44_wgrad_g_kernel, dim3((pairs + 255) / 256), dim3(256), 0, s, red, g.partb, dw, dbias, Cout, Cin,
-                       2 * g.S);
+    hipLaunchKernelGGL(wino44_wgrad_g_kernel, dim3((pairs + 255) / 256 + (g.partb ? Cout : 0)), dim3(256), 0, s, red, g.partb,
+                       dw, dbias, Cout, Cin, 2 * g.S);
     return afd::check_launch("wino44_wgrad_g_kernel");
 }
 

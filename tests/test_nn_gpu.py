@@ -819,16 +819,12 @@ def test_winograd_domain_backward_weight(case, with_sums):
     db = torch.empty(cout, device="cuda")
     sums = ref_b.cuda() if with_sums else None
     ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin, h, w, cout, 3, 1, 1), dtype=torch.uint8, device="cuda")
-    os.environ["AFD_WINO44_WGRAD"] = "1"  # also on the narrow shapes (the default sends only wide images there)
-    try:
-        def run():
-            _native.check(lib.afd_conv2d_backward_weight_sums(
-                _native.ptr(xc), _native.ptr(dyc), _native.ptr(dw), _native.ptr(db), _native.ptr(sums), n, cin, h, w,
-                cout, 3, 1, 1, rows, cols, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "wgrad")
-            return dw
-        _, c = _issued_class(run, "conv_wgrad")
-    finally:
-        os.environ.pop("AFD_WINO44_WGRAD", None)
+    def run():
+        _native.check(lib.afd_conv2d_backward_weight_sums(
+            _native.ptr(xc), _native.ptr(dyc), _native.ptr(dw), _native.ptr(db), _native.ptr(sums), n, cin, h, w,
+            cout, 3, 1, 1, rows, cols, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "wgrad")
+        return dw
+    _, c = _issued_class(run, "conv_wgrad")
     _close(dw, ref_w, 3e-5, "winograd-domain wgrad")
     _close(db, ref_b, 2e-5, "dbias")
     groups = -(-(-(-cols // 4)) // 4)

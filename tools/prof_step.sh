@@ -1,17 +1,16 @@
-# per-launch kernel timeline of one headline step (development helper)
+# rocprofv3 kernel trace of the bench step: tools/prof_step.sh <tag> [bench args...]
+tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/step; rm -rf $O; mkdir -p $O
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 bench.py --steps 2 --warmup 1 --cpu-frames 0 ${BENCH_ARGS} > $O/bench.json 2> $O/bench.err
-python3 - <<'PY'
-import csv,glob,re
-f=glob.glob('gpurun_out/step/prof/*/*kernel_trace.csv')[0]
-rows=list(csv.DictReader(open(f))); rows.sort(key=lambda r:int(r['Start_Timestamp']))
-idx=[i for i,r in enumerate(rows) if 'wpt2_top' in r['Kernel_Name'] or 'stft_mfma' in r['Kernel_Name']]
-s=idx[-1]; tot=0
-for r in rows[s:]:
-    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6; tot+=d
-    if d>0.2:
-        m=re.search(r'(\w+_kernel(<[^>]*>)?)',r['Kernel_Name'])
-        print(f"{d:8.3f} ms  {m.group(1) if m else r['Kernel_Name'][:60]}  grid={r.get('Grid_Size_X')} wg={r.get('Workgroup_Size_X')} vgpr={r.get('VGPR_Count')}")
-print('total',tot)
+rm -rf gpurun_out/prof_$tag && mkdir -p gpurun_out/prof_$tag
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 5 --warmup 3 --cpu-frames 0 "$@" > gpurun_out/prof_$tag/line.json 2> gpurun_out/prof_$tag/err.log
+f=$(ls gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1)
+cp $f gpurun_out/prof_${tag}_kernel_stats.csv
+python3 - "$f" <<'PY'
+import csv,sys,re
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:28]:
+    nm=re.sub(r'\(anonymous namespace\)::','',r['Name'])[:100]
+    print(f"{float(r['TotalDurationNs'])/1e6/11:8.3f} ms/step {int(r['Calls']):5d} calls avg {float(r['AverageNs'])/1e3:9.1f} us  {nm}")
+print('total kernel ms/step (11 steps in the trace)', tot/1e6/11)
 PY
