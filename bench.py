@@ -23,6 +23,8 @@ Extra objects on the JSON line:
                 HBM-bound front ends: achieved = algorithmic bytes 4 (N + C P T) per frame / launch
                 time over >= 20 timed launches.  traffic = HBM bytes per step of that class from the
                 committed rocprofv3 --pmc summary (profiles/), algorithmic_bytes beside it.
+  end_to_end    the same step fed by NativeFrameLoader from WAV files on disk (host-to-device copy included), after
+                the timed region: shows that `value` survives a real input path.  Never `value` itself.
   cpu_baseline  oracle/torch_ref.py (the reference's algorithm on torch CPU: per-node packet
                 recursion with Welford left on, full-width DCNN step) timed on this host's cores on a
                 bounded sample of the same workload.
@@ -260,6 +262,58 @@ def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 1
     return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
 
 
+def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads: int = 16):
+    """The same train step fed by the input pipeline instead of one HBM-resident batch (reference
+    train_classifier.py:131-159, :945-960: DataLoader -> batch[key].to(device) -> step): 16-bit PCM WAV files on
+    local disk (page cache warm) -> `NativeFrameLoader` (threaded window reads into pinned memory, host-to-device
+    copy, int16 -> f32 on the GPU) -> `_run_batch`.  Returns frames/s over `steps` steps, copies included."""
+    import shutil
+    import tempfile
+    import wave
+
+    import numpy as np
+
+    from audiofakedetect.data_loader import NativeFrameLoader, get_costum_dataset
+
+    root = tempfile.mkdtemp(prefix=f"afd_bench_wav_{rank}_")
+    try:
+        rng = np.random.default_rng(1234 + rank)
+        secs, files = 40, 16  # 2 x 16 files x 40 s: 896 one-second frames in the 70 % train split
+        for name in ("A_real", "B_fake"):
+            os.makedirs(os.path.join(root, name))
+            for i in range(files):
+                pcm = np.clip(rng.standard_normal(22050 * secs) * 3276.8, -32768, 32767).astype(np.int16)
+                with wave.open(os.path.join(root, name, f"{i:04d}.wav"), "wb") as f:
+                    f.setnchannels(1)
+                    f.setsampwidth(2)
+                    f.setframerate(22050)
+                    f.writeframes(pcm.tobytes())
+        ds = get_costum_dataset(data_path=root, save_path=os.path.join(root, "index"), ds_type="train", seconds=1,
+                                resample_rate=22050, limit=-1)
+        loader = NativeFrameLoader(ds, batch_size, device, shuffle=True, seed=0, drop_last=True, threads=threads)
+        done, t0 = 0, None
+        epoch = 0
+        while done < steps + 2:
+            loader.set_epoch(epoch)
+            epoch += 1
+            for batch in loader:
+                if done == 2:  # two untimed steps: pinned buffers, first file reads
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                trainer._run_batch(0, batch)
+                done += 1
+                if done >= steps + 2:
+                    break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": batch_size * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                "frames_on_disk": len(ds), "reader_threads": threads,
+                "path": "16-bit PCM WAV files (page cache) -> afd_wav_read_windows -> pinned int16 -> H2D -> "
+                        "afd_pcm16_resample -> the same train step"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def load_pmc(workload: str, batch: int):
     """Newest committed rocprofv3 --pmc summary for this workload/batch, or None."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
@@ -335,6 +389,8 @@ def main() -> None:
     ap.add_argument("--cpu-frames", type=int, default=1, help="CPU baseline batch, B_cpu of 128 frames (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=CPU_SHARE_PER_GPU,
                     help="torch threads of the CPU baseline (0 = every physical core)")
+    ap.add_argument("--e2e-steps", type=int, default=10,
+                    help="steps of the end-to-end leg (WAV files -> loader -> H2D -> train step; 0 = skip)")
     ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks through a child torch.distributed.run even for --gpus 1")
@@ -465,6 +521,13 @@ def main() -> None:
                     "algorithmic_bytes_per_frame": k["work"] / timed_steps / batch_size,
                     "hbm_bytes_per_step_pmc": class_traffic(pmc, "wpt")}
 
+    e2e = None
+    if kind == "train" and a.e2e_steps > 0:
+        try:
+            e2e = end_to_end(trainer, batch_size, rank, device, a.e2e_steps)
+            log(f"end to end (WAV files -> loader -> H2D -> step): {e2e['ms_per_step']:.3f} ms/step")
+        except Exception as exc:  # noqa: BLE001 - the headline figure does not depend on this leg
+            e2e = {"error": f"{type(exc).__name__}: {exc}"}
     cpu = None
     log(f"kernel classes (ms/step): { {k: round(v['ms_per_step'], 3) for k, v in classes.items()} }")
     if rank == 0 and world == 1 and a.cpu_frames > 0 and kind != "eval":
@@ -494,7 +557,7 @@ def main() -> None:
                        "features": list(args.input_dim[1:]), "flattend_size": args.get("flattend_size"),
                        "optimizer": "Adam lr 4e-4 wd 1e-3" if kind == "train" else None,
                        "parallelism": f"dp{world}"},
-            "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend,
+            "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "end_to_end": e2e,
             "world": {"size": world, "backend": "rccl (torch.distributed nccl)" if ddp else None,
                       "rccl_version": rccl, "devices": devices,
                       "collectives": "gradient arena all-reduce + packed SyncBN statistics" if ddp and kind == "train" else None},
