@@ -98,6 +98,11 @@ _SIGNATURES = {
     "afd_gemm_nt_bf16": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
     "afd_conv2d_bf16_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "afd_conv2d_forward_bf16": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
+    "afd_lcnn_prep_bytes": (c_sz, [c_i, c_i, c_i]),
+    "afd_lcnn_prep_conv_bf16": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
+    "afd_lcnn_conv1_nhwc_bf16": (c_i, [c_p, c_p, c_p] + [c_i] * 6 + [c_p]),
+    "afd_lcnn_conv_nhwc_bf16": (c_i, [c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
+    "afd_lcnn_pool_nhwc_bf16": (c_i, [c_p, c_p] + [c_i] * 5 + [c_p]),
     "afd_lstm_cell": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_lstm_cell_backward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "afd_cross_entropy": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
@@ -155,7 +160,7 @@ def float_array(vals):
 
 
 KERNEL_CLASSES = {"wpt": 0, "conv_igemm": 1, "conv_wgrad": 2, "stft": 3, "conv_direct": 4,
-                  "conv_winograd": 5, "conv_wgrad_1x1": 6}
+                  "conv_winograd": 5, "conv_wgrad_1x1": 6, "lcnn_bf16": 7}
 
 
 def timing_enable(on: bool) -> None:

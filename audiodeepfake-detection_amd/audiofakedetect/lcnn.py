@@ -10,6 +10,8 @@ four pools, ``afd_lstm_cell_backward`` + the same GEMM kernel).
 
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn as nn
 
@@ -93,8 +95,9 @@ def conv2d_bf16(x: torch.Tensor, w: torch.Tensor, b, padding: int, mfm: bool = F
     return y
 
 
-def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM) -> torch.Tensor:
-    """Inference forward of a bidirectional LSTM layer with bf16 projections (cell update in fp32)."""
+def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None) -> torch.Tensor:
+    """Inference forward of a bidirectional LSTM layer with bf16 projections (cell update in fp32).  `wih`:
+    replacement input weights per direction suffix (columns permuted to the caller's feature order)."""
     lib = _native.load()
     bsz, steps, d = x.shape
     h = m.weight_hh_l0.shape[1]
@@ -103,6 +106,8 @@ def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM) -> torch.Tensor:
     for direction, sfx in enumerate(("", "_reverse")):
         wi, wh = getattr(m, "weight_ih_l0" + sfx), getattr(m, "weight_hh_l0" + sfx)
         bias = getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)
+        if wih is not None:
+            wi = wih[sfx]
         pre = gemm_nt(xt, ops._f32c(wi), bias, bf16=True).view(steps, bsz, 4 * h)
         hs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
         cs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
@@ -213,6 +218,37 @@ class BLSTMLayer(nn.Module):
                             m.bias_hh_l0_reverse)
 
 
+class _Bf16Plan:
+    """Weights of the bf16-storage evaluation forward (csrc/lcnn_nhwc.hip), prepared once per model state: per
+    convolution the bf16 rows in matrix-tile order with the evaluation-mode BatchNorm behind it folded in, and the
+    first BLSTM layer's input weights with their columns permuted to the channels-last feature order."""
+
+    def __init__(self, net: "LCNN") -> None:
+        lib = _native.load()
+        self.key = net._bf16_key()
+        self.convs = []
+        dev = net.fc.weight.device
+        for conv_i, pooled, bn_i in net._plan:
+            conv = net.lcnn[conv_i]
+            cout, cin, k, _ = conv.weight.shape
+            buf = torch.empty(lib.afd_lcnn_prep_bytes(cin, cout, k), dtype=torch.uint8, device=dev)
+            bn = net.lcnn[bn_i] if bn_i is not None else None
+            mean = ops._f32c(bn.running_mean) if bn is not None else None
+            var = ops._f32c(bn.running_var) if bn is not None else None
+            _native.check(lib.afd_lcnn_prep_conv_bf16(
+                _native.ptr(ops._f32c(conv.weight.detach())), _native.ptr(ops._f32c(conv.bias.detach())),
+                _native.ptr(mean), _native.ptr(var), float(bn.eps) if bn is not None else 0.0, _native.ptr(buf), cin, cout,
+                k, _native.stream_ptr()), "afd_lcnn_prep_conv_bf16")
+            self.convs.append((buf, cin, cout, k, conv.padding[0], pooled))
+        # channels-last features: index w * C + c instead of the reference's c * W + w (models.py:118-119)
+        lstm0 = net.lstm[0].l_blstm
+        c_last = self.convs[-1][2] // 2
+        feat = lstm0.weight_ih_l0.shape[1]
+        wlast = feat // c_last
+        perm = torch.arange(feat, device=dev).view(c_last, wlast).t().reshape(-1)
+        self.wih0 = {sfx: ops._f32c(getattr(lstm0, "weight_ih_l0" + sfx).detach()[:, perm]) for sfx in ("", "_reverse")}
+
+
 class LCNN(nn.Module):
     """Light CNN + 2 x BLSTM + Linear (reference models.py:68-131)."""
 
@@ -256,6 +292,8 @@ class LCNN(nn.Module):
         if bf16 and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("LCNN(precision='bf16') is the evaluation path: call it under torch.no_grad() "
                                "(training runs in fp32)")
+        if bf16:
+            return self._forward_bf16(x)
         for conv_i, pooled, bn_i in self._plan:
             conv = net[conv_i]
             if bf16:
@@ -273,6 +311,50 @@ class LCNN(nn.Module):
         for layer in self.lstm:
             h = blstm_forward_bf16(ops._f32c(h), layer.l_blstm) if bf16 else layer(h)
         return ops.linear_mean(h, self.fc.weight, self.fc.bias)
+
+    def _bf16_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters()) + tuple(
+            (b.data_ptr(), b._version) for b in self.buffers())
+
+    def _forward_bf16(self, x: torch.Tensor) -> torch.Tensor:
+        """Evaluation forward with bf16 storage: channels-last bf16 activations between the layers, BatchNorm
+        (evaluation mode) folded into the convolutions, bf16 matrix products with fp32 accumulation."""
+        if self.training:
+            raise RuntimeError("LCNN(precision='bf16') is the evaluation path (call .eval()): BatchNorm is folded "
+                               "into the convolutions from its running statistics")
+        lib = _native.load()
+        plan = getattr(self, "_bf16_plan", None)
+        if plan is None or plan.key != self._bf16_key():
+            plan = self._bf16_plan = _Bf16Plan(self)
+        n = x.shape[0]
+        if x.shape[1] != 1:
+            raise RuntimeError("LCNN(precision='bf16'): one input channel")
+        # the reference permutes [B, 1, F, T] -> [B, 1, T, F]: a single-channel image is its own channels-last form
+        img = ops.transpose_contiguous(ops._f32c(x)) if x.is_contiguous() else ops._f32c(x.permute(0, 1, 3, 2))
+        h, w = img.shape[2], img.shape[3]
+        cur = img
+        last = len(plan.convs) - 1
+        for i, (buf, cin, cout, k, pad, pooled) in enumerate(plan.convs):
+            ho, wo = h + 2 * pad - (k - 1), w + 2 * pad - (k - 1)
+            y = torch.empty((n, ho, wo, cout // 2), dtype=torch.bfloat16, device=x.device)
+            if i == 0:
+                _native.check(lib.afd_lcnn_conv1_nhwc_bf16(_native.ptr(cur), _native.ptr(buf), _native.ptr(y), n, h, w, cout,
+                                                           k, pad, _native.stream_ptr()), "afd_lcnn_conv1_nhwc_bf16")
+            else:
+                _native.check(lib.afd_lcnn_conv_nhwc_bf16(_native.ptr(cur), _native.ptr(buf), _native.ptr(y), n, h, w, cin,
+                                                          cout, k, pad, _native.stream_ptr()), "afd_lcnn_conv_nhwc_bf16")
+            cur, h, w = y, ho, wo
+            if pooled:
+                f32 = i == last
+                z = torch.empty((n, h // 2, w // 2, cout // 2), dtype=torch.float32 if f32 else torch.bfloat16,
+                                device=x.device)
+                _native.check(lib.afd_lcnn_pool_nhwc_bf16(_native.ptr(cur), _native.ptr(z), n, h, w, cout // 2,
+                                                          1 if f32 else 0, _native.stream_ptr()), "afd_lcnn_pool_nhwc_bf16")
+                cur, h, w = z, h // 2, w // 2
+        seq = cur.reshape(n, h, -1)  # [B, T', W' C] fp32 (dropout is the identity in evaluation mode)
+        for li, layer in enumerate(self.lstm):
+            seq = blstm_forward_bf16(seq, layer.l_blstm, plan.wih0 if li == 0 else None)
+        return ops.linear_mean(seq, self.fc.weight, self.fc.bias)
 
     def get_name(self) -> str:
         return "LCNN"

@@ -267,6 +267,9 @@ extern "C" int afd_gemm_nt_bf16(const float* A, const float* B, const float* bia
                                 int lda, int ldb, int ldc, int accumulate, afd_stream_t stream) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || lda < K || ldb < K || ldc < N)
         return afd::fail(AFD_ERR_ARG, "gemm_nt bf16: bad argument");
+    afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * M * (double)N * K, AFD_STREAM);
+    timing.issued(2.0 * ((M + 63) / 64 * 64) * (double)((N + 63) / 64 * 64) * ((K + kChunk - 1) / kChunk * kChunk));
+    timing.bytes(4.0 * ((double)M * K + (double)N * K + (double)M * N));
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(kThreads), 0, AFD_STREAM, A, B,
                        bias, C, M, N, K, lda, ldb, ldc, accumulate);
     return afd::check_launch("gemm_nt_bf16_kernel");

@@ -1,0 +1,349 @@
+// LCNN evaluation forward with bf16 STORAGE (BASELINE.json configs[4]: "STFT + LCNN, bf16"): activations travel
+// between the layers as channels-last bf16 tensors [N][H][W][C], weights are converted once per model state.
+//
+// Reference: LCNN.forward of src/audiofakedetect/models.py:68-131 -- nine times Conv2d -> MaxFeatureMap2D
+// (:161-209) [-> MaxPool2d(2, 2)] [-> BatchNorm2d(affine=False), evaluation mode], then two BLSTM layers.
+//
+// Why channels-last: with k ordered (tap, input channel) the eight consecutive k a lane feeds to
+// v_mfma_f32_32x32x16_bf16 are eight consecutive channels of ONE input pixel -- a single 16-byte load, no
+// per-element index arithmetic (lcnn_bf16.hip gathers its im2col tile element by element from fp32 NCHW: its
+// convolutions ran at 4 % of the bf16 peak).  Evaluation-mode BatchNorm is a positive per-channel scale and a
+// shift, which commute with the channel-pair maximum and with max-pooling: they are folded into the weights and
+// bias of the convolution in front (both halves of the pair), so no BatchNorm pass is left.
+//
+//   afd_lcnn_prep_conv_bf16     w [Cout][Cin][K][K] f32 (+ bias, + the BatchNorm that follows) -> bf16 rows in MFMA
+//                               tile order (the two halves of the feature-map pairs on separate 32-row tiles),
+//                               k = (ky K + kx) Cin + ci, and the folded fp32 bias
+//   afd_lcnn_conv1_nhwc_bf16    first layer (Cin = 1, 5x5): fp32 image in, bf16 [N][H][W][32] out
+//   afd_lcnn_conv_nhwc_bf16     1x1 / 3x3 layers: workgroup = 128 output pixels x all rows; per tap the weight slice
+//                               is staged in LDS (shared by the four waves), the pixel fragments come straight from
+//                               global memory as 16-byte loads; epilogue: bias, pair maximum, four channels = one
+//                               8-byte store
+//   afd_lcnn_pool_nhwc_bf16     MaxPool2d(2, 2) on [N][H][W][C] bf16, 8 channels per thread; optionally writes fp32
+//                               (the last pool feeds the LSTM, whose input is [N][H'][W' C] -- the input weights'
+//                               columns are permuted to that order by the host)
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThr = 256;
+constexpr int kPixT = 128;  // output pixels per workgroup (32 per wave)
+
+inline int round_up_i(int v, int m) { return (v + m - 1) / m * m; }
+
+// rows: [0, HP) first halves, [HP, 2 HP) second halves of the feature-map pairs (HP = half padded to 32)
+__global__ void lcnn_prep_conv_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                      const float* __restrict__ bn_mean, const float* __restrict__ bn_var, float eps,
+                                      __bf16* __restrict__ wb, float* __restrict__ bb, int Cout, int Cin, int K,
+                                      int Kpad, int HP) {
+    const int half = Cout / 2;
+    const int total = 2 * HP * Kpad;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int row = e / Kpad, k = e - row * Kpad;
+        const int r = row < HP ? row : row - HP;
+        const int co = row < HP ? r : half + r;
+        float v = 0.f;
+        if (r < half && k < K * K * Cin) {
+            const int t = k / Cin, ci = k - t * Cin;
+            const float scale = bn_var ? rsqrtf(bn_var[r] + eps) : 1.f;
+            v = w[((size_t)co * Cin + ci) * K * K + t] * scale;
+        }
+        wb[e] = (__bf16)v;
+        if (k == 0) {
+            float b = 0.f;
+            if (r < half) {
+                const float scale = bn_var ? rsqrtf(bn_var[r] + eps) : 1.f;
+                b = ((bias ? bias[co] : 0.f) - (bn_mean ? bn_mean[r] : 0.f)) * scale;
+            }
+            bb[row] = b;
+        }
+    }
+}
+
+struct LG {
+    int N, H, W, Cin, Cout, pad, Ho, Wo, tiles, half, HP, Kpad;
+};
+
+// D fragment of a 32x32 tile: column (pixel) = lane & 31, row (channel) = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).
+// Pair maximum of tile i (first halves) and tile i + MT/2 (second halves), bias included; four consecutive channels
+// of a pixel leave as one 8-byte store.
+template <int MT>
+__device__ __forceinline__ void mfm_store(const f32x16 (&acc)[MT], const float* __restrict__ bb, __bf16* __restrict__ yp,
+                                          int half, int HP, int h) {
+#pragma unroll
+    for (int i = 0; i < MT / 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = 32 * i + 8 * g + 4 * h;
+            if (c0 < half) {  // half is a multiple of 4 (16 in this model)
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[i][4 * g + j] + bb[c0 + j];
+                    const float b = acc[i + MT / 2][4 * g + j] + bb[HP + c0 + j];
+                    o[j] = (__bf16)(b > a ? b : a);
+                }
+                *reinterpret_cast<bf16x4*>(yp + c0) = o;
+            }
+        }
+}
+
+// first layer: Cin = 1, K x K taps (25 -> Kpad 32); x fp32 [N][H][W]
+template <int MT>
+__global__ void __launch_bounds__(kThr) lcnn_conv1_kernel(const LG g, const float* __restrict__ x,
+                                                          const __bf16* __restrict__ wb, const float* __restrict__ bb,
+                                                          __bf16* __restrict__ y, int K) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x / g.tiles;
+    const int p = (blockIdx.x - n * g.tiles) * kPixT + 32 * wave + r;
+    const int HW = g.Ho * g.Wo;
+    const bool pv = p < HW;
+    const int oy = pv ? p / g.Wo : 0, ox = pv ? p - oy * g.Wo : 0;
+    const float* xn = x + (size_t)n * g.H * g.W;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+    for (int k0 = 0; k0 < g.Kpad; k0 += 16) {
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = k0 + 8 * h + e;
+            const int ky = k / K, kx = k - ky * K;
+            const int iy = oy + ky - g.pad, ix = ox + kx - g.pad;
+            float f = 0.f;
+            if (pv && k < K * K && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) f = xn[(size_t)iy * g.W + ix];
+            b[e] = (__bf16)f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + (size_t)(32 * mt + r) * g.Kpad + k0 + 8 * h);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mt], 0, 0, 0);
+        }
+    }
+    if (pv) mfm_store<MT>(acc, bb, y + ((size_t)n * HW + p) * g.half, g.half, g.HP, h);
+}
+
+// 1x1 / 3x3 layers on channels-last bf16
+template <int K, int MT, int CIN>
+__global__ void __launch_bounds__(kThr) lcnn_conv_nhwc_kernel(const LG g, const __bf16* __restrict__ x,
+                                                              const __bf16* __restrict__ wb,
+                                                              const float* __restrict__ bb, __bf16* __restrict__ y) {
+    constexpr int PITCH = CIN + 8;            // bf16 per LDS row: 16-byte aligned rows, banks spread
+    constexpr int ROWS = 32 * MT;
+    constexpr int PIECES = ROWS * (CIN / 8);  // 16-byte pieces of one tap's weight slice
+    constexpr int PER = (PIECES + kThr - 1) / kThr;
+    constexpr int CB = CIN / 16;              // k-steps per tap
+    __shared__ __attribute__((aligned(16))) __bf16 As[2][ROWS][PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n = blockIdx.x / g.tiles;
+    const int p = (blockIdx.x - n * g.tiles) * kPixT + 32 * wave + r;
+    const int HW = g.Ho * g.Wo;
+    const bool pv = p < HW;
+    const int oy = pv ? p / g.Wo : 0, ox = pv ? p - oy * g.Wo : 0;
+    const __bf16* xn = x + (size_t)n * g.H * g.W * CIN + 8 * h;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+    bf16x8 aw[PER];   // this thread's pieces of the coming tap's weight slice
+    bf16x8 bx[CB];    // this lane's pixel fragments of the coming tap
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int piece = tid + kThr * j;
+            const int row = piece / (CIN / 8), c8 = piece - row * (CIN / 8);
+            if (PIECES % kThr == 0 || piece < PIECES)
+                aw[j] = *reinterpret_cast<const bf16x8*>(wb + (size_t)row * g.Kpad + t * CIN + 8 * c8);
+        }
+        const int ky = t / K, kx = t - ky * K;
+        const int iy = oy + ky - g.pad, ix = ox + kx - g.pad;
+        const bool ok = pv && iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+        const __bf16* px = xn + ((size_t)(ok ? iy : 0) * g.W + (ok ? ix : 0)) * CIN;
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(px + 16 * j);
+            if (!ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+            }
+            bx[j] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const int piece = tid + kThr * j;
+            const int row = piece / (CIN / 8), c8 = piece - row * (CIN / 8);
+            if (PIECES % kThr == 0 || piece < PIECES) *reinterpret_cast<bf16x8*>(&As[buf][row][8 * c8]) = aw[j];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int t = 0; t < K * K; ++t) {
+        bf16x8 bc[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) bc[j] = bx[j];
+        if (t + 1 < K * K) fetch(t + 1);  // in flight during this tap's matrix instructions
+        const int buf = t & 1;
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(&As[buf][32 * mt + r][16 * j + 8 * h]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bc[j], acc[mt], 0, 0, 0);
+            }
+        if (t + 1 < K * K) stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (pv) mfm_store<MT>(acc, bb, y + ((size_t)n * HW + p) * g.half, g.half, g.HP, h);
+}
+
+// MaxPool2d(2, 2), floor mode, 8 channels per thread
+template <bool OUT_F32>
+__global__ void __launch_bounds__(256) lcnn_pool_kernel(const __bf16* __restrict__ x, void* __restrict__ yv, int N, int H,
+                                                        int W, int C) {
+    const int C8 = C / 8, PH = H / 2, PW = W / 2;
+    const long total = (long)N * PH * PW * C8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % C8);
+    long q = i / C8;
+    const int px = (int)(q % PW);
+    q /= PW;
+    const int py = (int)(q % PH);
+    const int n = (int)(q / PH);
+    const __bf16* p00 = x + (((size_t)n * H + 2 * py) * W + 2 * px) * C + 8 * c8;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p00), b = *reinterpret_cast<const bf16x8*>(p00 + C);
+    const bf16x8 c = *reinterpret_cast<const bf16x8*>(p00 + (size_t)W * C);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(p00 + (size_t)W * C + C);
+    bf16x8 o;
+    float of[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float m = fmaxf(fmaxf((float)a[e], (float)b[e]), fmaxf((float)c[e], (float)d[e]));
+        o[e] = (__bf16)m;
+        of[e] = m;
+    }
+    const size_t off = (((size_t)n * PH + py) * PW + px) * C + 8 * c8;
+    if (OUT_F32) {
+        float* y = static_cast<float*>(yv) + off;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = of[e];
+    } else {
+        *reinterpret_cast<bf16x8*>(static_cast<__bf16*>(yv) + off) = o;
+    }
+}
+
+template <int K, int MT>
+int launch_nhwc(const LG& g, const __bf16* x, const __bf16* wb, const float* bb, __bf16* y, hipStream_t s) {
+    const unsigned grid = (unsigned)(g.N * g.tiles);
+    switch (g.Cin) {
+        case 32: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 32>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
+        case 48: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 48>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
+        case 64: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 64>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
+        default: return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: %d input channels", g.Cin);
+    }
+    return afd::check_launch("lcnn_conv_nhwc_kernel");
+}
+
+int fill_geom(LG& g, int N, int H, int W, int Cin, int Cout, int K, int pad) {
+    if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 2 || (Cout & 1)) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: bad shape");
+    if (pad < 0 || pad >= K) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: padding %d", pad);
+    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pad = pad;
+    g.Ho = H + 2 * pad - (K - 1);
+    g.Wo = W + 2 * pad - (K - 1);
+    if (g.Ho < 1 || g.Wo < 1) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: empty output");
+    g.tiles = (g.Ho * g.Wo + kPixT - 1) / kPixT;
+    g.half = Cout / 2;
+    if (g.half % 4) return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: %d feature-map pairs", g.half);
+    g.HP = round_up_i(g.half, 32);
+    g.Kpad = round_up_i(K * K * Cin, 16);
+    if (2 * g.HP > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: Cout %d", Cout);
+    if ((long)N * g.tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: grid too large");
+    return AFD_OK;
+}
+
+}  // namespace
+
+#define AFD_STREAM static_cast<hipStream_t>(stream)
+
+extern "C" size_t afd_lcnn_prep_bytes(int Cin, int Cout, int K) {
+    if (Cin < 1 || Cout < 2 || K < 1) return 0;
+    const int HP = round_up_i(Cout / 2, 32);
+    return (size_t)2 * HP * round_up_i(K * K * Cin, 16) * sizeof(__bf16) + (size_t)2 * HP * sizeof(float);
+}
+
+// wb_bb: [2 HP][Kpad] bf16 followed by [2 HP] f32 (afd_lcnn_prep_bytes); bn_mean / bn_var: the evaluation-mode
+// BatchNorm2d(affine=False) that follows the layer's max-feature-map (and pool), or null
+extern "C" int afd_lcnn_prep_conv_bf16(const float* w, const float* bias, const float* bn_mean, const float* bn_var,
+                                       float eps, void* wb_bb, int Cin, int Cout, int K, afd_stream_t stream) {
+    if (!w || !wb_bb || Cin < 1 || Cout < 2 || (Cout & 1) || K < 1 || (bn_mean == nullptr) != (bn_var == nullptr))
+        return afd::fail(AFD_ERR_ARG, "lcnn prep: bad argument");
+    const int HP = round_up_i(Cout / 2, 32), Kpad = round_up_i(K * K * Cin, 16);
+    __bf16* wb = static_cast<__bf16*>(wb_bb);
+    float* bb = reinterpret_cast<float*>(wb + (size_t)2 * HP * Kpad);
+    const int total = 2 * HP * Kpad;
+    hipLaunchKernelGGL(lcnn_prep_conv_kernel, dim3((total + 255) / 256), dim3(256), 0, AFD_STREAM, w, bias, bn_mean, bn_var,
+                       eps, wb, bb, Cout, Cin, K, Kpad, HP);
+    return afd::check_launch("lcnn_prep_conv_kernel");
+}
+
+extern "C" int afd_lcnn_conv1_nhwc_bf16(const float* x, const void* wb_bb, void* y, int N, int H, int W, int Cout, int K,
+                                        int pad, afd_stream_t stream) {
+    if (!x || !wb_bb || !y) return afd::fail(AFD_ERR_ARG, "lcnn conv1 bf16: null pointer");
+    LG g{};
+    int rc = fill_geom(g, N, H, W, 1, Cout, K, pad);
+    if (rc) return rc;
+    const __bf16* wb = static_cast<const __bf16*>(wb_bb);
+    const float* bb = reinterpret_cast<const float*>(wb + (size_t)2 * g.HP * g.Kpad);
+    afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * N * (double)g.Ho * g.Wo * Cout * K * K, AFD_STREAM);
+    timing.issued(2.0 * N * (double)g.tiles * kPixT * 2 * g.HP * g.Kpad);
+    timing.bytes((double)N * (4.0 * H * W + 2.0 * g.Ho * g.Wo * g.half));
+    const unsigned grid = (unsigned)(g.N * g.tiles);
+    if (2 * g.HP == 64) hipLaunchKernelGGL((lcnn_conv1_kernel<2>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, static_cast<__bf16*>(y), K);
+    else hipLaunchKernelGGL((lcnn_conv1_kernel<4>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, static_cast<__bf16*>(y), K);
+    return afd::check_launch("lcnn_conv1_kernel");
+}
+
+extern "C" int afd_lcnn_conv_nhwc_bf16(const void* x, const void* wb_bb, void* y, int N, int H, int W, int Cin, int Cout,
+                                       int K, int pad, afd_stream_t stream) {
+    if (!x || !wb_bb || !y) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: null pointer");
+    if (K != 1 && K != 3) return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: kernel size %d", K);
+    LG g{};
+    int rc = fill_geom(g, N, H, W, Cin, Cout, K, pad);
+    if (rc) return rc;
+    const __bf16* wb = static_cast<const __bf16*>(wb_bb);
+    const float* bb = reinterpret_cast<const float*>(wb + (size_t)2 * g.HP * g.Kpad);
+    const __bf16* xb = static_cast<const __bf16*>(x);
+    __bf16* yb = static_cast<__bf16*>(y);
+    afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * N * (double)g.Ho * g.Wo * Cout * Cin * K * K, AFD_STREAM);
+    timing.issued(2.0 * N * (double)g.tiles * kPixT * 2 * g.HP * g.Kpad);
+    timing.bytes(2.0 * N * ((double)H * W * Cin + (double)g.Ho * g.Wo * g.half));
+    const bool two = 2 * g.HP == 64;
+    if (K == 1) return two ? launch_nhwc<1, 2>(g, xb, wb, bb, yb, AFD_STREAM) : launch_nhwc<1, 4>(g, xb, wb, bb, yb, AFD_STREAM);
+    return two ? launch_nhwc<3, 2>(g, xb, wb, bb, yb, AFD_STREAM) : launch_nhwc<3, 4>(g, xb, wb, bb, yb, AFD_STREAM);
+}
+
+extern "C" int afd_lcnn_pool_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, int out_f32,
+                                       afd_stream_t stream) {
+    if (!x || !y || N < 1 || H < 2 || W < 2 || C < 8 || (C & 7)) return afd::fail(AFD_ERR_ARG, "lcnn pool bf16: bad argument");
+    const long total = (long)N * (H / 2) * (W / 2) * (C / 8);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (out_f32) hipLaunchKernelGGL((lcnn_pool_kernel<true>), dim3(grid), dim3(256), 0, AFD_STREAM, static_cast<const __bf16*>(x), y, N, H, W, C);
+    else hipLaunchKernelGGL((lcnn_pool_kernel<false>), dim3(grid), dim3(256), 0, AFD_STREAM, static_cast<const __bf16*>(x), y, N, H, W, C);
+    return afd::check_launch("lcnn_pool_kernel");
+}

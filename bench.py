@@ -51,6 +51,7 @@ import torch.distributed as dist  # noqa: E402
 
 METRIC = "1s@22050Hz frames/sec (WPT-coif4 + DCNN train step) at 1/2/4/8 MI355X"
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (spec)
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E spec (6.29 TB/s measured float4 copy)
 
 WORKLOADS = {
@@ -72,7 +73,7 @@ WORKLOADS = {
     "coif4-l8-frontend": ("packets", "coif4", 256, 0, "frontend", "packets-coif4 level-8 front end only"),
 }
 DEFAULT_BATCH = {"haar-l14-frontend": 4096}
-MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv_wgrad_1x1", "stft")
+MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv_wgrad_1x1", "stft", "lcnn_bf16")
 # rocprof kernel names of each timing class (profiles/r*_pmc_traffic.json is keyed by kernel)
 CLASS_KERNELS = {
     "conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
@@ -82,6 +83,7 @@ CLASS_KERNELS = {
     "wpt": ("wpt2_deep_mfma_kernel", "wpt2_deep_kernel", "wpt2_top_kernel", "wpt_fused_kernel",
             "wpt_haar14_kernel", "wpt3_kernel", "wpt3_top_kernel", "wpt3_deep_kernel"),
     "stft": ("stft_mfma_kernel",),
+    "lcnn_bf16": ("lcnn_conv_nhwc_kernel", "lcnn_conv1_kernel", "gemm_nt_bf16_kernel", "conv_bf16_kernel"),
 }
 
 
@@ -362,8 +364,9 @@ def roofline_of(cls: str, k: dict, steps_timed: int, pmc) -> dict:
         algo_bytes = k["work"] / steps_timed
     else:
         ach = k["issued"] / sec / 1e12
-        r = {"kernel": cls, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-             "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+        peak = PEAK_BF16_MFMA_TFLOPS if cls == "lcnn_bf16" else PEAK_F32_MFMA_TFLOPS
+        r = {"kernel": cls, "bound": "mfma", "achieved": ach, "peak": peak,
+             "unit": "TFLOP/s", "frac": ach / peak,
              "algorithmic_TFLOPs": k["work"] / sec / 1e12,
              "note": "achieved = flops issued on the matrix cores (tile padding included; Winograd F(2x2,3x3) "
                      "= 16 GEMMs per 2x2 tile, F(4x4,3x3) = 36 per 4x4 tile) / summed launch time; algorithmic_TFLOPs = the layers' "
@@ -508,7 +511,7 @@ def main() -> None:
         if k["issued"]:
             c["issued_TFLOPs"] = k["issued"] / (k["total_ms"] * 1e-3) / 1e12
             c["algorithmic_TFLOPs"] = k["work"] / (k["total_ms"] * 1e-3) / 1e12
-            c["mfma_frac"] = c["issued_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
+            c["mfma_frac"] = c["issued_TFLOPs"] / (PEAK_BF16_MFMA_TFLOPS if name == "lcnn_bf16" else PEAK_F32_MFMA_TFLOPS)
         else:
             c["achieved_GBps"] = c["algorithmic_bytes_per_step"] / (c["ms_per_step"] * 1e-3) / 1e9 if c["ms_per_step"] else None
         classes[name] = c

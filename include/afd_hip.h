@@ -49,6 +49,8 @@ int afd_version(void);
 #define AFD_K_CONV_WGRAD_1X1 6 /* backward-weight of the 1x1 layers (a plain GEMM over pixels, HBM-leaning) */
 #define AFD_K_CONV_WINOGRAD 5 /* 3x3 forward / backward-data launches on the Winograd F(2x2,3x3) kernel:
                                   work = direct-form flops, of which the kernel issues 16/36 as MFMAs */
+#define AFD_K_LCNN_BF16 7 /* bf16 matrix-core launches of the LCNN evaluation forward (convolutions, LSTM / Linear
+                             projections): work = the layer's flops, issued = with row / k padding; peak = bf16 MFMA */
 int afd_timing_enable(int on);
 int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work,
                        double* total_issued_flops, double* total_algorithmic_bytes);
@@ -408,6 +410,25 @@ int afd_conv2d_forward_bf16(const float* x, const float* w, const float* bias /*
                             size_t ws_bytes, afd_stream_t stream);
 int afd_gemm_nt_bf16(const float* A, const float* B, const float* bias, float* C, int M, int N, int K,
                      int lda, int ldb, int ldc, int accumulate, afd_stream_t stream);
+/* The same evaluation forward with bf16 STORAGE (csrc/lcnn_nhwc.hip): activations are channels-last bf16 tensors
+ * [N][H][W][C] between the layers, weights are converted once per model state.  Replaces, per layer of
+ * models.py:85-110, Conv2d -> MaxFeatureMap2D (:161-209) [-> MaxPool2d(2, 2)] [-> BatchNorm2d(affine=False) in
+ * evaluation mode: a positive per-channel scale and a shift, folded into the convolution in front of it].
+ * afd_lcnn_prep_conv_bf16 : w [Cout][Cin][K][K], bias (may be NULL), bn_mean / bn_var [Cout/2] (both NULL or both
+ *                           given) -> wb_bb (afd_lcnn_prep_bytes): bf16 weight rows in matrix-tile order with
+ *                           k = (ky K + kx) Cin + ci, followed by the folded fp32 bias.
+ * afd_lcnn_conv1_nhwc_bf16: first layer, x fp32 [N][H][W] (one channel) -> y bf16 [N][Ho][Wo][Cout/2].
+ * afd_lcnn_conv_nhwc_bf16 : K in {1, 3}, Cin in {32, 48, 64}: x bf16 [N][H][W][Cin] -> y bf16 [N][Ho][Wo][Cout/2].
+ * afd_lcnn_pool_nhwc_bf16 : MaxPool2d(2, 2) (floor mode) on bf16 [N][H][W][C], C % 8 == 0; out_f32 != 0 writes
+ *                           fp32 (the tensor that feeds the BLSTM layers as [N][H/2][(W/2) C]). */
+size_t afd_lcnn_prep_bytes(int Cin, int Cout, int K);
+int afd_lcnn_prep_conv_bf16(const float* w, const float* bias, const float* bn_mean, const float* bn_var, float eps,
+                            void* wb_bb, int Cin, int Cout, int K, afd_stream_t stream);
+int afd_lcnn_conv1_nhwc_bf16(const float* x, const void* wb_bb, void* y, int N, int H, int W, int Cout, int K, int pad,
+                             afd_stream_t stream);
+int afd_lcnn_conv_nhwc_bf16(const void* x, const void* wb_bb, void* y, int N, int H, int W, int Cin, int Cout, int K,
+                            int pad, afd_stream_t stream);
+int afd_lcnn_pool_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, int out_f32, afd_stream_t stream);
 /* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):
  * gates = saved pre-activation sums [B][4H] of the step, c / cprev = cell state after / before it
  * (cprev NULL = zero), dh = gradient reaching h_t (row stride lddh), dc = running cell-state

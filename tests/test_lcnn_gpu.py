@@ -200,3 +200,57 @@ def test_lcnn_train_step_matches_cpu_restatement():
         if k.startswith(("lstm.", "fc.")):
             err = (p.grad.cpu() - refp[k].grad).norm().item() / refp[k].grad.norm().item()
             assert err <= 1e-4, (k, err)
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,h,w,bn", [(1, 64, 5, 2, 21, 40, False), (32, 64, 1, 0, 10, 24, True),
+                                                     (32, 96, 3, 1, 10, 24, True), (48, 128, 3, 1, 9, 17, False),
+                                                     (64, 64, 3, 1, 12, 32, True), (48, 96, 1, 0, 7, 19, True)])
+def test_lcnn_nhwc_bf16_layers(cin, cout, k, pad, h, w, bn):
+    """csrc/lcnn_nhwc.hip: Conv2d -> MaxFeatureMap2D [-> BatchNorm2d(affine=False), evaluation mode] on channels-last
+    bf16 tensors, against float64 on the SAME bf16-rounded operands (folded weights rounded as the kernel rounds
+    them): 1e-5 of the largest value before the output is rounded to bf16, i.e. half a bf16 ulp (4e-3) after it.
+    Then MaxPool2d(2, 2) on the bf16 result: exact."""
+    from audiofakedetect import _native
+    lib = _native.load()
+    g = torch.Generator().manual_seed(cin * 100 + cout + k)
+    n = 3
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g)
+    half = cout // 2
+    mean = torch.randn(half, generator=g) * 0.3
+    var = torch.rand(half, generator=g) + 0.5
+    eps = 1e-5
+    scale = torch.rsqrt(var + eps) if bn else torch.ones(half)
+    shift = mean if bn else torch.zeros(half)
+    # the reference computation on the operands the kernel sees: bf16 x, bf16 (w * scale), fp32 bias (b - mean) * scale
+    wf = (wt * torch.cat([scale, scale]).view(-1, 1, 1, 1)).to(torch.bfloat16).double()
+    bf = ((b - torch.cat([shift, shift])) * torch.cat([scale, scale])).double()
+    xq = x.to(torch.bfloat16) if cin > 1 else x  # the first layer reads the fp32 image and rounds while it gathers
+    yr = torch.nn.functional.conv2d(xq.to(torch.bfloat16).double(), wf, bf, padding=pad)
+    yr = torch.maximum(yr[:, :half], yr[:, half:])
+    buf = torch.empty(lib.afd_lcnn_prep_bytes(cin, cout, k), dtype=torch.uint8, device="cuda")
+    wc, bc = wt.cuda(), b.cuda()
+    mc, vc = (mean.cuda(), var.cuda()) if bn else (None, None)
+    _native.check(lib.afd_lcnn_prep_conv_bf16(_native.ptr(wc), _native.ptr(bc), _native.ptr(mc), _native.ptr(vc), eps,
+                                              _native.ptr(buf), cin, cout, k, _native.stream_ptr()), "prep")
+    ho, wo = h + 2 * pad - (k - 1), w + 2 * pad - (k - 1)
+    y = torch.empty(n, ho, wo, half, dtype=torch.bfloat16, device="cuda")
+    if cin == 1:
+        xc = x[:, 0].contiguous().cuda()
+        _native.check(lib.afd_lcnn_conv1_nhwc_bf16(_native.ptr(xc), _native.ptr(buf), _native.ptr(y), n, h, w, cout, k, pad,
+                                                   _native.stream_ptr()), "conv1")
+    else:
+        xc = xq.permute(0, 2, 3, 1).contiguous().cuda()
+        _native.check(lib.afd_lcnn_conv_nhwc_bf16(_native.ptr(xc), _native.ptr(buf), _native.ptr(y), n, h, w, cin, cout, k,
+                                                  pad, _native.stream_ptr()), "conv")
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    scale_ref = yr.abs().max().item()
+    assert (got - yr).abs().max().item() <= 4.5e-3 * scale_ref
+    # pooling of the bf16 tensor: exact, both output types
+    for f32 in (0, 1):
+        z = torch.empty(n, ho // 2, wo // 2, half, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+        _native.check(lib.afd_lcnn_pool_nhwc_bf16(_native.ptr(y), _native.ptr(z), n, ho, wo, half, f32,
+                                                  _native.stream_ptr()), "pool")
+        zr = torch.nn.functional.max_pool2d(y.float().cpu().permute(0, 3, 1, 2), 2, 2)
+        assert torch.equal(z.float().cpu().permute(0, 3, 1, 2), zr)
