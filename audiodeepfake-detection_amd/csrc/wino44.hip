@@ -137,6 +137,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const int ty = id % g.tilesY;
     const int n = id / g.tilesY;
     const int tx0 = wx * kTiles;
+    const bool skip5 = g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
 
     // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
     // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
@@ -250,13 +251,17 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                 else load_u(un, grp + 2 - 12, (grp + 2) % 3);
                 if (grp + 1 < 12) load_b(grp + 1, (grp + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
+                // positions 30..35 (transform row 5) only enter output row 3 of the tile (A^T row 3): a tile row with
+                // at most three live output rows -- the last one of the 13- and 6-row level-14 images -- skips them
+                if (grp < 10 || !skip5) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
+                    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const int p = 3 * grp + q;
-                        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[grp % 3][q][ks], b[grp & 1][q][ks], acc[p], 0, 0, 0);
-                    }
+                        for (int q = 0; q < 3; ++q) {
+                            const int p = 3 * grp + q;
+                            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u[grp % 3][q][ks], b[grp & 1][q][ks], acc[p], 0, 0, 0);
+                        }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -442,7 +447,10 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     const long rows = (long)g.N * g.tilesY;
     // 36 GEMMs [16 CG x Cin] x [Cin x 16 tiles] per workgroup, every tile computed in full
-    afd::timing_annotate(2.0 * kPos * (16.0 * CG) * ((double)kTiles * g.wgX) * (double)rows * g.Cin, -1.0);
+    // (30 of them in a tile row with at most three live output rows)
+    const int last_live = g.rows - 4 * (g.tilesY - 1);
+    const double pos_rows = (double)kPos * (g.tilesY - 1) + (last_live <= 3 ? 30.0 : (double)kPos);
+    afd::timing_annotate(2.0 * pos_rows * (16.0 * CG) * ((double)kTiles * g.wgX) * (double)g.N * g.Cin, -1.0);
     // interior workgroup columns: every patch column inside the image (6 columns from 4 tx - 1)
     const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
     const int edge = g.wgX >= 2 ? 2 : 1;
