@@ -31,7 +31,7 @@
 // 16-byte loads (2.5 ms each class), also with 48 of their 64 lanes switched off -- a load costs by the instruction /
 // the cache lines it asks for, not by its bytes; TCP_PENDING_STALL_CYCLES 39 % of the kernel's cycles, average
 // L1 -> L2 read latency 540 cycles, L2 hit rate 71 %, HBM traffic 7.5 GB (about the tensors once).  Tried and
-// measured level or slower: the dy tile requested a round ahead, channel groups of a split on one XCD, quads /
+// measured level or slower: the dy tile requested a round ahead, quads /
 // octets of lanes on consecutive addresses (jobs of 8 channels x 8 tiles), all 16-byte loads before the 8-byte
 // ones, touching the lines two rounds ahead with dummy loads.
 #include "afd_common.h"
@@ -116,8 +116,13 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wa = wave / CIB, wb = wave % CIB;  // this wave's (co block, ci block)
     const int cgroups = g.cig * (g.Cout / (16 * COB));
-    const int cg = blockIdx.x % cgroups;
-    const int split = blockIdx.x / cgroups;
+    // the channel groups of one split read the same x / dy tiles: they get block ids 8 apart (one XCD under the
+    // observed round-robin placement, so its L2 serves the second and third reader: HBM fetch of the block-3 launch
+    // 23 -> 7.2 GB, the tensors once; the kernel's time is set by its L1 requests and does not change.  Speed only)
+    const int bq = blockIdx.x >> 3, br = blockIdx.x & 7;
+    const int cg = bq % cgroups;
+    const int split = (bq / cgroups) * 8 + br;
+    if (split >= g.S) return;
     const int co0 = (cg / g.cig) * 16 * COB, ci0 = (cg % g.cig) * 16 * CIB;
     const long u_begin = (long)split * g.units_per_split;
     long u_end = u_begin + g.units_per_split;
@@ -508,7 +513,7 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     // 36 GEMMs [Cout x Cin] with K = every tile of every k-step (tile padding included)
     timing.issued(2.0 * kPos * (double)Cout * Cin * 4.0 * (double)g.units);
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
-    const unsigned grid = (unsigned)(cgroups * g.S);
+    const unsigned grid = (unsigned)(cgroups * ((g.S + 7) / 8) * 8);
     if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
     else hipLaunchKernelGGL((wino44_wgrad_kernel<4, 2>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
     int rc = afd::check_launch("wino44_wgrad_kernel");

@@ -11,11 +11,14 @@ run() {  # name, bench flags...
   cp $O/line.json profiles/${tag}_${name}_line.json
   echo "$name done"
 }
-run bench_coif4l14_b128 --steps 5 --warmup 3 --cpu-frames 0 &&
-AFD_WGRAD_STREAM=0 run bench_coif4l14_b128_serial --steps 5 --warmup 3 --cpu-frames 0 &&
+run bench_coif4l14_b128 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
+run bench_sym5l14_b128 --workload sym5-l14 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
+run bench_coif4l8_b128 --workload coif4-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
+run bench_stft_b128 --workload stft --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run frontend_coif4l14_b128 --workload coif4-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
 run frontend_coif4l14_b4096 --workload coif4-l14-frontend --batch 4096 --steps 20 --warmup 5 --cpu-frames 0 &&
 run frontend_sym5l14_b128 --workload sym5-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
+run frontend_sym5l14_b4096 --workload sym5-l14-frontend --batch 4096 --steps 20 --warmup 5 --cpu-frames 0 &&
 run frontend_haarl14_b4096 --workload haar-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
 run lcnn_eval_bf16 --workload stft-lcnn-eval-bf16 --steps 30 --warmup 5 --cpu-frames 0 &&
 cp profiles/${tag}_*kernel_stats.csv profiles/${tag}_*_line.json gpurun_out/
