@@ -12,7 +12,11 @@ bytes per step = total / steps_in_trace (bench.py's roofline.traffic).
 import collections, csv, glob, json, os, re, sys
 
 workload, batch, out_path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-WIDE = ("wino_conv_kernel", "wino16_conv_kernel", "wino44_conv_kernel", "conv3x3_kernel", "wgrad3x3_kernel", "wgrad3x3p_kernel", "conv1x1_kernel",
+# Calibration of the patch-row readers (round 3): for wino44_wgrad_kernel on the block-3 shape the RAW FETCH_SIZE
+# (7.24 GB) equals TCC_MISS_sum x 64 B (7.5 GB) and the two tensors read once (8.3 GB) -- the 16-byte + 8-byte loads
+# at 4-byte alignment of the Winograd patch rows are counted in full, so the Winograd kernels are NOT doubled
+# (round 2 doubled wino44_conv_kernel and carried a caveat); the x2 stays for the aligned 16-byte streaming readers.
+WIDE = ("conv3x3_kernel", "wgrad3x3_kernel", "wgrad3x3p_kernel", "conv1x1_kernel",
         "wpt_haar14_kernel", "conv_wgrad2_kernel", "bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel",
         "bn_bwd_apply_kernel", "prelu_pool_fwd_kernel", "prelu_pool_bwd_kernel")
 out = {"note": __doc__.strip(), "workload": workload, "batch": batch, "kernels": {}}
