@@ -74,6 +74,7 @@ _SIGNATURES = {
     "afd_conv1x1_prelu_bn_backward": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_l, c_p, c_sz, c_p]),
     "afd_moments_accumulate": (c_i, [c_p, c_sz, c_p, c_p]),
     "afd_normalize_forward": (c_i, [c_p, c_p, c_sz, c_f, c_f, c_p]),
+    "afd_normalize_channels_forward": (c_i, [c_p, c_p, c_i, c_i, c_sz, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_p]),
     "afd_packet_stats": (c_i, [c_p, c_l, c_i, c_p, c_p, c_p]),
     "afd_packet_block_norm": (c_i, [c_p, c_i, c_i, c_i, c_p, c_u, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p]),
     "afd_transpose_last2": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -125,7 +125,7 @@ def normalize_forward(t: torch.Tensor, mean: float, std: float) -> torch.Tensor:
 
 def normalize_channels_forward(t: torch.Tensor, means, stds) -> torch.Tensor:
     """(t[:, c] - means[c]) / stds[c] for [B, C, ...] features, out of place, memory order kept:
-    one `afd_normalize_forward` launch per (frame, channel) plane set of the dense buffer."""
+    one `afd_normalize_channels_forward` launch."""
     _native.require_gpu()
     src, perm = t, None
     if not t.is_contiguous():
@@ -137,12 +137,20 @@ def normalize_channels_forward(t: torch.Tensor, means, stds) -> torch.Tensor:
     out = torch.empty_like(src)
     b, c = src.shape[0], src.shape[1]
     plane = src.numel() // (b * c)
-    for i in range(b):
-        for ch in range(c):
-            off = (i * c + ch) * plane * 4
-            _native.check(_lib().afd_normalize_forward(
-                _native.c_p(src.data_ptr() + off), _native.c_p(out.data_ptr() + off), plane,
-                float(means[ch]), float(stds[ch]), _native.stream_ptr()), "afd_normalize_forward")
+    if c <= 8 and b * c <= 65535:
+        import ctypes
+
+        ms = (ctypes.c_float * c)(*[float(means[ch]) for ch in range(c)])
+        sd = (ctypes.c_float * c)(*[float(stds[ch]) for ch in range(c)])
+        _native.check(_lib().afd_normalize_channels_forward(
+            _native.ptr(src), _native.ptr(out), b, c, plane, ms, sd, _native.stream_ptr()), "afd_normalize_channels_forward")
+    else:
+        for i in range(b):
+            for ch in range(c):
+                off = (i * c + ch) * plane * 4
+                _native.check(_lib().afd_normalize_forward(
+                    _native.c_p(src.data_ptr() + off), _native.c_p(out.data_ptr() + off), plane,
+                    float(means[ch]), float(stds[ch]), _native.stream_ptr()), "afd_normalize_forward")
     return out.permute(*perm) if perm else out
 
 

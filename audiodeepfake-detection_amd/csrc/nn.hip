@@ -64,6 +64,17 @@ __global__ void normalize_kernel(const float* __restrict__ x, float* __restrict_
         y[i] = (x[i] - mean) / std;
 }
 
+// per-channel form over [B][C][plane]: blockIdx.y = (frame, channel) plane, statistics by value (C <= 8)
+struct ChanStats { float mean[8], std[8]; };
+__global__ void normalize_channels_kernel(const float* __restrict__ x, float* __restrict__ y, size_t plane, int C,
+                                          const ChanStats st) {
+    const int ch = blockIdx.y % C;
+    const float mean = st.mean[ch], std = st.std[ch];
+    const size_t base = (size_t)blockIdx.y * plane;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < plane; i += (size_t)gridDim.x * kT)
+        y[base + i] = (x[base + i] - mean) / std;
+}
+
 // y[p][c][r] = x[p][r][c]
 __global__ void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int C) {
     __shared__ float tile[32][33];
@@ -662,6 +673,23 @@ extern "C" int afd_normalize_forward(const float* x, float* y, size_t n, float m
     if (!x || !y || std == 0.f) return afd::fail(AFD_ERR_ARG, "normalize: bad argument");
     hipLaunchKernelGGL(normalize_kernel, dim3(grid1d(n)), dim3(kT), 0, AFD_STREAM, x, y, n, mean, std);
     return afd::check_launch("normalize_kernel");
+}
+
+extern "C" int afd_normalize_channels_forward(const float* x, float* y, int B, int C, size_t plane, const float* means,
+                                              const float* stds, afd_stream_t stream) {
+    if (!x || !y || !means || !stds || B < 1 || C < 1 || plane < 1) return afd::fail(AFD_ERR_ARG, "normalize channels: bad argument");
+    if (C > 8 || (long)B * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "normalize channels: %d channels x %d frames", C, B);
+    ChanStats st{};
+    for (int c = 0; c < C; ++c) {
+        if (stds[c] == 0.f) return afd::fail(AFD_ERR_ARG, "normalize channels: zero std");
+        st.mean[c] = means[c];
+        st.std[c] = stds[c];
+    }
+    size_t gx = (plane + kT - 1) / kT;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(normalize_channels_kernel, dim3((unsigned)gx, (unsigned)(B * C)), dim3(kT), 0, AFD_STREAM, x, y,
+                       plane, C, st);
+    return afd::check_launch("normalize_channels_kernel");
 }
 
 extern "C" int afd_transpose_last2(const float* x, float* y, int planes, int R, int C,

@@ -270,6 +270,11 @@ int afd_packet_block_norm(const float* x, int B, int T, int P, const float* absm
 /* torchvision Normalize with scalar statistics (wavelet_math.py:380-382): y = (x-mean)/std */
 int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,
                           afd_stream_t stream);
+/* The per-channel form of torchvision's Normalize for [B][C][plane] features (the loss-less packets' two channels,
+ * wavelet_math.py:380-382 with per-channel statistics): y = (x - means[c]) / stds[c]; means / stds are HOST arrays of
+ * C <= 8 floats; one launch. */
+int afd_normalize_channels_forward(const float* x, float* y, int B, int C, size_t plane, const float* means,
+                                   const float* stds, afd_stream_t stream);
 /* y[p][c][r] = x[p][r][c]: the .permute(0,1,3,2) of models.py:304 made contiguous */
 int afd_transpose_last2(const float* x, float* y, int planes, int R, int C, afd_stream_t stream);
 
