@@ -525,7 +525,9 @@ def main() -> None:
                     "hbm_bytes_per_step_pmc": class_traffic(pmc, "wpt")}
 
     e2e = None
-    if kind == "train" and a.e2e_steps > 0:
+    # (single-process runs only: with several ranks a failure of this leg on one rank would leave the others
+    # waiting in a collective)
+    if kind == "train" and a.e2e_steps > 0 and world == 1:
         try:
             e2e = end_to_end(trainer, batch_size, rank, device, a.e2e_steps)
             log(f"end to end (WAV files -> loader -> H2D -> step): {e2e['ms_per_step']:.3f} ms/step")
