@@ -95,9 +95,11 @@ def conv2d_bf16(x: torch.Tensor, w: torch.Tensor, b, padding: int, mfm: bool = F
     return y
 
 
-def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None) -> torch.Tensor:
+def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, whh: Optional[dict] = None) -> torch.Tensor:
     """Inference forward of a bidirectional LSTM layer with bf16 projections (cell update in fp32).  `wih`:
-    replacement input weights per direction suffix (columns permuted to the caller's feature order)."""
+    replacement input weights per direction suffix (columns permuted to the caller's feature order); `whh`:
+    recurrent weights per direction suffix already converted to bf16 (`afd_f32_to_bf16`) -- the step then is one
+    launch (`afd_lstm_step_bf16`: projection + cell)."""
     lib = _native.load()
     bsz, steps, d = x.shape
     h = m.weight_hh_l0.shape[1]
@@ -109,15 +111,23 @@ def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None) 
         if wih is not None:
             wi = wih[sfx]
         pre = gemm_nt(xt, ops._f32c(wi), bias, bf16=True).view(steps, bsz, 4 * h)
-        hs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+        hs = torch.zeros((2, bsz, h), dtype=torch.float32, device=x.device)
         cs = torch.zeros((bsz, h), dtype=torch.float32, device=x.device)
+        order = range(steps) if direction == 0 else range(steps - 1, -1, -1)
+        if whh is not None and h % 16 == 0:
+            for n_step, t in enumerate(order):
+                hout = out[t, :, direction * h:(direction + 1) * h]
+                _native.check(lib.afd_lstm_step_bf16(
+                    _native.ptr(pre[t]), _native.ptr(whh[sfx]), _native.ptr(hs[n_step & 1]), _native.ptr(cs), _native.ptr(hout),
+                    2 * h, _native.ptr(hs[1 - (n_step & 1)]), bsz, h, _native.stream_ptr()), "afd_lstm_step_bf16")
+            continue
         whc = ops._f32c(wh)
-        for t in (range(steps) if direction == 0 else range(steps - 1, -1, -1)):
+        for t in order:
             gates = pre[t]
-            gemm_nt(hs, whc, None, out=gates, accumulate=True, bf16=True)
+            gemm_nt(hs[0], whc, None, out=gates, accumulate=True, bf16=True)
             hout = out[t, :, direction * h:(direction + 1) * h]
             _native.check(lib.afd_lstm_cell(_native.ptr(gates), _native.ptr(cs), _native.ptr(hout),
-                                            _native.ptr(hs), bsz, h, 2 * h, _native.stream_ptr()), "afd_lstm_cell")
+                                            _native.ptr(hs[0]), bsz, h, 2 * h, _native.stream_ptr()), "afd_lstm_cell")
     return out.permute(1, 0, 2).contiguous()
 
 
@@ -247,6 +257,17 @@ class _Bf16Plan:
         wlast = feat // c_last
         perm = torch.arange(feat, device=dev).view(c_last, wlast).t().reshape(-1)
         self.wih0 = {sfx: ops._f32c(getattr(lstm0, "weight_ih_l0" + sfx).detach()[:, perm]) for sfx in ("", "_reverse")}
+        # recurrent weights as bf16, once
+        self.whh = []
+        for layer in net.lstm:
+            d = {}
+            for sfx in ("", "_reverse"):
+                w = ops._f32c(getattr(layer.l_blstm, "weight_hh_l0" + sfx).detach())
+                wb = torch.empty(w.shape, dtype=torch.bfloat16, device=dev)
+                _native.check(lib.afd_f32_to_bf16(_native.ptr(w), _native.ptr(wb), w.numel(), _native.stream_ptr()),
+                              "afd_f32_to_bf16")
+                d[sfx] = wb
+            self.whh.append(d)
 
 
 class LCNN(nn.Module):
@@ -353,7 +374,7 @@ class LCNN(nn.Module):
                 cur, h, w = z, h // 2, w // 2
         seq = cur.reshape(n, h, -1)  # [B, T', W' C] fp32 (dropout is the identity in evaluation mode)
         for li, layer in enumerate(self.lstm):
-            seq = blstm_forward_bf16(seq, layer.l_blstm, plan.wih0 if li == 0 else None)
+            seq = blstm_forward_bf16(seq, layer.l_blstm, plan.wih0 if li == 0 else None, plan.whh[li])
         return ops.linear_mean(seq, self.fc.weight, self.fc.bias)
 
     def get_name(self) -> str:

@@ -434,6 +434,13 @@ int afd_lcnn_conv1_nhwc_bf16(const float* x, const void* wb_bb, void* y, int N, 
 int afd_lcnn_conv_nhwc_bf16(const void* x, const void* wb_bb, void* y, int N, int H, int W, int Cin, int Cout, int K,
                             int pad, afd_stream_t stream);
 int afd_lcnn_pool_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, int out_f32, afd_stream_t stream);
+/* One step of an LSTM direction in evaluation (nn.LSTM inside BLSTMLayer, models.py:212-237), recurrent projection and
+ * cell in one launch: gates = pre [B][4H] (input projection + biases of the step, order i | f | g | o) + hprev [B][H] .
+ * Wh^T with bf16 operands (wh_bf16 = weight_hh [4H][H] converted by afd_f32_to_bf16), fp32 accumulation and cell;
+ * c [B][H] is updated in place, h goes to hnext [B][H] (a different buffer than hprev) and to hout (row stride ldh). */
+int afd_f32_to_bf16(const float* x, void* y, size_t n, afd_stream_t stream);
+int afd_lstm_step_bf16(const float* pre, const void* wh_bf16, const float* hprev, float* c, float* hout, int ldh,
+                       float* hnext, int B, int H, afd_stream_t stream);
 /* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):
  * gates = saved pre-activation sums [B][4H] of the step, c / cprev = cell state after / before it
  * (cprev NULL = zero), dh = gradient reaching h_t (row stride lddh), dc = running cell-state

@@ -254,3 +254,28 @@ def test_lcnn_nhwc_bf16_layers(cin, cout, k, pad, h, w, bn):
                                                   _native.stream_ptr()), "pool")
         zr = torch.nn.functional.max_pool2d(y.float().cpu().permute(0, 3, 1, 2), 2, 2)
         assert torch.equal(z.float().cpu().permute(0, 3, 1, 2), zr)
+
+
+def test_lstm_step_bf16_matches_the_two_launch_form():
+    """afd_lstm_step_bf16 (recurrent projection + cell in one launch) against the GEMM + cell kernels it replaces in the
+    bf16 evaluation path: same bf16-rounded operands, fp32 accumulation in a different order -- 1e-5 of the largest
+    output over six steps of both directions; and against nn.LSTM in float64 at the bf16 bar."""
+    from audiofakedetect import _native
+    from audiofakedetect.lcnn import blstm_forward_bf16
+    lib = _native.load()
+    torch.manual_seed(4)
+    m = torch.nn.LSTM(64, 32, batch_first=True, bidirectional=True).cuda()
+    x = torch.randn(40, 6, 64, device="cuda")
+    whh = {}
+    for sfx in ("", "_reverse"):
+        w = getattr(m, "weight_hh_l0" + sfx).detach().contiguous()
+        wb = torch.empty(w.shape, dtype=torch.bfloat16, device="cuda")
+        _native.check(lib.afd_f32_to_bf16(_native.ptr(w), _native.ptr(wb), w.numel(), _native.stream_ptr()), "cvt")
+        assert torch.equal(wb, w.to(torch.bfloat16))
+        whh[sfx] = wb
+    with torch.no_grad():
+        two = blstm_forward_bf16(x, m)
+        one = blstm_forward_bf16(x, m, None, whh)
+        ref, _ = m.double()(x.double())
+    assert (one - two).abs().max().item() <= 1e-5 * two.abs().max().item()
+    assert (one.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
