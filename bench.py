@@ -23,6 +23,9 @@ Extra objects on the JSON line:
                 HBM-bound front ends: achieved = algorithmic bytes 4 (N + C P T) per frame / launch
                 time over >= 20 timed launches.  traffic = HBM bytes per step of that class from the
                 committed rocprofv3 --pmc summary (profiles/), algorithmic_bytes beside it.
+  frontend_only the front-end-only workloads (Haar level 14 at B = 4096 = BASELINE configs[3]; coif4 / sym5 level 14 at
+                B = 128 and 4096) measured in the same process after the timed region: ms per transform, GB/s,
+                fraction of the HBM peak.  Default workload, single process only.
   end_to_end    the same step fed by NativeFrameLoader from WAV files on disk (host-to-device copy included), after
                 the timed region: shows that `value` survives a real input path.  Never `value` itself.
   cpu_baseline  oracle/torch_ref.py (the reference's algorithm on torch CPU: per-node packet
@@ -316,6 +319,42 @@ def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads:
         shutil.rmtree(root, ignore_errors=True)
 
 
+def frontend_lines(device, _native, launches: int = 20):
+    """The front-end-only workloads (BASELINE configs[3] and the level-14 transforms of configs[1] / [2]) measured in
+    this same process, so that the driver's own run of the default command records them: per workload the mean launch
+    time of the transform (HIP events, all launches of the `wpt` class) over `launches` calls on resident frames,
+    algorithmic bytes 4 (N + C P T) per frame, and the fraction of the 8 TB/s HBM peak."""
+    from audiofakedetect.wavelet_math import fuse_normalization, get_transforms
+
+    out = []
+    for name, batch in (("haar-l14-frontend", 4096), ("coif4-l14-frontend", 128), ("coif4-l14-frontend", 4096),
+                        ("sym5-l14-frontend", 128), ("sym5-l14-frontend", 4096)):
+        args = make_args(name, batch, False)
+        transforms, normalize = get_transforms(args, "none", str(device), False, verbose=False)
+        fuse_normalization(transforms, normalize)
+        x = synthetic_batch(batch, 0, device)["audio"]
+        with torch.no_grad():
+            for _ in range(3):
+                transforms(x)
+            torch.cuda.synchronize()
+            _native.timing_reset()
+            _native.timing_enable(True)
+            for _ in range(launches):
+                transforms(x)
+            torch.cuda.synchronize()
+            _native.timing_enable(False)
+        k = _native.timing_collect("wpt")
+        _native.timing_reset()
+        ms = k["total_ms"] / launches
+        gbs = k["work"] / (k["total_ms"] * 1e-3) / 1e9
+        out.append({"workload": WORKLOADS[name][5], "batch": batch, "ms_per_transform": ms,
+                    "frames_per_s": batch / (ms * 1e-3), "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
+                    "algorithmic_bytes_per_frame": k["work"] / launches / batch})
+        del x, transforms
+        torch.cuda.empty_cache()
+    return out
+
+
 def load_pmc(workload: str, batch: int):
     """Newest committed rocprofv3 --pmc summary for this workload/batch, or None."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
@@ -392,6 +431,8 @@ def main() -> None:
     ap.add_argument("--cpu-frames", type=int, default=1, help="CPU baseline batch, B_cpu of 128 frames (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=CPU_SHARE_PER_GPU,
                     help="torch threads of the CPU baseline (0 = every physical core)")
+    ap.add_argument("--no-frontends", dest="frontends", action="store_false",
+                    help="skip the front-end-only measurements appended to the default workload's line")
     ap.add_argument("--e2e-steps", type=int, default=10,
                     help="steps of the end-to-end leg (WAV files -> loader -> H2D -> train step; 0 = skip)")
     ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
@@ -524,6 +565,14 @@ def main() -> None:
                     "algorithmic_bytes_per_frame": k["work"] / timed_steps / batch_size,
                     "hbm_bytes_per_step_pmc": class_traffic(pmc, "wpt")}
 
+    fe_lines = None
+    if a.workload == "coif4-l14" and world == 1 and a.frontends:
+        try:
+            fe_lines = frontend_lines(device, _native)
+            log("front ends: " + "; ".join(f"{f['workload']} B={f['batch']}: {f['ms_per_transform']:.4f} ms, "
+                                           f"{f['frac_of_hbm_peak']:.3f}" for f in fe_lines))
+        except Exception as exc:  # noqa: BLE001 - the headline figure does not depend on this leg
+            fe_lines = [{"error": f"{type(exc).__name__}: {exc}"}]
     e2e = None
     # (single-process runs only: with several ranks a failure of this leg on one rank would leave the others
     # waiting in a collective)
@@ -563,6 +612,7 @@ def main() -> None:
                        "optimizer": "Adam lr 4e-4 wd 1e-3" if kind == "train" else None,
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "end_to_end": e2e,
+            "frontend_only": fe_lines,
             "world": {"size": world, "backend": "rccl (torch.distributed nccl)" if ddp else None,
                       "rccl_version": rccl, "devices": devices,
                       "collectives": "gradient arena all-reduce + packed SyncBN statistics" if ddp and kind == "train" else None},

@@ -52,6 +52,17 @@ def test_bench_line_has_the_contract_fields(workload):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert "cropped" not in c["sample"] and "scaled" not in c["sample"]
+    # the same step fed from WAV files through the native loader (host-to-device copy included)
+    e = d["end_to_end"]
+    assert e["value"] > 0 and e["steps"] >= 1 and 0.5 * d["value"] <= e["value"] <= 1.2 * d["value"], e
+    if workload == "coif4-l14":
+        # the front-end-only workloads ride on the default workload's line (BASELINE configs[3] among them)
+        fe = {(f["workload"], f["batch"]): f for f in d["frontend_only"]}
+        haar = fe[("packets-haar level-14 front end only", 4096)]
+        assert haar["algorithmic_bytes_per_frame"] == 4 * (22050 + 32768) and 0.3 < haar["frac_of_hbm_peak"] <= 1.0
+        assert all(0.0 < f["frac_of_hbm_peak"] <= 1.0 for f in d["frontend_only"])
+    else:
+        assert d["frontend_only"] is None
 
 
 def test_frontend_workload_line():

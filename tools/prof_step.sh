@@ -2,7 +2,7 @@
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag && mkdir -p gpurun_out/prof_$tag
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 "$@" > gpurun_out/prof_$tag/line.json 2> gpurun_out/prof_$tag/err.log
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 --no-frontends "$@" > gpurun_out/prof_$tag/line.json 2> gpurun_out/prof_$tag/err.log
 f=$(ls gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1)
 cp $f gpurun_out/prof_${tag}_kernel_stats.csv
 python3 - "$f" <<'PY'
