@@ -53,6 +53,7 @@ struct GW {
     const float* bn_in;
     float* stat_part;
     int part_row0;
+    const float* x_end;  // one past the input tensor (border patches: see load_patch)
 };
 
 // U table: [chunk][position][mt][kstep][lane] = U_p[32 mt + (lane & 31)][8 chunk + 2 kstep + (lane >> 5)]
@@ -154,10 +155,22 @@ wino_conv_kernel(const GW g, const float* __restrict__ x, const float* __restric
                 const f4u v = *reinterpret_cast<const f4u*>(row + ix0);
                 d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w;
             } else {
+                // a patch that sticks out of its row reads the neighbouring row's elements (inside the tensor, and
+                // zeroed by `okmask` when the patch is consumed): the same unaligned 16-byte load as in the interior.
+                // Only where that load would leave the tensor itself (first row of the first plane, last row of the
+                // last one) the elements are fetched one by one from clamped addresses -- a branch two waves of the
+                // launch take.  (Element loads for every border patch cost the level-8 / STFT images, where every
+                // workgroup is a border workgroup, four times the load instructions.)
+                const float* p4 = row + ix0;
+                if (p4 >= x && p4 + 4 <= g.x_end) {
+                    const f4u v = *reinterpret_cast<const f4u*>(p4);
+                    d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int ix = ix0 + j;
-                    d[r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+                    for (int j = 0; j < 4; ++j) {
+                        const int ix = ix0 + j;
+                        d[r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+                    }
                 }
             }
         }
@@ -522,6 +535,7 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     g.tilesY = (g.rows + 1) / 2;
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     g.nchunks = Cin / kCh;
+    g.x_end = x + (size_t)N * Cin * H * W;
     g.slope = slope; g.u = u; g.idx = idx;
     g.bn_in = bn_in; g.stat_part = stat_part;
     if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx))
