@@ -33,6 +33,7 @@ struct GV {
     int N, Cin, Cout, H, W;
     int rows, cols;
     int tilesX, tilesY, wgX, wxCount, nchunks;
+    const float* x_end;  // one past the input tensor (border patches: see load_patch)
 };
 
 // U table: [chunk][position][cg][kstep (2)][lane] = U_p[16 cg + (lane & 15)][8 chunk + 4 kstep + (lane >> 4)]
@@ -126,10 +127,18 @@ wino16_conv_kernel(const GV g, const float* __restrict__ x, const float* __restr
                     const f4u v = *reinterpret_cast<const f4u*>(row + ix0);
                     d[q][r][0] = v.x; d[q][r][1] = v.y; d[q][r][2] = v.z; d[q][r][3] = v.w;
                 } else {
+                    // as in wino.hip: the interior's 16-byte load (what it reads past a row end is inside the tensor
+                    // and masked when consumed); element loads only where the load would leave the tensor
+                    const float* p4 = row + ix0;
+                    if (p4 >= x && p4 + 4 <= g.x_end) {
+                        const f4u v = *reinterpret_cast<const f4u*>(p4);
+                        d[q][r][0] = v.x; d[q][r][1] = v.y; d[q][r][2] = v.z; d[q][r][3] = v.w;
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int ix = ix0 + j;
-                        d[q][r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+                        for (int j = 0; j < 4; ++j) {
+                            const int ix = ix0 + j;
+                            d[q][r][j] = row[ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix)];
+                        }
                     }
                 }
             }
@@ -306,6 +315,7 @@ int wino16_run(const float* x, const float* w, const float* bias, float* y, int 
     g.tilesX = (g.cols + 1) / 2;
     g.tilesY = (g.rows + 1) / 2;
     g.nchunks = Cin / kCh;
+    g.x_end = x + (size_t)N * Cin * H * W;
     const int CG = (Cout + 15) / 16;
     float* U = static_cast<float*>(ws);
     const int total = g.nchunks * 16 * CG * 2 * 64;
