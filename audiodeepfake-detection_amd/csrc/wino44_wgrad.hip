@@ -443,7 +443,8 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     g.cig = Cin / (16 * cib);
     const int cgroups = g.cig * (Cout / (16 * cob));
     // about three workgroups per CU in all (one is resident per CU: 110 KB of LDS), at least 16 rounds each
-    long S = 768 / cgroups;
+    const char* env_wg = getenv("AFD_WW_WGS");  // (development: total workgroups aimed at)
+    long S = (env_wg ? atoi(env_wg) : 768) / cgroups;
     const long max_s = g.units / 32 > 0 ? g.units / 32 : 1;
     S = S < max_s ? S : max_s;
     S = S < 1 ? 1 : S;
