@@ -430,6 +430,15 @@ int pick_shape(int Cin, int Cout) {
     return 0;
 }
 
+// workgroups aimed at in all: one is resident per CU (110 KB of LDS) and all do the same work, so the grid should
+// be a whole number of rounds over the 256 CUs -- 264 workgroups take as long as 512 (measured: 256-aimed grids of
+// 264 ran 13.3 ms against 6.6 ms for 768).  AFD_WW_WGS overrides (development); the workspace bound follows it.
+int target_wgs() {
+    const char* e = getenv("AFD_WW_WGS");
+    const int v = e ? atoi(e) : 768;
+    return v < 8 ? 8 : (v > 8192 ? 8192 : v);
+}
+
 void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols) {
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.H = H; g.W = W;
     g.rows = dy_rows < H ? dy_rows : H;
@@ -442,12 +451,15 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     const int cob = shape / 10, cib = shape % 10;
     g.cig = Cin / (16 * cib);
     const int cgroups = g.cig * (Cout / (16 * cob));
-    // about three workgroups per CU in all (one is resident per CU: 110 KB of LDS), at least 16 rounds each
-    const char* env_wg = getenv("AFD_WW_WGS");  // (development: total workgroups aimed at)
-    long S = (env_wg ? atoi(env_wg) : 768) / cgroups;
-    const long max_s = g.units / 32 > 0 ? g.units / 32 : 1;
-    S = S < max_s ? S : max_s;
-    S = S < 1 ? 1 : S;
+    // three, two or one rounds of workgroups over the CUs (see target_wgs), each workgroup with at least 8 rounds
+    // of its own; a smaller problem gets as many splits as that allows
+    const long max_s = g.units / 16 > 0 ? g.units / 16 : 1;
+    long S = 0;
+    for (int rounds = 3; rounds >= 1 && !S; --rounds) {
+        const long cand = (long)target_wgs() * rounds / 3 / cgroups;
+        if (cand >= 1 && cand <= max_s) S = cand;
+    }
+    if (!S) S = max_s;
     long ups = (g.units + S - 1) / S;
     ups += ups & 1;
     g.units_per_split = ups;
@@ -480,7 +492,7 @@ size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int
     const int shape = pick_shape(Cin, Cout);
     if (!shape) return 0;
     const int cgroups = (Cin / (16 * (shape % 10))) * (Cout / (16 * (shape / 10)));
-    const size_t smax = (size_t)(768 / cgroups > 0 ? 768 / cgroups : 1);
+    const size_t smax = (size_t)(target_wgs() / cgroups > 0 ? target_wgs() / cgroups : 1);
     const size_t m = (size_t)kPos * Cout * Cin;
     return smax * m + m + smax * 2 * Cout;
 }
