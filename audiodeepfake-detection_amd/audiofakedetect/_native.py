@@ -48,6 +48,8 @@ _SIGNATURES = {
     "afd_conv1x1_forward_stats_workspace_bytes": (c_sz, [c_i]),
     "afd_conv1x1_forward_stats": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_l, c_p, c_sz, c_p]),
     "afd_conv3x3_backward_data_bnstats_applicable": (c_i, [c_i] * 4),
+    "afd_conv3x3_backward_data_bnstats_needs_input": (c_i, [c_i] * 4),
+    "afd_conv_weight_dot": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     "afd_conv3x3_backward_data_bnstats_workspace_bytes": (c_sz, [c_i] * 4),
     "afd_conv3x3_backward_data_bnstats": (c_i, [c_p] * 5 + [c_i] * 5 + [c_p, c_sz, c_p, c_sz, c_p]),
     "afd_conv3x3_forward_stats_applicable": (c_i, [c_i] * 5),

@@ -251,15 +251,19 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
     nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
     ws = _ws(nbytes, x.device)
     dx = dw = db = None
+    dot_sums = False
     bn = bn_link.get("bn") if bn_link is not None else None
     if (need_dx and bn is not None and k == 3 and pad == 1 and dil == 1
             and lib.afd_conv3x3_backward_data_bnstats_applicable(cin, h, wd, cout)):
         dx = torch.empty_like(x)
         sums = torch.empty(2 * cin, dtype=torch.float64, device=x.device)
         sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), x.device, "bnstats")
+        # sum(dx * x) per channel equals sum over (cout, taps) of w * dw: with the weight gradient coming anyway, the
+        # launch need not read x again
+        dot_sums = need_dw and not lib.afd_conv3x3_backward_data_bnstats_needs_input(cin, h, wd, cout)
         _native.check(lib.afd_conv3x3_backward_data_bnstats(
-            _native.ptr(dy), _native.ptr(w), _native.ptr(dx), _native.ptr(x), _native.ptr(sums), n, cin, h, wd,
-            cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()),
+            _native.ptr(dy), _native.ptr(w), _native.ptr(dx), None if dot_sums else _native.ptr(x), _native.ptr(sums),
+            n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()),
             "afd_conv3x3_backward_data_bnstats")
         bn_link["bwd_sums"] = sums
     elif need_dx:
@@ -274,6 +278,9 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
             _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), _native.ptr(dy_sums), n, cin, h,
             wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
             _native.stream_ptr()), "afd_conv2d_backward_weight")
+        if dot_sums:
+            _native.check(lib.afd_conv_weight_dot(_native.ptr(w), _native.ptr(dw), cout, cin, k * k,
+                                                  sums.data_ptr() + 8 * cin, _native.stream_ptr()), "afd_conv_weight_dot")
     return dx, dw, db
 
 

@@ -573,6 +573,44 @@ extern "C" int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int 
     return mt == 2 || mt == 3;
 }
 
+// 0: the launch can leave sum(g * xhat) to the caller (xhat = nullptr; sums[Cin .. 2 Cin) come back as zeros and the
+// caller adds afd_conv_weight_dot of the layer's weights and weight gradient) -- the F(4x4) kernel
+extern "C" int afd_conv3x3_backward_data_bnstats_needs_input(int Cin, int H, int W, int Cout) {
+    if (getenv("AFD_BNSTATS_FROM_INPUT")) return 1;
+    return afd::wino44_applicable(Cout, H, W, Cin) ? 0 : 1;
+}
+
+// out[ci] = sum over co and the KK taps of w[co][ci][k] * dw[co][ci][k], in double precision: for a convolution
+// y = w * x (any padding), sum_px dx[ci][px] x[ci][px] = sum_{co,k} w[co][ci][k] dw[co][ci][k] -- the second backward sum
+// of a BatchNorm whose output x feeds the convolution, without a pass over the activations
+__global__ void __launch_bounds__(256)
+conv_weight_dot_kernel(const float* __restrict__ w, const float* __restrict__ dw, int Cout, int Cin, int KK,
+                       double* __restrict__ out) {
+    __shared__ double red[256];
+    const int ci = blockIdx.x;
+    double s = 0.0;
+    for (int e = threadIdx.x; e < Cout * KK; e += 256) {
+        const int co = e / KK, k = e - co * KK;
+        const size_t o = ((size_t)co * Cin + ci) * KK + k;
+        s += (double)w[o] * (double)dw[o];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[ci] = red[0];
+}
+
+extern "C" int afd_conv_weight_dot(const float* w, const float* dw, int Cout, int Cin, int KK, double* out,
+                                   afd_stream_t stream) {
+    if (!w || !dw || !out || Cout < 1 || Cin < 1 || KK < 1) return afd::fail(AFD_ERR_ARG, "conv weight dot: bad argument");
+    hipLaunchKernelGGL(conv_weight_dot_kernel, dim3(Cin), dim3(256), 0, static_cast<hipStream_t>(stream), w, dw, Cout, Cin,
+                       KK, out);
+    return afd::check_launch("conv_weight_dot_kernel");
+}
+
 extern "C" size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, int W) {
     const size_t slots = 2 * ((size_t)(Cin + 31) / 32 * 32);
     long rows = wino_stat_rows(N, H, W);
@@ -584,8 +622,10 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
                                                  double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
                                                  size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes,
                                                  afd_stream_t stream) {
-    if (!dy || !w || !dx || !xhat || !sums || !ws || !stat_ws)
+    if (!dy || !w || !dx || !sums || !ws || !stat_ws)
         return afd::fail(AFD_ERR_ARG, "conv3x3 dgrad + bn sums: null pointer");
+    if (!xhat && afd_conv3x3_backward_data_bnstats_needs_input(Cin, H, W, Cout))
+        return afd::fail(AFD_ERR_ARG, "conv3x3 dgrad + bn sums: this shape's kernel needs the BatchNorm output");
     if (N < 1 || W < 2 || !afd_conv3x3_backward_data_bnstats_applicable(Cin, H, W, Cout))
         return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 dgrad + bn sums: shape not on the Winograd kernel");
     if (stat_ws_bytes < afd_conv3x3_backward_data_bnstats_workspace_bytes(N, Cin, H, W))

@@ -299,7 +299,14 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     };
     static_assert(!(BST && FST), "one statistics epilogue per launch");
     float sg[(BST || FST) ? 4 : 1], sgv[(BST || FST) ? 4 : 1];
-    if constexpr (BST) load_xhat(0);
+    // bn_in == nullptr: only the sums of the result are wanted (the caller takes sum(g * x) from the weight gradient:
+    // sum_px g[ci] x[ci] = sum_{co,k} w[co][ci][k] dw[co][ci][k], afd_conv_weight_dot) -- no loads, 3.5 GB less per launch
+    const bool have_x = BST && g.bn_in != nullptr;  // uniform
+    if constexpr (BST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zn[r] = f4u{0.f, 0.f, 0.f, 0.f};
+        if (have_x) load_xhat(0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int co = 16 * wave + 4 * kq + j;
@@ -307,7 +314,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         if constexpr (BST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) zq[r] = zn[r];
-            if (j + 1 < 4) load_xhat(j + 1);
+            if (j + 1 < 4 && have_x) load_xhat(j + 1);
             sg[j] = sgv[j] = 0.f;
         }
         if constexpr (FST) sg[j] = sgv[j] = 0.f;
@@ -546,7 +553,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.slope = slope; g.u = u; g.idx = idx;
     if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx || (stat_part && !fwd_stats)))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv + pool: bad arguments");
-    if (stat_part && !fwd_stats && (!bn_in || g.rows != H || g.cols != W))
+    if (stat_part && !fwd_stats && (g.rows != H || g.cols != W))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: statistics epilogue on a cropped output");
     if (fwd_stats && (!stat_part || dgrad || (!u && (g.rows != H || g.cols != W))))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: forward statistics: bad arguments");

@@ -176,8 +176,14 @@ int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, const float* u
  * dx = conv_transpose(dy, w) as afd_conv2d_backward_data, and sums[c] = sum_px dx[c], sums[Cin + c] =
  * sum_px dx[c] xhat[c] (double, the layout afd_bn_backward_means takes; deterministic).  Saves the statistics
  * pass of the batch-norm backward (reference models.py:264-268: SyncBatchNorm -> Conv2d k3).
- * `ws` as for afd_conv2d_backward_data. */
+ * `ws` as for afd_conv2d_backward_data.
+ * Where afd_conv3x3_backward_data_bnstats_needs_input returns 0, xhat may be NULL: sums[Cin + c] then comes back 0 and
+ * the caller overwrites it with afd_conv_weight_dot(w, dw) once the layer's weight gradient exists -- for any
+ * convolution, sum_px dx[c] x[c] = sum_{co,k} w[co][c][k] dw[co][c][k] (out[c], double), so the launch does not read
+ * the activations a second time. */
 int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int W, int Cout);
+int afd_conv3x3_backward_data_bnstats_needs_input(int Cin, int H, int W, int Cout);
+int afd_conv_weight_dot(const float* w, const float* dw, int Cout, int Cin, int KK, double* out, afd_stream_t stream);
 size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, int W);
 int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w, float* dx, const float* xhat, double* sums,
                                       int N, int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes,
