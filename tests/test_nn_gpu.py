@@ -517,6 +517,25 @@ def test_backward_data_with_batchnorm_sums(shape, cout, act):
     assert (sums - ref).abs().max().item() <= 2e-6 * scale
     bn_in = xhat
 
+    # the same launch without the activations (where the kernel allows it): sum(dx * xhat) is left to
+    # afd_conv_weight_dot -- for a convolution, sum_px dx[c] x[c] = sum_{co,k} w[co][c][k] dw[co][c][k]
+    if not lib.afd_conv3x3_backward_data_bnstats_needs_input(cin, h, w, cout):
+        dx2 = torch.empty_like(dx0)
+        sums2 = torch.full((2 * cin,), float("nan"), dtype=torch.float64, device="cuda")
+        _native.check(lib.afd_conv3x3_backward_data_bnstats(
+            _native.ptr(dy), _native.ptr(wt), _native.ptr(dx2), None, _native.ptr(sums2), n, cin, h, w, cout,
+            _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "dgrad + sum(dx)")
+        assert torch.equal(dx0, dx2)
+        assert (sums2[:cin] - ref[:cin]).abs().max().item() <= 2e-6 * scale
+        assert (sums2[cin:] == 0).all()
+        dw = torch.empty_like(wt)
+        _native.check(lib.afd_conv2d_backward_weight(
+            _native.ptr(xhat), _native.ptr(dy), _native.ptr(dw), None, n, cin, h, w, cout, 3, 1, 1,
+            _native.ptr(ws), ws.numel(), _native.stream_ptr()), "wgrad")
+        _native.check(lib.afd_conv_weight_dot(_native.ptr(wt), _native.ptr(dw), cout, cin, 9,
+                                              sums2.data_ptr() + 8 * cin, _native.stream_ptr()), "weight dot")
+        assert (sums2[cin:] - ref[cin:]).abs().max().item() <= 2e-5 * scale
+
     # autograd: BatchNorm -> Conv2d(3x3) with and without the link
     bn = torch.nn.BatchNorm2d(cin, affine=False).cuda().train()
     conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
