@@ -397,6 +397,15 @@ def prelu_maxpool2x2(z, slope: Optional[torch.Tensor], out_link: Optional[dict] 
     return _PReLUPool.apply(z, slope, out_link)
 
 
+def _empty_with_slack(shape, dtype, device, slack: int = 16):
+    """A tensor of `shape` whose storage continues `slack` elements past its end: the kernels that expand a pooled
+    gradient read whole 2- / 4-element vectors whose last elements may lie past the last row (and are masked)."""
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    return torch.empty(numel + slack, dtype=dtype, device=device)[:numel].view(shape)
+
+
 class _Conv3x3PReLUPool(torch.autograd.Function):
     """Conv2d(k=3, padding=1) + PReLU + MaxPool2d(2, 2) in one launch (DCNN blocks 3 and 6): on the
     Winograd kernel the 2x2 output tile is the pooling window, so the convolution output is never
@@ -412,7 +421,7 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
         n, cin, h, wd = x.shape
         cout = w.shape[0]
         u = torch.empty((n, cout, h // 2, wd // 2), dtype=torch.float32, device=x.device)
-        idx = torch.empty((n, cout, h // 2, wd // 2), dtype=torch.uint8, device=x.device)
+        idx = _empty_with_slack((n, cout, h // 2, wd // 2), torch.uint8, x.device)
         nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1)
         ws = _ws(nbytes, x.device)
         if (out_link is not None and out_link.get("want_stats")
@@ -436,6 +445,37 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
     def backward(ctx, du):
         x, w, u, idx, slope = ctx.saved_tensors
         n, cin, h, wd, cout = ctx.geom[:5]
+        lib = _lib()
+        bn = ctx.bn_link.get("bn") if ctx.bn_link is not None else None
+        if (bn is not None and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and lib.afd_conv3x3_pooled_backward_applicable(cin, h, wd, cout)):
+            # the pooled gradient + the argmax codes stand for the dense one (three quarters zeros, 4x the bytes,
+            # written once and read twice): both convolution kernels expand them while they load
+            du = _f32c(du)
+            gg = _empty_with_slack(u.shape, torch.float32, u.device)
+            dslope = torch.zeros(1, dtype=torch.float32, device=u.device)
+            coef = ctx.out_link.pop("affine_coef", None) if ctx.out_link is not None else None
+            _native.check(lib.afd_prelu_pool_backward_compact(
+                _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(coef), cout,
+                _native.ptr(gg), _native.ptr(dslope), n * cout, h // 2, wd // 2, _native.stream_ptr()),
+                "afd_prelu_pool_backward_compact")
+            ws = _ws(lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1), x.device)
+            dx = torch.empty_like(x)
+            sums = torch.empty(2 * cin, dtype=torch.float64, device=x.device)
+            sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), x.device, "bnstats")
+            _native.check(lib.afd_conv3x3_backward_data_bnstats_pooled(
+                _native.ptr(gg), _native.ptr(idx), _native.ptr(w), _native.ptr(dx), _native.ptr(sums), n, cin, h, wd,
+                cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()),
+                "afd_conv3x3_backward_data_bnstats_pooled")
+            dw = torch.empty_like(w)
+            db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            _native.check(lib.afd_conv3x3_backward_weight_pooled(
+                _native.ptr(x), _native.ptr(gg), _native.ptr(idx), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
+                cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv3x3_backward_weight_pooled")
+            _native.check(lib.afd_conv_weight_dot(_native.ptr(w), _native.ptr(dw), cout, cin, 9,
+                                                  sums.data_ptr() + 8 * cin, _native.stream_ptr()), "afd_conv_weight_dot")
+            ctx.bn_link["bwd_sums"] = sums
+            return dx, dw, db, dslope, None, None
         dz, dslope = _pool_backward(u, slope, idx, du, (n, cout, h, wd), ctx.out_link)
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dz,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],

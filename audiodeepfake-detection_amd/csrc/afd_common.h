@@ -95,7 +95,8 @@ size_t wino44_workspace_bytes(int Cin, int Cout);
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
                const float* bn_in = nullptr, float* stat_part = nullptr, const float* slope = nullptr,
-               float* u = nullptr, unsigned char* idx = nullptr, int fwd_stats = 0);
+               float* u = nullptr, unsigned char* idx = nullptr, int fwd_stats = 0,
+               const unsigned char* pooled_codes = nullptr);  // backward-data from the pooled gradient: see G4::pidx
 long wino44_stat_rows(int N, int H, int W);
 bool wino44_pool_applicable(int Cin, int H, int W, int Cout);
 // wino16.hip: the same with 16x16x4 tiles and a register-only output transform
@@ -108,8 +109,11 @@ int wino16_run(const float* x, const float* w, const float* bias, float* y, int 
 bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 bool wino44_wgrad_crop_ok(int H, int W, int dy_rows, int dy_cols);
 size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols);
+// pooled_codes != nullptr: dy is the POOLED gradient [N][Cout][H/2][W/2] of the PReLU + 2x2 max-pool behind the
+// convolution (afd_prelu_pool_backward_compact) and pooled_codes the pool's argmax codes; the crop is 2 (H/2) x 2 (W/2)
 int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
-                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s);
+                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s,
+                     const unsigned char* pooled_codes = nullptr);
 
 bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int dz_cols, int* S,

@@ -260,6 +260,56 @@ prelu_pool_bwd_kernel(const float* __restrict__ u, const float* __restrict__ slo
     }
 }
 
+// The pool's backward WITHOUT the scatter: gg[i] = the value prelu_pool_bwd_kernel would route to position (code & 3) of
+// window i (BatchNorm-backward affine and PReLU slope applied), at pooled resolution.  The consumers of the
+// gradient (the F(4x4) backward-data and backward-weight kernels, wino44*.hip) expand it from gg and the codes while
+// they load: the dense gradient -- three quarters zeros, written once and read twice -- never exists.
+__global__ void __launch_bounds__(kT)
+prelu_pool_bwd_compact_kernel(const float* __restrict__ u, const float* __restrict__ slope,
+                              const unsigned char* __restrict__ idx, const float* __restrict__ du,
+                              float* __restrict__ gg, float* __restrict__ dslope, int HWp, int chunks, long items,
+                              const float* __restrict__ coef, int C) {
+    constexpr int UN = 4;
+    const float a = slope ? slope[0] : 1.f;
+    const float inva = (slope && a != 0.f) ? 1.f / a : 0.f;
+    float ds = 0.f, u0 = 0.f, u1 = 0.f;
+    for (long item = blockIdx.x; item < items; item += gridDim.x) {
+        const size_t plane = (size_t)(item / chunks);
+        const int base = (int)(item - (long)plane * chunks) * kT * UN;
+        float kA = 1.f, kB = 0.f, kK = 0.f;
+        if (coef) {
+            const int c = (int)(plane % (size_t)C);
+            kA = coef[4 * c]; kB = coef[4 * c + 1]; kK = coef[4 * c + 2];
+        }
+        const size_t pbase = plane * (size_t)HWp;
+        int code[UN];
+        float g[UN], uu[UN];
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int i = base + r * kT + threadIdx.x;
+            const bool ok = i < HWp;
+            code[r] = ok ? idx[pbase + i] : 0;
+            g[r] = ok ? du[pbase + i] : 0.f;
+            uu[r] = (ok && (slope || coef)) ? u[pbase + i] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < UN; ++r) {
+            const int i = base + r * kT + threadIdx.x;
+            if (i >= HWp) continue;
+            float v = fmaf(kA, g[r], fmaf(kB, uu[r], kK));
+            if (code[r] & 4) {
+                ds += v * uu[r] * inva;
+                v *= a;
+            }
+            gg[pbase + i] = v;
+        }
+    }
+    if (slope) {
+        block_sum3(ds, u0, u1);
+        if (threadIdx.x == 0 && ds != 0.f) atomicAdd(dslope, ds);
+    }
+}
+
 // ------------------------------- BatchNorm ---------------------------------------------
 // Visits the HW elements of one (n, c) plane with 16-byte accesses: a scalar head up to the
 // first 16-byte boundary of the tensor, float4 body, scalar tail.  f1(i) / f4(i) receive the
@@ -743,6 +793,21 @@ extern "C" int afd_prelu_pool_backward(const float* u, const float* slope, const
                                        const float* du, float* dz, float* dslope, int NC, int H,
                                        int W, afd_stream_t stream) {
     return afd_prelu_pool_backward_affine(u, slope, idx, du, nullptr, 1, dz, dslope, NC, H, W, stream);
+}
+
+extern "C" int afd_prelu_pool_backward_compact(const float* u, const float* slope, const uint8_t* idx,
+                                               const float* du, const float* coef, int C, float* gg,
+                                               float* dslope, int NC, int Hp, int Wp, afd_stream_t stream) {
+    if (!u || !idx || !du || !gg || (slope && !dslope)) return afd::fail(AFD_ERR_ARG, "pool bwd (compact): null pointer");
+    if (coef && (C < 1 || NC % C != 0)) return afd::fail(AFD_ERR_ARG, "pool bwd (compact): planes are not a multiple of the channels");
+    if (NC < 1 || Hp < 1 || Wp < 1 || (long)Hp * Wp >= (1L << 30)) return afd::fail(AFD_ERR_ARG, "pool bwd (compact): bad geometry");
+    const int HWp = Hp * Wp;
+    const int chunks = (HWp + kT * 4 - 1) / (kT * 4);
+    const long items = (long)NC * chunks;
+    const unsigned blocks = (unsigned)(items < 8192 ? items : 8192);
+    hipLaunchKernelGGL(prelu_pool_bwd_compact_kernel, dim3(blocks), dim3(kT), 0, AFD_STREAM, u, slope, idx, du, gg, dslope,
+                       HWp, chunks, items, coef, C);
+    return afd::check_launch("prelu_pool_bwd_compact_kernel");
 }
 
 extern "C" int afd_prelu_pool_backward_affine(const float* u, const float* slope, const uint8_t* idx,

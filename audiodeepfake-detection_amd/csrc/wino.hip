@@ -648,6 +648,54 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
     return afd::check_launch("wino_bnstats_reduce kernels");
 }
 
+// ---- the same launch pair for a convolution followed by PReLU + MaxPool2d(2, 2), from the POOLED gradient ----
+// gg [N][Cout][H/2][W/2] (afd_prelu_pool_backward_compact) and the pool's codes stand for the dense gradient dz
+// [N][Cout][H][W] (gg at position code & 3 of each 2x2 window, zero elsewhere, zero in an odd last row / column): the
+// backward-data and backward-weight kernels build their patches / tiles from them while loading, dz is never stored.
+extern "C" int afd_conv3x3_pooled_backward_applicable(int Cin, int H, int W, int Cout) {
+    if (getenv("AFD_NO_POOLED_BWD")) return 0;
+    if (Cin != 64 && Cin != 32) return 0;  // result channels of the backward-data launch built with pooled input
+    if (H < 2 || W < 2) return 0;
+    if (!afd::wino44_applicable(Cout, H, W, Cin)) return 0;
+    if (!afd::wino44_wgrad_applicable(Cin, H, W, Cout, 3, 1, 1)) return 0;
+    return afd::wino44_wgrad_crop_ok(H, W, 2 * (H / 2), 2 * (W / 2)) ? 1 : 0;
+}
+
+extern "C" int afd_conv3x3_backward_data_bnstats_pooled(const float* gg, const uint8_t* codes, const float* w, float* dx,
+                                                        double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
+                                                        size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes,
+                                                        afd_stream_t stream) {
+    if (!gg || !codes || !w || !dx || !sums || !ws || !stat_ws)
+        return afd::fail(AFD_ERR_ARG, "conv3x3 dgrad from the pooled gradient: null pointer");
+    if (N < 1 || !afd_conv3x3_pooled_backward_applicable(Cin, H, W, Cout))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 dgrad from the pooled gradient: shape not built");
+    if (stat_ws_bytes < afd_conv3x3_backward_data_bnstats_workspace_bytes(N, Cin, H, W))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv3x3 dgrad from the pooled gradient: statistics workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int co_pad = (Cin + 31) / 32 * 32;
+    const int slots = 2 * co_pad;
+    const long rows = afd::wino44_stat_rows(N, H, W);
+    float* part = static_cast<float*>(stat_ws);
+    double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
+    int rc = afd::wino44_run(gg, w, nullptr, dx, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, nullptr, part, nullptr, nullptr,
+                             nullptr, 0, codes);
+    if (rc) return rc;
+    const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
+    hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cin,
+                       sums);
+    return afd::check_launch("wino_bnstats_reduce kernels");
+}
+
+extern "C" int afd_conv3x3_backward_weight_pooled(const float* x, const float* gg, const uint8_t* codes, float* dw,
+                                                  float* dbias, int N, int Cin, int H, int W, int Cout, void* ws,
+                                                  size_t ws_bytes, afd_stream_t stream) {
+    if (!x || !gg || !codes || !dw || !ws) return afd::fail(AFD_ERR_ARG, "conv3x3 wgrad from the pooled gradient: null pointer");
+    if (N < 1 || !afd_conv3x3_pooled_backward_applicable(Cin, H, W, Cout))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 wgrad from the pooled gradient: shape not built");
+    return afd::wino44_wgrad_run(x, gg, dw, dbias, N, Cin, H, W, Cout, H, W, ws, ws_bytes, static_cast<hipStream_t>(stream), codes);
+}
+
 // ---- forward 3x3 convolution whose result feeds a training-mode BatchNorm, with that BatchNorm's batch sums ----
 // (the F(4x4) kernel's epilogue, wino44.hip: block 3's pooled forward and block 4's forward at level 14)
 extern "C" int afd_conv3x3_forward_stats_applicable(int Cin, int H, int W, int Cout, int pooled) {

@@ -45,6 +45,11 @@ struct G4 {
     float* u;
     unsigned char* idx;
     const float* x_end;  // one past the input tensor (border patches: see load_patch)
+    // pooled input (PIN; backward-data only): x is the POOLED gradient gg [N][Cin][Hp][Wp] of the PReLU + 2x2 max-pool
+    // behind the convolution, pidx the pool's argmax codes (position = code & 3); the dense gradient -- gg at that
+    // position of each window, zero elsewhere -- is built in registers when a patch is consumed
+    const unsigned char* pidx;
+    int Hp, Wp;
 };
 
 // U = G g G^T, G (6x3)
@@ -122,7 +127,9 @@ __device__ __forceinline__ void at6(const float m0, const float m1, const float 
 // row [sum v | sum v^2] per workgroup, in the rows the BST form uses
 // KS = k-steps of 4 input channels per chunk: 4, or 2 for the two-wave form (32 output channels: 128 threads
 // transform the 128 patches of an 8-channel chunk; 37 KB of LDS, four workgroups per CU)
-template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4>
+typedef unsigned u32b __attribute__((aligned(1)));
+
+template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false>
 __global__ void __launch_bounds__((CG + HELP) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
@@ -163,7 +170,38 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const float* xn = x + (size_t)n * g.Cin * plane;
     const bool rows_in = iy0 >= 0 && iy0 + 5 < g.H;  // uniform
     float d[6][6];
+    // PIN: the patch's rows 4 ty - 1 .. + 4 lie in the pooled rows 2 ty - 1 .. + 2, its columns in the pooled columns
+    // 2 tx - 1 .. + 2: 4 x 4 pooled values and codes travel (20 registers across the matrix loop instead of 36)
+    float pq[PIN ? 4 : 1][4];
+    unsigned pcd[PIN ? 4 : 1];
     auto load_patch = [&](int c) {
+        if constexpr (PIN) {
+            const size_t pplane = (size_t)g.Hp * g.Wp;
+            const size_t co = ((size_t)n * g.Cin + c * CHK + ch) * pplane;
+            const int pr0 = 2 * ty - 1, pc0 = 2 * txp - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pr = pr0 + r;
+                const size_t ro = co + (size_t)(pr < 0 ? 0 : (pr >= g.Hp ? g.Hp - 1 : pr)) * g.Wp;
+                if (!BORDER) {
+                    // (the fourth value of the last interior tile may lie one past the row: the next row or the slack
+                    // the host leaves behind the tensors; it is masked in store_v)
+                    const f4u v = *reinterpret_cast<const f4u*>(x + ro + pc0);
+                    pq[r][0] = v.x; pq[r][1] = v.y; pq[r][2] = v.z; pq[r][3] = v.w;
+                    pcd[r] = *reinterpret_cast<const u32b*>(g.pidx + ro + pc0);
+                } else {
+                    pcd[r] = 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pc = pc0 + j;
+                        const size_t o = ro + (pc < 0 ? 0 : (pc >= g.Wp ? g.Wp - 1 : pc));
+                        pq[r][j] = x[o];
+                        pcd[r] |= (unsigned)g.pidx[o] << (8 * j);
+                    }
+                }
+            }
+            return;
+        }
         const float* xc = xn + (size_t)(c * CHK + ch) * plane;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -193,6 +231,31 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         }
     };
     auto store_v = [&](int buf) {
+        if constexpr (PIN) {
+            const int pr0 = 2 * ty - 1, pc0 = 2 * txp - 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool rok = pr0 + r >= 0 && pr0 + r < g.Hp;  // uniform
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bool ok = rok;
+                    if (BORDER) ok = ok && txp < g.tilesX && pc0 + j >= 0 && pc0 + j < g.Wp;
+                    else if (j == 3) ok = ok && pc0 + 3 < g.Wp;
+                    if (BORDER || j == 3) pq[r][j] = ok ? pq[r][j] : 0.f;
+                    else if (!rok) pq[r][j] = 0.f;
+                }
+            }
+            // patch row r = image row 4 ty - 1 + r: pooled row (r + 1) >> 1 of the four, window row bit (r + 1) & 1
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int pr = (r + 1) >> 1, pc = (j + 1) >> 1;
+                    const unsigned want = (unsigned)((((r + 1) & 1) << 1) | ((j + 1) & 1));
+                    const unsigned pos = (pcd[pr] >> (8 * pc)) & 3u;
+                    d[r][j] = pos == want ? pq[pr][pc] : 0.f;
+                }
+        } else
         if (!rows_in || BORDER) {
 #pragma unroll
             for (int r = 0; r < 6; ++r)
@@ -448,15 +511,15 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     }
 }
 
-template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4>
+template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * kPos * 64 * KS * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS>),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr = true;
@@ -476,12 +539,12 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.part_row0 = 0;
     if (inner > 0) {
         g.wxCount = inner;
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
                            s, g, x, U, bias, y);
         g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
                        x, U, bias, y);
     return afd::check_launch("wino44_conv_kernel");
 }
@@ -537,7 +600,8 @@ long wino44_stat_rows(int N, int H, int W) {
 
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
-               const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx, int fwd_stats) {
+               const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx, int fwd_stats,
+               const unsigned char* pooled_codes) {
     if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
     G4 g{};
@@ -551,6 +615,10 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.bn_in = bn_in; g.stat_part = stat_part;
     g.x_end = x + (size_t)N * Cin * H * W;
     g.slope = slope; g.u = u; g.idx = idx;
+    g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
+    if (pooled_codes && (!dgrad || !stat_part || fwd_stats || u || g.rows != H || g.cols != W || (Cout != 64 && Cout != 32)))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: pooled input is built for the backward-data launches with "
+                                              "BatchNorm sums of 64 / 32 result channels");
     if (u && (g.rows != 2 * (H / 2) || g.cols != 2 * (W / 2) || !slope || !idx || (stat_part && !fwd_stats)))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv + pool: bad arguments");
     if (stat_part && !fwd_stats && (g.rows != H || g.cols != W))
@@ -582,6 +650,9 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
         if (CG == 2) return launch44<2, false, false, 0, true, 2>(g, x, U, bias, y, s);
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: forward statistics for Cout %d", Cout);
     }
+    if (pooled_codes)
+        return CG == 4 ? launch44<4, true, false, 0, false, 4, true>(g, x, U, bias, y, s)
+                       : launch44<2, true, false, 0, false, 2, true>(g, x, U, bias, y, s);
     if (CG == 2)
         return stat_part ? launch44<2, true, false, 0, false, 2>(g, x, U, bias, y, s)
                          : launch44<2, false, false, 0, false, 2>(g, x, U, bias, y, s);

@@ -59,6 +59,11 @@ struct GW {
     int cig;                    // channel groups along Cin
     float* slab;                // [S][36][Cout][Cin]
     float* partb;               // [S][Cout] (bias partials) or null
+    // pooled dy (PDY): dy is the pooled-resolution gradient gg [N][Cout][Hp][Wp] of a PReLU + 2x2 max-pool behind the
+    // convolution and didx its argmax codes (position = code & 3): the 4 x 4 dy tile of a lane is built from 2 x 2
+    // pooled values while it loads (rows = 2 Hp, cols = 2 Wp)
+    const unsigned char* didx;
+    int Hp, Wp;
 };
 
 // B^T d along one axis (wino44.hip)
@@ -105,7 +110,9 @@ __device__ __forceinline__ Unit decode_unit(long u, long end, const GW& g) {
     return r;
 }
 
-template <int COB, int CIB>
+typedef unsigned short u16u __attribute__((aligned(1)));
+
+template <int COB, int CIB, bool PDY = false>
 __global__ void __launch_bounds__(kThreadsW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dy) {
     static_assert(COB * CIB == 8, "eight waves");
@@ -146,7 +153,13 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     // (channel lc of the block, tile lt of the k-step): scalar registers do the bookkeeping
     const unsigned loff = (unsigned)lc * (unsigned)plane + 4u * (unsigned)lt;
     const float* xblk = x + (size_t)(ci0 + 16 * xb) * plane;    // + n * Cin * plane
-    const float* dblk = dy + (size_t)(co0 + 16 * db_) * plane;  // + n * Cout * plane
+    const size_t pplane = PDY ? (size_t)g.Hp * g.Wp : plane;    // plane of dy as it is stored
+    const float* dblk = dy + (size_t)(co0 + 16 * db_) * pplane;  // + n * Cout * plane
+    const unsigned char* iblk = PDY ? g.didx + (size_t)(co0 + 16 * db_) * pplane : nullptr;
+    const unsigned poff = (unsigned)lc * (unsigned)pplane + 2u * (unsigned)lt;  // PDY: channel lc, pooled column pair lt
+    float pg[2][2];      // PDY: the tile's 2 x 2 pooled gradients and codes of the coming round
+    unsigned pcd[2];
+    int pleft = 2;       // PDY: valid pooled columns of the tile (edge groups)
 
     float d[6][6];   // x patch of the coming round
     float e[4][4];   // dy tile of the coming round
@@ -204,6 +217,24 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
         ud = decode_unit(u0 + dks, u_end, g);
         const int oy0 = 4 * ud.ty;
         d_edge = 16 * ud.xg + 16 > g.cols;
+        if constexpr (PDY) {
+            const size_t nb = (size_t)ud.n * g.Cout * pplane + 8 * ud.xg;
+            const int tx = 4 * ud.xg + lt;
+            const bool tile_ok = !d_edge || tx < g.tilesX;
+            const unsigned o1 = d_edge ? (unsigned)lc * (unsigned)pplane + (tile_ok ? 2u * (unsigned)lt : 0u) : poff;
+            pleft = d_edge ? (tile_ok ? (g.cols - 4 * tx) >> 1 : 0) : 2;  // cols is even: whole windows
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int pr = 2 * ud.ty + r < g.Hp ? 2 * ud.ty + r : g.Hp - 1;
+                const size_t ro = nb + (size_t)pr * g.Wp;  // uniform
+                // an edge tile with one window left reads its second value from the next row / plane / the slack the
+                // host leaves behind the tensors; it is masked in transform_d
+                const f2u v = *reinterpret_cast<const f2u*>(dblk + ro + o1);
+                pg[r][0] = v.x; pg[r][1] = v.y;
+                pcd[r] = *reinterpret_cast<const u16u*>(iblk + ro + o1);
+            }
+            return;
+        }
         const float* dc = dblk + (size_t)ud.n * g.Cout * plane + 16 * ud.xg;
         if (!d_edge) {
 #pragma unroll
@@ -269,6 +300,20 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     };
     auto transform_d = [&](bool want_bias) {
         const int oy0 = 4 * ud.ty;
+        if constexpr (PDY) {
+            // window (r, c) of the tile: its gradient sits at position code & 3 = 2 dy + dx, the other three are zero
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const unsigned pos = (pcd[r] >> (8 * c)) & 3u;
+                    const float v = c < pleft ? pg[r][c] : 0.f;
+                    e[2 * r][2 * c] = pos == 0u ? v : 0.f;
+                    e[2 * r][2 * c + 1] = pos == 1u ? v : 0.f;
+                    e[2 * r + 1][2 * c] = pos == 2u ? v : 0.f;
+                    e[2 * r + 1][2 * c + 1] = pos == 3u ? v : 0.f;
+                }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (!ud.live || oy0 + r >= g.rows) {  // uniform
@@ -498,9 +543,16 @@ size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int
 }
 
 int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
-                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s) {
+                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s, const unsigned char* pooled_codes) {
     GW g{};
+    if (pooled_codes) {  // dy is the pooled gradient [N][Cout][H / 2][W / 2]: the crop is the pooled region
+        dy_rows = 2 * (H / 2);
+        dy_cols = 2 * (W / 2);
+    }
     plan(g, N, Cin, H, W, Cout, dy_rows, dy_cols);
+    g.didx = pooled_codes;
+    g.Hp = H / 2;
+    g.Wp = W / 2;
     if (!wino44_wgrad_crop_ok(H, W, dy_rows, dy_cols) || g.units >= 0x7fffffffL)
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd backward-weight: image %d x %d, crop %d x %d", H, W, dy_rows, dy_cols);
     const size_t m = (size_t)kPos * Cout * Cin;
@@ -514,20 +566,25 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     const size_t lds = (size_t)12 * kSetFloats * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<2, 4>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<4, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipSuccess;
+        const void* fns[4] = {reinterpret_cast<const void*>(&wino44_wgrad_kernel<2, 4>),
+                              reinterpret_cast<const void*>(&wino44_wgrad_kernel<4, 2>),
+                              reinterpret_cast<const void*>(&wino44_wgrad_kernel<2, 4, true>),
+                              reinterpret_cast<const void*>(&wino44_wgrad_kernel<4, 2, true>)};
+        for (int i = 0; i < 4 && e == hipSuccess; ++i)
+            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd backward-weight: %s", hipGetErrorString(e));
         attr = true;
     }
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     // 36 GEMMs [Cout x Cin] with K = every tile of every k-step (tile padding included)
     timing.issued(2.0 * kPos * (double)Cout * Cin * 4.0 * (double)g.units);
-    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
+    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols * (pooled_codes ? 0.3125 : 1.0)));
     const unsigned grid = (unsigned)(cgroups * ((g.S + 7) / 8) * 8);
-    if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+    if (pooled_codes) {
+        if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4, true>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+        else hipLaunchKernelGGL((wino44_wgrad_kernel<4, 2, true>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+    } else if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
     else hipLaunchKernelGGL((wino44_wgrad_kernel<4, 2>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
     int rc = afd::check_launch("wino44_wgrad_kernel");
     if (rc) return rc;

@@ -184,6 +184,23 @@ int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, const float* u
 int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int W, int Cout);
 int afd_conv3x3_backward_data_bnstats_needs_input(int Cin, int H, int W, int Cout);
 int afd_conv_weight_dot(const float* w, const float* dw, int Cout, int Cin, int KK, double* out, afd_stream_t stream);
+/* Backward of Conv2d(Cin, Cout, 3, padding=1) -> PReLU -> MaxPool2d(2, 2) (reference models.py:263-266, 279-281) WITHOUT
+ * the dense gradient of the convolution output: afd_prelu_pool_backward_compact leaves gg [N*Cout][H/2][W/2], the value
+ * the pool's backward routes to position (code & 3) of each window (BatchNorm-backward coefficients `coef` [C][4] and
+ * the PReLU slope applied, dslope += as afd_prelu_pool_backward_affine); the two convolution launches expand gg and the
+ * codes while they load.  gg and codes must be followed by >= 16 readable bytes (vector loads at the row ends are
+ * masked, not shortened).  sums as afd_conv3x3_backward_data_bnstats with xhat = NULL.  _applicable: both launches on the
+ * F(4x4) Winograd kernels with 64 / 32 input channels. */
+int afd_conv3x3_pooled_backward_applicable(int Cin, int H, int W, int Cout);
+int afd_prelu_pool_backward_compact(const float* u, const float* slope, const uint8_t* idx, const float* du,
+                                    const float* coef, int C, float* gg, float* dslope, int NC, int Hp, int Wp,
+                                    afd_stream_t stream);
+int afd_conv3x3_backward_data_bnstats_pooled(const float* gg, const uint8_t* codes, const float* w, float* dx,
+                                             double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
+                                             size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
+int afd_conv3x3_backward_weight_pooled(const float* x, const float* gg, const uint8_t* codes, float* dw, float* dbias,
+                                       int N, int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes,
+                                       afd_stream_t stream);
 size_t afd_conv3x3_backward_data_bnstats_workspace_bytes(int N, int Cin, int H, int W);
 int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w, float* dx, const float* xhat, double* sums,
                                       int N, int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes,

@@ -550,6 +550,93 @@ def test_backward_data_with_batchnorm_sums(shape, cout, act):
     _close(grads[1], grads[0].cpu(), 2e-6, "linked BatchNorm backward")
 
 
+@pytest.mark.parametrize("shape,cout", [((2, 64, 13, 1157), 96), ((2, 64, 12, 1028), 96), ((1, 32, 6, 517), 64),
+                                        ((2, 64, 4, 200), 96), ((1, 64, 7, 256), 96), ((1, 32, 3, 64), 64)])
+def test_conv_pool_backward_from_the_pooled_gradient(shape, cout):
+    """Conv3x3 -> PReLU -> MaxPool2d(2, 2) backward without the dense gradient (`afd_prelu_pool_backward_compact`,
+    `afd_conv3x3_backward_data_bnstats_pooled`, `afd_conv3x3_backward_weight_pooled`): dx is the dense path's bit for bit,
+    the weight / bias gradients and the BatchNorm sums agree to rounding; then through autograd with the switch on / off."""
+    import os
+    torch.manual_seed(41)
+    lib = _native.load()
+    n, cin, h, w = shape
+    assert lib.afd_conv3x3_pooled_backward_applicable(cin, h, w, cout)
+    x = torch.randn(shape, device="cuda")
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    wt, bias = conv.weight.detach().contiguous(), conv.bias.detach()
+    slope = torch.full((1,), 0.25, device="cuda")
+    hp, wp = h // 2, w // 2
+    u = torch.empty(n, cout, hp, wp, device="cuda")
+    idx = ops._empty_with_slack((n, cout, hp, wp), torch.uint8, "cuda")
+    ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin, h, w, cout, 3, 1, 1), dtype=torch.uint8, device="cuda")
+    _native.check(lib.afd_conv3x3_prelu_pool_forward(_native.ptr(x), _native.ptr(wt), _native.ptr(bias), _native.ptr(slope),
+                                                     _native.ptr(u), _native.ptr(idx), n, cin, h, w, cout, _native.ptr(ws),
+                                                     ws.numel(), _native.stream_ptr()), "conv + pool")
+    du = torch.randn_like(u)
+    coef = torch.randn(cout, 4, device="cuda")
+    sws = torch.empty(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, w), dtype=torch.uint8, device="cuda")
+    # dense path
+    dz = torch.empty(n, cout, h, w, device="cuda")
+    ds0 = torch.zeros(1, device="cuda")
+    _native.check(lib.afd_prelu_pool_backward_affine(_native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du),
+                                                     _native.ptr(coef), cout, _native.ptr(dz), _native.ptr(ds0), n * cout, h, w,
+                                                     _native.stream_ptr()), "pool bwd")
+    dx0 = torch.empty_like(x)
+    sums0 = torch.empty(2 * cin, dtype=torch.float64, device="cuda")
+    _native.check(lib.afd_conv3x3_backward_data_bnstats(
+        _native.ptr(dz), _native.ptr(wt), _native.ptr(dx0), None, _native.ptr(sums0), n, cin, h, w, cout,
+        _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "dense dgrad")
+    dw0, db0 = torch.empty_like(wt), torch.empty(cout, device="cuda")
+    _native.check(lib.afd_conv2d_backward_weight(_native.ptr(x), _native.ptr(dz), _native.ptr(dw0), _native.ptr(db0), n, cin, h, w,
+                                                 cout, 3, 1, 1, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "dense wgrad")
+    # pooled path
+    gg = ops._empty_with_slack(u.shape, torch.float32, "cuda")
+    ds1 = torch.zeros(1, device="cuda")
+    _native.check(lib.afd_prelu_pool_backward_compact(_native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du),
+                                                      _native.ptr(coef), cout, _native.ptr(gg), _native.ptr(ds1), n * cout, hp, wp,
+                                                      _native.stream_ptr()), "pool bwd compact")
+    dx1 = torch.empty_like(x)
+    sums1 = torch.empty(2 * cin, dtype=torch.float64, device="cuda")
+    _native.check(lib.afd_conv3x3_backward_data_bnstats_pooled(
+        _native.ptr(gg), _native.ptr(idx), _native.ptr(wt), _native.ptr(dx1), _native.ptr(sums1), n, cin, h, w, cout,
+        _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "pooled dgrad")
+    dw1, db1 = torch.empty_like(wt), torch.empty(cout, device="cuda")
+    _native.check(lib.afd_conv3x3_backward_weight_pooled(_native.ptr(x), _native.ptr(gg), _native.ptr(idx), _native.ptr(dw1),
+                                                         _native.ptr(db1), n, cin, h, w, cout, _native.ptr(ws), ws.numel(),
+                                                         _native.stream_ptr()), "pooled wgrad")
+    assert torch.equal(dx0, dx1)
+    assert torch.allclose(ds0, ds1, rtol=1e-5, atol=1e-6)
+    assert (sums0[:cin] - sums1[:cin]).abs().max().item() <= 1e-9 * max(1.0, sums0[:cin].abs().max().item())
+    _close(dw1, dw0.cpu().double(), 2e-6, "pooled wgrad")
+    _close(db1, db0.cpu().double(), 2e-6, "pooled dbias")
+
+    # autograd: BatchNorm -> conv + PReLU + pool -> BatchNorm, with and without the pooled backward
+    bn_in = torch.nn.BatchNorm2d(cin, affine=False).cuda().train()
+    bn_out = torch.nn.BatchNorm2d(cout, affine=False).cuda().train()
+    sl = torch.nn.Parameter(torch.full((1,), 0.25, device="cuda"))
+    dy = torch.randn(n, cout, hp, wp, device="cuda")
+    res = []
+    for off in (True, False):
+        if off:
+            os.environ["AFD_NO_POOLED_BWD"] = "1"
+        else:
+            os.environ.pop("AFD_NO_POOLED_BWD", None)
+        try:
+            conv.zero_grad()
+            sl.grad = None
+            z = x.clone().requires_grad_(True)
+            link, pool_link = {}, {}
+            hcur = ops.batch_norm(z, bn_in, None, False, link)
+            hcur = ops.conv3x3_prelu_maxpool(hcur, conv.weight, conv.bias, sl, link, pool_link)
+            y = ops.batch_norm(hcur, bn_out, None, False, None, pool_link)
+            y.backward(dy)
+            res.append((z.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone(), sl.grad.clone()))
+        finally:
+            os.environ.pop("AFD_NO_POOLED_BWD", None)
+    for got, want, what in zip(res[1], res[0], ("dx", "dw", "db", "dslope")):
+        _close(got, want.cpu().double(), 5e-6, "pooled backward through autograd: " + what)
+
+
 @pytest.mark.parametrize("shape,cout,pooled", [((2, 64, 12, 1030), 96, True), ((1, 64, 13, 259), 96, True),
                                                ((2, 96, 6, 1101), 128, False), ((2, 128, 6, 1027), 32, False)])
 def test_batchnorm_batch_sums_from_the_convolution_epilogue(shape, cout, pooled):
