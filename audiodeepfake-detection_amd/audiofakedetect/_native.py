@@ -50,6 +50,7 @@ _SIGNATURES = {
     "afd_conv3x3_backward_data_bnstats_applicable": (c_i, [c_i] * 4),
     "afd_conv3x3_backward_data_bnstats_needs_input": (c_i, [c_i] * 4),
     "afd_conv_weight_dot": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "afd_multi_gather": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p]),
     "afd_conv3x3_pooled_backward_applicable": (c_i, [c_i] * 4),
     "afd_conv3x3_backward_data_bnstats_pooled": (c_i, [c_p] * 5 + [c_i] * 5 + [c_p, c_sz, c_p, c_sz, c_p]),
     "afd_conv3x3_backward_weight_pooled": (c_i, [c_p] * 5 + [c_i] * 5 + [c_p, c_sz, c_p]),

@@ -1132,9 +1132,15 @@ class FusedAdam(torch.optim.Optimizer):
     """Adam with coupled L2 over ONE flat fp32 arena (params, grads, m, v contiguous).
 
     Same update rule as ``torch.optim.Adam(params, lr, weight_decay=wd)`` (reference
-    train_classifier.py:1215-1219).  The parameters are re-pointed into ``self.flat`` and
-    their ``.grad`` into ``self.flat_grad``: the gradient all-reduce of the data-parallel step
-    is one collective over ``flat_grad`` and the update is one launch.
+    train_classifier.py:1215-1219).  The parameters are re-pointed into ``self.flat``; the gradient all-reduce of the
+    data-parallel step is one collective over ``flat_grad`` and the update is one launch.
+
+    Gradients: ``zero_grad`` drops them (``p.grad = None``), so the backward pass hands every parameter its own fresh
+    gradient tensor without a launch; ``gather_grads`` -- implied by reading ``flat_grad`` and by ``step`` -- copies
+    them into the arena in ONE launch (`afd_multi_gather`) and re-points ``p.grad`` at the arena slices.  (Until
+    round 3 the gradients were arena views from the start and autograd added every one of them in with a launch of its
+    own: ~50 four-microsecond kernels per step.)  A second backward pass before the step accumulates into the slices in
+    place, as torch does.
     """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
@@ -1144,7 +1150,7 @@ class FusedAdam(torch.optim.Optimizer):
         dev = self._params[0].device
         total = sum(p.numel() for p in self._params)
         self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
@@ -1159,22 +1165,58 @@ class FusedAdam(torch.optim.Optimizer):
         self._relink()
         self.step_count = 0
 
-    def zero_grad(self, set_to_none: bool = False):  # keep the arena views alive
-        self.flat_grad.zero_()
-        self._relink()
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        """The gradient arena, with every parameter's gradient in its slice."""
+        self.gather_grads()
+        return self._flat_grad
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self._params:
+            p.grad = None
 
     def _relink(self):
-        base = self.flat_grad.data_ptr()
+        base = self._flat_grad.data_ptr()
         for p, off in zip(self._params, self._offsets):
             if p.grad is None or p.grad.data_ptr() != base + 4 * off:
-                p.grad = self.flat_grad[off:off + p.numel()].view_as(p)
+                p.grad = self._flat_grad[off:off + p.numel()].view_as(p)
+
+    @torch.no_grad()
+    def gather_grads(self) -> None:
+        """Every gradient that is not in its arena slice yet goes there (a missing one as zeros)."""
+        base = self._flat_grad.data_ptr()
+        todo = []
+        for p, off in zip(self._params, self._offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * off:
+                continue
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.float().contiguous()
+            todo.append((g, off, p.numel()))
+        if not todo:
+            return
+        if self._flat_grad.is_cuda:
+            n = len(todo)
+            srcs = (_native.c_p * n)(*[(g.data_ptr() if g is not None else 0) for g, _, _ in todo])
+            offs = (_native.c_l * n)(*[off for _, off, _ in todo])
+            cnts = (_native.c_l * n)(*[cnt for _, _, cnt in todo])
+            _native.check(_lib().afd_multi_gather(srcs, offs, cnts, n, _native.ptr(self._flat_grad),
+                                                  _native.stream_ptr()), "afd_multi_gather")
+        else:
+            for g, off, cnt in todo:
+                if g is None:
+                    self._flat_grad[off:off + cnt].zero_()
+                else:
+                    self._flat_grad[off:off + cnt].copy_(g.reshape(-1))
+        self._relink()  # (the sources die here; the allocator is stream-ordered)
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         g = self.param_groups[0]
         self.step_count += 1
+        self.gather_grads()
         _native.check(_lib().afd_adam_step(
-            _native.ptr(self.flat), _native.ptr(self.flat_grad), _native.ptr(self.m),
+            _native.ptr(self.flat), _native.ptr(self._flat_grad), _native.ptr(self.m),
             _native.ptr(self.v), self.flat.numel(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
             g["weight_decay"], self.step_count, grad_scale, _native.stream_ptr()), "afd_adam_step")
         return None

@@ -1094,6 +1094,47 @@ extern "C" int afd_cross_entropy(const float* logits, const int64_t* labels, flo
     return afd::check_launch("ce_kernel");
 }
 
+// Many small tensors -> slices of one arena in ONE launch (the optimizer's gradient arena: autograd hands every
+// parameter its own gradient tensor; adding each into the arena was ~50 four-microsecond launches per step).  The table
+// travels as a kernel argument; a null source zero-fills its slice (a parameter that took no gradient).
+constexpr int kGatherMax = 96;
+struct GatherTable {
+    const float* src[kGatherMax];
+    long off[kGatherMax];
+    int count[kGatherMax];
+};
+
+__global__ void __launch_bounds__(kT)
+multi_gather_kernel(const GatherTable t, float* __restrict__ dst) {
+    const int k = blockIdx.y;
+    const float* __restrict__ s = t.src[k];
+    float* __restrict__ d = dst + t.off[k];
+    const int n = t.count[k];
+    for (int i = blockIdx.x * kT + threadIdx.x; i < n; i += gridDim.x * kT) d[i] = s ? s[i] : 0.f;
+}
+
+extern "C" int afd_multi_gather(const float* const* srcs, const long* offsets, const long* counts, int n, float* dst,
+                                afd_stream_t stream) {
+    if (n < 0 || (n > 0 && (!srcs || !offsets || !counts || !dst))) return afd::fail(AFD_ERR_ARG, "multi gather: bad argument");
+    for (int base = 0; base < n; base += kGatherMax) {
+        GatherTable t{};
+        const int m = n - base < kGatherMax ? n - base : kGatherMax;
+        long big = 1;
+        for (int k = 0; k < m; ++k) {
+            if (counts[base + k] < 0 || counts[base + k] > 0x7fffffffL || offsets[base + k] < 0)
+                return afd::fail(AFD_ERR_ARG, "multi gather: tensor %d has a bad size or offset", base + k);
+            t.src[k] = srcs[base + k];
+            t.off[k] = offsets[base + k];
+            t.count[k] = (int)counts[base + k];
+            if (counts[base + k] > big) big = counts[base + k];
+        }
+        long bx = (big + kT * 4 - 1) / (kT * 4);
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(multi_gather_kernel, dim3((unsigned)bx, (unsigned)m), dim3(kT), 0, AFD_STREAM, t, dst);
+    }
+    return afd::check_launch("multi_gather_kernel");
+}
+
 extern "C" int afd_adam_step(float* params, const float* grads, float* m, float* v, size_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int step,
                              float grad_scale, afd_stream_t stream) {

@@ -477,6 +477,11 @@ int afd_lstm_cell_backward(const float* gates, const float* c, const float* cpre
 int afd_cross_entropy(const float* logits, const int64_t* labels, float* loss, float* dlogits,
                       float* correct, int B, int O, afd_stream_t stream);
 
+/* n tensors srcs[k] (counts[k] floats each; NULL: zeros) -> dst + offsets[k], one launch per 96 tensors: the
+ * per-parameter gradients of a backward pass into the optimizer's flat gradient arena (ops.FusedAdam.gather_grads).
+ * srcs / offsets / counts are HOST arrays. */
+int afd_multi_gather(const float* const* srcs, const long* offsets, const long* counts, int n, float* dst,
+                     afd_stream_t stream);
 /* Adam with coupled L2 weight decay over one flat parameter arena
  * (train_classifier.py:986,1215-1219); grads are multiplied by grad_scale first */
 int afd_adam_step(float* params, const float* grads, float* m, float* v, size_t n, float lr,

@@ -240,7 +240,7 @@ def test_fused_adam_matches_torch_adam():
         opt_g.zero_grad()
         for p, q, gr in zip(ps_r, ps_g, grads):
             p.grad = gr.clone()
-            q.grad.copy_(gr)
+            q.grad = gr.clone().cuda()
         opt_r.step()
         opt_g.step()
     for p, q in zip(ps_r, ps_g):
