@@ -634,7 +634,8 @@ def test_conv_pool_backward_from_the_pooled_gradient(shape, cout):
         finally:
             os.environ.pop("AFD_NO_POOLED_BWD", None)
     for got, want, what in zip(res[1], res[0], ("dx", "dw", "db", "dslope")):
-        _close(got, want.cpu().double(), 5e-6, "pooled backward through autograd: " + what)
+        # (dslope: one float atomic per workgroup, the order differs run to run)
+        _close(got, want.cpu().double(), 3e-4 if what == "dslope" else 5e-6, "pooled backward through autograd: " + what)
 
 
 @pytest.mark.parametrize("shape,cout,pooled", [((2, 64, 12, 1030), 96, True), ((1, 64, 13, 259), 96, True),
