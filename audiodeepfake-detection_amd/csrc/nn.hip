@@ -108,13 +108,22 @@ __global__ void prelu_dropout_bwd_kernel(const float* __restrict__ z, const floa
     const float a = slope[0];
     const float scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
     float ds = 0.f, u0 = 0.f, u1 = 0.f;
-    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT) {
-        float g = dy[i];
+    auto one = [&](float g, float zz, size_t i) {
         if (p > 0.f) g = uniform01(seed, i) >= p ? g * scale : 0.f;
-        const float zz = z[i];
-        dz[i] = zz > 0.f ? g : a * g;
         if (zz <= 0.f) ds += g * zz;
+        return zz > 0.f ? g : a * g;
+    };
+    // 16-byte accesses where the three tensors allow (the element form ran at 2.5 TB/s)
+    const bool vec = ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0;
+    const size_t n4 = vec ? n >> 2 : 0;
+    for (size_t i = (size_t)blockIdx.x * kT + threadIdx.x; i < n4; i += (size_t)gridDim.x * kT) {
+        const float4 g = reinterpret_cast<const float4*>(dy)[i];
+        const float4 zz = reinterpret_cast<const float4*>(z)[i];
+        reinterpret_cast<float4*>(dz)[i] =
+            make_float4(one(g.x, zz.x, 4 * i), one(g.y, zz.y, 4 * i + 1), one(g.z, zz.z, 4 * i + 2), one(g.w, zz.w, 4 * i + 3));
     }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * kT + threadIdx.x; i < n; i += (size_t)gridDim.x * kT)
+        dz[i] = one(dy[i], z[i], i);
     block_sum3(ds, u0, u1);
     if (threadIdx.x == 0 && ds != 0.f) atomicAdd(dslope, ds);
 }
