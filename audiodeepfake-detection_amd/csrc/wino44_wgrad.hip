@@ -501,7 +501,8 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     const long max_s = g.units / 16 > 0 ? g.units / 16 : 1;
     long S = 0;
     for (int rounds = 3; rounds >= 1 && !S; --rounds) {
-        const long cand = (long)target_wgs() * rounds / 3 / cgroups;
+        long cand = (long)target_wgs() * rounds / 3 / cgroups;
+        if (cand >= 8) cand = cand / 8 * 8;  // the grid is cgroups * ceil(S / 8) * 8 workgroups: do not pass the aim
         if (cand >= 1 && cand <= max_s) S = cand;
     }
     if (!S) S = max_s;
