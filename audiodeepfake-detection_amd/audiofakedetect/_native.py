@@ -113,6 +113,7 @@ _SIGNATURES = {
     "afd_lcnn_pool_nhwc_bf16": (c_i, [c_p, c_p] + [c_i] * 5 + [c_p]),
     "afd_f32_to_bf16": (c_i, [c_p, c_p, c_sz, c_p]),
     "afd_lstm_step_bf16": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "afd_lstm_step_bf16_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "afd_lstm_cell": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_lstm_cell_backward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "afd_cross_entropy": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -105,6 +105,27 @@ def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, 
     h = m.weight_hh_l0.shape[1]
     xt = x.permute(1, 0, 2).contiguous().view(steps * bsz, d)
     out = torch.empty((steps, bsz, 2 * h), dtype=torch.float32, device=x.device)
+    if whh is not None and h % 16 == 0:
+        # both directions advance together: one launch per time step (`afd_lstm_step_bf16_pair`)
+        pres, hs2, cs2 = [], [], []
+        for sfx in ("", "_reverse"):
+            wi = wih[sfx] if wih is not None else getattr(m, "weight_ih_l0" + sfx)
+            bias = getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)
+            pres.append(gemm_nt(xt, ops._f32c(wi), bias, bf16=True).view(steps, bsz, 4 * h))
+            hs2.append(torch.zeros((2, bsz, h), dtype=torch.float32, device=x.device))
+            cs2.append(torch.zeros((bsz, h), dtype=torch.float32, device=x.device))
+        two = _native.c_p * 2
+        whp = two(whh[""].data_ptr(), whh["_reverse"].data_ptr())
+        cp = two(cs2[0].data_ptr(), cs2[1].data_ptr())
+        for n_step in range(steps):
+            tf, tr = n_step, steps - 1 - n_step
+            a, b2 = n_step & 1, 1 - (n_step & 1)
+            _native.check(lib.afd_lstm_step_bf16_pair(
+                two(pres[0][tf].data_ptr(), pres[1][tr].data_ptr()), whp,
+                two(hs2[0][a].data_ptr(), hs2[1][a].data_ptr()), cp,
+                two(out[tf, :, 0:h].data_ptr(), out[tr, :, h:2 * h].data_ptr()), 2 * h,
+                two(hs2[0][b2].data_ptr(), hs2[1][b2].data_ptr()), bsz, h, _native.stream_ptr()), "afd_lstm_step_bf16_pair")
+        return out.permute(1, 0, 2).contiguous()
     for direction, sfx in enumerate(("", "_reverse")):
         wi, wh = getattr(m, "weight_ih_l0" + sfx), getattr(m, "weight_hh_l0" + sfx)
         bias = getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)

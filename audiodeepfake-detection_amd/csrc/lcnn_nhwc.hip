@@ -255,10 +255,18 @@ __global__ void __launch_bounds__(256) lcnn_pool_kernel(const __bf16* __restrict
 // for its batch row, all four gates of four units -- the cell update is lane-local.  h_prev / h_next are two
 // buffers: other workgroups still read h_prev.  (The two-launch form -- a 64x64-tile GEMM over [128 x 1024 x 256]
 // on 32 workgroups, then the cell kernel -- took 27 + 5 us per step, 0.76 ms of the 1.5 ms evaluation step.)
-__global__ void __launch_bounds__(64) lstm_step_bf16_kernel(const float* __restrict__ pre, const __bf16* __restrict__ wh,
-                                                            const float* __restrict__ hprev, float* __restrict__ c,
-                                                            float* __restrict__ hout, int ldh, float* __restrict__ hnext,
-                                                            int B, int H) {
+struct LstmDir {
+    const float* pre;
+    const __bf16* wh;
+    const float* hprev;
+    float* c;
+    float* hout;
+    float* hnext;
+};
+
+__device__ __forceinline__ void lstm_step_body(const float* __restrict__ pre, const __bf16* __restrict__ wh,
+                                               const float* __restrict__ hprev, float* __restrict__ c,
+                                               float* __restrict__ hout, int ldh, float* __restrict__ hnext, int B, int H) {
     const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
     const int j0 = blockIdx.x * 8;
     const int b = blockIdx.y * 32 + r;
@@ -302,6 +310,20 @@ __global__ void __launch_bounds__(64) lstm_step_bf16_kernel(const float* __restr
     *reinterpret_cast<float4*>(hnext + (size_t)b * H + u0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) hout[(size_t)b * ldh + u0 + j] = hn[j];
+}
+
+__global__ void __launch_bounds__(64) lstm_step_bf16_kernel(const float* __restrict__ pre, const __bf16* __restrict__ wh,
+                                                            const float* __restrict__ hprev, float* __restrict__ c,
+                                                            float* __restrict__ hout, int ldh, float* __restrict__ hnext,
+                                                            int B, int H) {
+    lstm_step_body(pre, wh, hprev, c, hout, ldh, hnext, B, H);
+}
+
+// both directions of a bidirectional layer in one launch (blockIdx.z): their steps are independent, and a step is
+// bound by its launch and its one round of loads, not by the 128 workgroups' arithmetic
+__global__ void __launch_bounds__(64) lstm_step_bf16_pair_kernel(const LstmDir d0, const LstmDir d1, int ldh, int B, int H) {
+    const LstmDir& d = blockIdx.z ? d1 : d0;
+    lstm_step_body(d.pre, d.wh, d.hprev, d.c, d.hout, ldh, d.hnext, B, H);
 }
 
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t n) {
@@ -414,6 +436,25 @@ extern "C" int afd_f32_to_bf16(const float* x, void* y, size_t n, afd_stream_t s
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, AFD_STREAM, x, static_cast<__bf16*>(y), n);
     return afd::check_launch("f32_to_bf16_kernel");
+}
+
+extern "C" int afd_lstm_step_bf16_pair(const float* const* pre, const void* const* wh_bf16, const float* const* hprev,
+                                       float* const* c, float* const* hout, int ldh, float* const* hnext, int B, int H,
+                                       afd_stream_t stream) {
+    if (!pre || !wh_bf16 || !hprev || !c || !hout || !hnext || B < 1 || H < 16 || (H & 15) || ldh < H)
+        return afd::fail(AFD_ERR_ARG, "lstm step bf16 (pair): bad argument");
+    LstmDir d[2];
+    for (int k = 0; k < 2; ++k) {
+        if (!pre[k] || !wh_bf16[k] || !hprev[k] || !c[k] || !hout[k] || !hnext[k] || hprev[k] == hnext[k])
+            return afd::fail(AFD_ERR_ARG, "lstm step bf16 (pair): bad pointer of direction %d", k);
+        d[k] = LstmDir{pre[k], static_cast<const __bf16*>(wh_bf16[k]), hprev[k], c[k], hout[k], hnext[k]};
+    }
+    afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * 2.0 * B * 4.0 * H * H, AFD_STREAM);
+    timing.issued(2.0 * 2.0 * ((B + 31) / 32 * 32) * 4.0 * H * H);
+    timing.bytes(2.0 * (2.0 * 4 * H * H + 4.0 * B * (4.0 * H + 4.0 * H)));
+    hipLaunchKernelGGL(lstm_step_bf16_pair_kernel, dim3((unsigned)(H / 8), (unsigned)((B + 31) / 32), 2), dim3(64), 0, AFD_STREAM,
+                       d[0], d[1], ldh, B, H);
+    return afd::check_launch("lstm_step_bf16_pair_kernel");
 }
 
 extern "C" int afd_lstm_step_bf16(const float* pre, const void* wh_bf16, const float* hprev, float* c, float* hout, int ldh,

@@ -464,6 +464,11 @@ int afd_lcnn_pool_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, 
 int afd_f32_to_bf16(const float* x, void* y, size_t n, afd_stream_t stream);
 int afd_lstm_step_bf16(const float* pre, const void* wh_bf16, const float* hprev, float* c, float* hout, int ldh,
                        float* hnext, int B, int H, afd_stream_t stream);
+/* The same step for BOTH directions of a bidirectional layer in one launch: every argument is a HOST array of two
+ * pointers (forward direction, reverse direction). */
+int afd_lstm_step_bf16_pair(const float* const* pre, const void* const* wh_bf16, const float* const* hprev,
+                            float* const* c, float* const* hout, int ldh, float* const* hnext, int B, int H,
+                            afd_stream_t stream);
 /* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):
  * gates = saved pre-activation sums [B][4H] of the step, c / cprev = cell state after / before it
  * (cprev NULL = zero), dh = gradient reaching h_t (row stride lddh), dc = running cell-state
