@@ -95,7 +95,8 @@ def conv2d_bf16(x: torch.Tensor, w: torch.Tensor, b, padding: int, mfm: bool = F
     return y
 
 
-def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, whh: Optional[dict] = None) -> torch.Tensor:
+def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, whh: Optional[dict] = None,
+                       bias2: Optional[dict] = None) -> torch.Tensor:
     """Inference forward of a bidirectional LSTM layer with bf16 projections (cell update in fp32).  `wih`:
     replacement input weights per direction suffix (columns permuted to the caller's feature order); `whh`:
     recurrent weights per direction suffix already converted to bf16 (`afd_f32_to_bf16`) -- the step then is one
@@ -108,12 +109,13 @@ def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, 
     if whh is not None and h % 16 == 0:
         # both directions advance together: one launch per time step (`afd_lstm_step_bf16_pair`)
         pres, hs2, cs2 = [], [], []
-        for sfx in ("", "_reverse"):
+        state = torch.zeros((2, 3, bsz, h), dtype=torch.float32, device=x.device)  # per direction: two h buffers and c
+        for d, sfx in enumerate(("", "_reverse")):
             wi = wih[sfx] if wih is not None else getattr(m, "weight_ih_l0" + sfx)
-            bias = getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)
+            bias = bias2[sfx] if bias2 is not None else getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)
             pres.append(gemm_nt(xt, ops._f32c(wi), bias, bf16=True).view(steps, bsz, 4 * h))
-            hs2.append(torch.zeros((2, bsz, h), dtype=torch.float32, device=x.device))
-            cs2.append(torch.zeros((bsz, h), dtype=torch.float32, device=x.device))
+            hs2.append(state[d, :2])
+            cs2.append(state[d, 2])
         two = _native.c_p * 2
         whp = two(whh[""].data_ptr(), whh["_reverse"].data_ptr())
         cp = two(cs2[0].data_ptr(), cs2[1].data_ptr())
@@ -289,6 +291,9 @@ class _Bf16Plan:
                               "afd_f32_to_bf16")
                 d[sfx] = wb
             self.whh.append(d)
+        # b_ih + b_hh per layer and direction, once (two launches per layer and step otherwise)
+        self.bias = [{sfx: (getattr(layer.l_blstm, "bias_ih_l0" + sfx) + getattr(layer.l_blstm, "bias_hh_l0" + sfx)).detach()
+                      for sfx in ("", "_reverse")} for layer in net.lstm]
 
 
 class LCNN(nn.Module):
@@ -395,7 +400,7 @@ class LCNN(nn.Module):
                 cur, h, w = z, h // 2, w // 2
         seq = cur.reshape(n, h, -1)  # [B, T', W' C] fp32 (dropout is the identity in evaluation mode)
         for li, layer in enumerate(self.lstm):
-            seq = blstm_forward_bf16(seq, layer.l_blstm, plan.wih0 if li == 0 else None, plan.whh[li])
+            seq = blstm_forward_bf16(seq, layer.l_blstm, plan.wih0 if li == 0 else None, plan.whh[li], plan.bias[li])
         return ops.linear_mean(seq, self.fc.weight, self.fc.bias)
 
     def get_name(self) -> str:
