@@ -156,6 +156,8 @@ dilconv_direct_kernel(const DirGeom g, const float* __restrict__ in, const float
 // offsets are huge unsigned ones) write ZERO (tools/micro/buf_lds.hip checks exactly this on the hardware), so the
 // zero halo costs no vector instruction; bytes = 0 clears the row.  Inline assembly because the compiler, which cannot
 // tell LDS-DMA destinations from other LDS data, would otherwise wait for ALL loads in flight before every LDS read.
+// (m0 is a reserved register to the compiler: it writes it immediately before each of its own uses and keeps nothing
+// in it across statements, so the block may overwrite it -- naming it as a clobber only draws a warning.)
 typedef int i4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void row_to_lds(const float* base, int bytes, unsigned lds_addr, int voff) {
     const unsigned long long b = (unsigned long long)base;
