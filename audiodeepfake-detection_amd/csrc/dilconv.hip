@@ -383,16 +383,24 @@ int launch_wgrad(const DirGeom& g, const float* x, const float* dy, float* parti
         reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
         (int)lds);
     if (attr != hipSuccess) return afd::fail(AFD_ERR_HIP, "dilconv wgrad: %zu bytes of LDS refused", lds);
+    // ablation runs (AFD_DILW_ABL = 1: no loads, 2: no arithmetic; the time of each part is quoted in DESIGN.md)
     static const int abl = [] { const char* e = getenv("AFD_DILW_ABL"); return e ? atoi(e) : 0; }();
     if (abl && C == 3) {
+        hipError_t e;
         if (abl == 1) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS, 1>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy, partial, ntiles);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS, 1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS, 1>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy,
+                                   partial, ntiles);
         } else {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS, 2>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy, partial, ntiles);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS, 2>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy,
+                                   partial, ntiles);
         }
-        return 0;
+        return e == hipSuccess ? 0 : afd::fail(AFD_ERR_HIP, "dilconv wgrad (ablation): %s", hipGetErrorString(e));
     }
     hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy, partial,
                        ntiles);
