@@ -259,6 +259,15 @@ class Trainer:
                 acc = (out.argmax(-1) == labels).sum().item() / self.args.batch_size
             self.loss_list.append([self.step_total, e, lv])
             self.accuracy_list.append([self.step_total, e, acc])
+            self._scalars({"loss/train": lv, "accuracy/train": acc})
+
+    def _scalars(self, values: dict) -> None:
+        """The reference's TensorBoard scalars (:879-883, :936-943, :991-995) when a writer was given: same tags,
+        the lead rank only, x = step_total.  (The reference's add_graph of the first step is not reproduced.)"""
+        if self.writer is None or not is_lead(self.args):
+            return
+        for tag, v in values.items():
+            self.writer.add_scalar(tag, float(v), self.step_total)
 
     def _run_epoch(self, epoch: int) -> None:
         sampler = getattr(self.train_data_loader, "sampler", None)
@@ -458,6 +467,7 @@ class Trainer:
         if self.cross_loader_test is not None:
             cross_acc, cross_eer = self.val_test_loop(self.cross_loader_test, name="test unknown")
         self.test_results = (acc, eer, cross_acc, cross_eer)
+        self._scalars({"accuracy/test": acc, "eer/test": eer, "accuracy/cross_test": cross_acc, "eer/cross_test": cross_eer})
         return self.test_results
 
     def _run_validation(self, epoch: int) -> None:
@@ -466,6 +476,9 @@ class Trainer:
         if self.cross_loader_val is not None:
             entry += list(self.val_test_loop(self.cross_loader_val, name="val unknown"))
         self.validation_list.append(entry)
+        cr = entry[4:6] if len(entry) >= 6 else [0, 0]
+        self._scalars({"accuracy/validation": acc, "eer/validation": eer, "accuracy/cross_validation": cr[0],
+                       "eer/cross_validation": cr[1], "epochs": epoch})
 
     # -- snapshots ------------------------------------------------------------------------
     def _save_snapshot(self, epoch: int) -> None:
@@ -494,6 +507,35 @@ class Trainer:
                 self.testing()
 
 
+def loss_less_flag(args: DotDict) -> bool:
+    """The sign-channel switch as the reference reads its string flag (:1167): everything but "False" is on.  One
+    derivation for the model's input channels, the snapshot name and the writer directory."""
+    return False if args.loss_less == "False" else True
+
+
+def make_writer(args: DotDict, model_name: str):
+    """`--tensorboard`: a SummaryWriter on the reference's directory layout (:1271-1291), lead rank only.  The
+    tensorboard package is an optional dependency: without it the flag is refused loudly instead of being dropped."""
+    if not args.tensorboard or not is_lead(args):
+        return None
+    try:
+        from torch.utils.tensorboard import SummaryWriter
+    except Exception as err:  # ImportError, or tensorboard's own import-time failures
+        import warnings
+        warnings.warn(f"--tensorboard given but torch.utils.tensorboard is not importable ({err}): "
+                      "no scalars will be written; the loss / accuracy lists and the printed summary are unaffected",
+                      RuntimeWarning, stacklevel=2)
+        return None
+    only_use = list(args.only_use or ["all"])
+    known = only_use[1] if len(only_use) > 1 else only_use[-1]
+    wav = f"{args.wavelet}/" if args.transform == "packets" else ""
+    path = (f"{args.log_dir}/tensorboard/{model_name}/{args.transform}/{wav}{args.features}/"
+            f"{args.batch_size}_{args.learning_rate}_{args.weight_decay}_{args.epochs}/{args.f_min}-{args.f_max}/"
+            f"{args.num_of_scales}/signs{loss_less_flag(args)}/augc{args.aug_contrast}/augn{args.aug_noise}/"
+            f"power{args.power}/{known}/{args.seed}")
+    return SummaryWriter(path, max_queue=100)
+
+
 def snapshot_name(args: DotDict, model) -> str:
     """Snapshot file stem exactly as the reference composes it (:1162, :1221-1267), so that `--only-testing` /
     `--only-ig` find files written by the reference or by earlier runs: `path_name = basename(data_prefix).split("_")`
@@ -502,12 +544,13 @@ def snapshot_name(args: DotDict, model) -> str:
     augmentation flags are written as given.  Where the reference would raise IndexError (a prefix with fewer
     than four fields, fewer than two sources) the field is left out / the last source is used."""
     tr = "stft" if args.transform == "stft" else "packets" + str(args.wavelet)
-    name = model.get_name() if hasattr(model, "get_name") else "customModel"
+    # the reference asks the model for its name only for --model modules (:1197); LCNN / grid models are "customModel"
+    name = model.get_name() if args.model == "modules" and hasattr(model, "get_name") else "customModel"
     path_name = str(args.data_prefix or "fake").rstrip("/").split("/")[-1].split("_")
     only_use = list(args.only_use or ["all"])
     src = only_use[1] if len(only_use) > 1 else only_use[-1]
     ratio = f"{path_name[3]}_" if len(path_name) > 3 else ""
-    loss_less = False if args.loss_less == "False" else True
+    loss_less = loss_less_flag(args)
     return (f"{path_name[0]}_{tr}_{args.features}_{args.hop_length}_{args.sample_rate}_{args.window_size}_"
             f"{args.num_of_scales}_{int(args.f_min or 0)}-{int(args.f_max or 0)}_{ratio}{args.learning_rate}_"
             f"{args.weight_decay}_{args.batch_size}_{args.nclasses}_{args.epochs}e_{name}_"
@@ -550,7 +593,7 @@ def main() -> None:
         transforms, normalize = get_transforms(args, args.features, device, args.calc_normalization,
                                                pbar=args.pbar, verbose=is_lead(args))
         args.input_dim = get_input_dims(args, transforms)
-        in_channels = 2 if args.loss_less == "True" else 1
+        in_channels = 2 if loss_less_flag(args) else 1
         model = get_model(args, args.model, args.nclasses, in_channels, is_lead(args))
         train_loader, val_loader, test_loader, cross_val, cross_test = create_data_loaders(
             args, limit=args.batch_size * (args.synthetic_steps or 8))
@@ -559,8 +602,9 @@ def main() -> None:
         loss_fun = ops.CrossEntropyLoss()
         os.makedirs(os.path.join(args.log_dir, "models"), exist_ok=True)
         snap = os.path.join(args.log_dir, "models", snapshot_name(args, model))
+        model_name = model.get_name() if args.model == "modules" and hasattr(model, "get_name") else "customModel"
         trainer = Trainer(snap, args, normalize, transforms, test_loader, model, train_loader,
-                          val_loader, cross_val, cross_test, optimizer, loss_fun, None)
+                          val_loader, cross_val, cross_test, optimizer, loss_fun, make_writer(args, model_name))
         if args.only_testing:
             # evaluate an existing snapshot on the cross-source test set (reference :1313-1316)
             trainer._check_model_init()
@@ -571,7 +615,7 @@ def main() -> None:
             trainer._check_model_init()
             trainer.load_snapshot(trainer.snapshot_path)
             tag = (f"{args.transform}_{args.sample_rate}_{args.seconds}_{args.seed}_"
-                   f"{(args.only_use or ['all'])[-1]}_{args.wavelet}_{args.power}_{args.loss_less == 'True'}")
+                   f"{(args.only_use or ['all'])[-1]}_{args.wavelet}_{args.power}_{loss_less_flag(args)}")
             trainer.integrated_gradients(tag)
         else:
             trainer.train(args.epochs)

@@ -485,6 +485,7 @@ int dilconv_forward(const float* x, const float* w, const float* bias, float* y,
     g.Hout = H + 2 * pad - dil * (K - 1);
     g.Wout = W + 2 * pad - dil * (K - 1);
     afd::ScopedTiming timing(AFD_K_CONV_DIRECT, 2.0 * N * C * C * K * K * (double)g.Hout * g.Wout, s);
+    timing.bytes(4.0 * N * C * ((double)H * W + (double)g.Hout * g.Wout));  // x once, y once
     return dispatch_c(C, 0, K, dil, g, x, w, bias, y, nullptr, nullptr, s);
 }
 
@@ -499,6 +500,7 @@ int dilconv_backward_data(const float* dy, const float* w, float* dx, int N, int
     g.Hout = H;
     g.Wout = W;
     afd::ScopedTiming timing(AFD_K_CONV_DIRECT, 2.0 * N * C * C * K * K * (double)g.Hin * g.Win, s);
+    timing.bytes(4.0 * N * C * ((double)H * W + (double)g.Hin * g.Win));  // dy once, dx once
     return dispatch_c(C, 1, K, dil, g, dy, w, nullptr, dx, nullptr, nullptr, s);
 }
 
@@ -513,6 +515,7 @@ int dilconv_backward_weight(const float* x, const float* dy, float* dw, float* d
     g.Hout = H + 2 * pad - dil * (K - 1);
     g.Wout = W + 2 * pad - dil * (K - 1);
     afd::ScopedTiming timing(AFD_K_CONV_DIRECT, 2.0 * N * C * C * K * K * (double)g.Hout * g.Wout, s);
+    timing.bytes(4.0 * N * C * ((double)H * W + (double)g.Hout * g.Wout));  // x once, dy once
     return dispatch_c(C, 2, K, dil, g, x, dy, nullptr, dw, dbias, static_cast<float*>(ws), s);
 }
 

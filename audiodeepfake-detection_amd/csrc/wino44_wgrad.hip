@@ -506,6 +506,10 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
         if (cand >= 1 && cand <= max_s) S = cand;
     }
     if (!S) S = max_s;
+    // never more splits than the workspace bound holds slabs for (wino44_wgrad_workspace_floats: with more channel
+    // groups than workgroups aimed at, every candidate above is 0 and max_s could pass it)
+    const long smax = target_wgs() / cgroups > 0 ? target_wgs() / cgroups : 1;
+    if (S > smax) S = smax;
     long ups = (g.units + S - 1) / S;
     ups += ups & 1;
     g.units_per_split = ups;
@@ -557,7 +561,9 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     if (!wino44_wgrad_crop_ok(H, W, dy_rows, dy_cols) || g.units >= 0x7fffffffL)
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd backward-weight: image %d x %d, crop %d x %d", H, W, dy_rows, dy_cols);
     const size_t m = (size_t)kPos * Cout * Cin;
-    if (!ws || ws_bytes < wino44_wgrad_workspace_floats(N, Cin, H, W, Cout, dy_rows, dy_cols) * sizeof(float))
+    // the bound the caller sized the workspace by, and what this launch writes: S slabs + the reduced M + bias partials
+    if (!ws || ws_bytes < wino44_wgrad_workspace_floats(N, Cin, H, W, Cout, dy_rows, dy_cols) * sizeof(float) ||
+        ws_bytes < ((size_t)g.S * m + m + (size_t)g.S * 2 * Cout) * sizeof(float))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd backward-weight: workspace too small");
     g.slab = static_cast<float*>(ws);
     float* red = g.slab + (size_t)g.S * m;

@@ -26,6 +26,9 @@ Extra objects on the JSON line:
   frontend_only the front-end-only workloads (Haar level 14 at B = 4096 = BASELINE configs[3]; coif4 / sym5 level 14 at
                 B = 128 and 4096) measured in the same process after the timed region: ms per transform, GB/s,
                 fraction of the HBM peak.  Default workload, single process only.
+  secondary     the other BASELINE configurations (sym5 level 14, the level-8 models, STFT + DCNN, STFT + LCNN bf16
+                evaluation) measured in the same process after the timed region: ms/step, frames/s, dominant kernel
+                class and its fraction of the bounding roof.  Default workload, single process only.
   end_to_end    the same step fed by NativeFrameLoader from WAV files on disk (host-to-device copy included), after
                 the timed region: shows that `value` survives a real input path.  Never `value` itself.
   cpu_baseline  oracle/torch_ref.py (the reference's algorithm on torch CPU: per-node packet
@@ -81,13 +84,29 @@ MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv_wgrad_1x1", "
 CLASS_KERNELS = {
     "conv_igemm": ("conv3x3_kernel", "conv1x1_kernel", "conv_igemm_kernel"),
     "conv_winograd": ("wino_conv_kernel", "wino16_conv_kernel", "wino44_conv_kernel"),
-    "conv_wgrad": ("wgrad3x3_kernel", "wgrad3x3p_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
+    "conv_wgrad": ("wino44_wgrad_kernel", "wino44_wgrad_reduce_kernel", "wino44_wgrad_g_kernel", "wgrad3x3_kernel",
+                   "wgrad3x3p_kernel", "wgrad_reduce_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
+    "conv_direct": ("dilconv_direct_kernel", "dilconv_wgrad_kernel", "dilconv_reduce_kernel"),
     "conv_wgrad_1x1": ("conv1x1_wgrad_kernel", "conv1x1_fused_bwd_kernel"),
     "wpt": ("wpt2_deep_mfma_kernel", "wpt2_deep_kernel", "wpt2_top_kernel", "wpt_fused_kernel",
             "wpt_haar14_kernel", "wpt3_kernel", "wpt3_top_kernel", "wpt3_deep_kernel"),
     "stft": ("stft_mfma_kernel",),
     "lcnn_bf16": ("lcnn_conv_nhwc_kernel", "lcnn_conv1_kernel", "gemm_nt_bf16_kernel", "conv_bf16_kernel"),
 }
+
+
+WAVELET_TAPS = {"haar": 2, "sym5": 10, "coif4": 24}
+
+
+def wpt_direct_flops(wavelet: str, level: int, n: int = 22050) -> float:
+    """Direct-form flops of one frame's packet transform: 2 L per filter output, outputs of
+    level k = 2^k nodes of length n_k, n_k = floor((n_{k-1} + L - 2 + (n_{k-1} odd)) / 2)."""
+    taps = WAVELET_TAPS[wavelet]
+    outputs = 0
+    for k in range(1, level + 1):
+        n = (n + taps - 2 + (n & 1)) // 2
+        outputs += (1 << k) * n
+    return 2.0 * taps * outputs
 
 
 def log(msg: str) -> None:
@@ -196,21 +215,22 @@ def host_cores() -> int:
     return max(1, min(allowed, physical))
 
 
-def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 10, threads: int = 0):
+def cpu_baseline(workload: str, step_frames: int, fe_frames: int = 128, steps: int = 3, fe_batches: int = 10,
+                 threads: int = 0, fe_budget_s: float = 30.0):
     """The reference's algorithm on torch CPU (oracle 'port') on a bounded sample of the workload, by the
-    protocol of BASELINE.md section 3: >= 10 timed front-end batches and 1 untimed + >= 3 timed train steps,
-    medians; frames/s = B_cpu / (front end + step).  Threads: `threads`, default one GPU's share of the node's
-    physical cores (16 of 128 on the MI355X box -- the job is one of eight per node).  All 128 cores were
-    measured SLOWER on this workload (round 3, B = 1: front end 20.5 s against 2.6 s per frame with 16 threads --
-    16 383 pad / conv1d / Welford node updates on tensors of 24-11 036 floats are bound by per-op overhead, which
-    grows with the thread-pool size; `--cpu-threads 0` uses every physical core).
+    protocol of BASELINE.md section 3: timed front-end batches AT THE PROTOCOL'S B = 128 and 1 untimed + >= 3 timed
+    train steps, medians; frames/s = 1 / (front end per frame + step per frame).
 
-    Front end: batches of `frames` full frames through the per-node pad + conv1d recursion with the per-node
-    Welford updates left on, as the reference runs it (wavelet_math.py:182-206), + log + normalise.
-    Train workloads add the FULL-WIDTH DCNN step (forward, cross entropy, backward, Adam with coupled L2).
-    BASELINE.md asks for B = 128; one level-14 frame is 64 GFLOP of fp32 convolutions plus 16 384
-    pad/conv/Welford node updates (~2.5 s per frame on 16 threads, linear in the frames), so the batch is cut
-    to `frames` of 128 frames to keep the default bench run within minutes -- the figure is frames/s either way.
+    Front end: batches of `fe_frames` (128) full frames through the per-node pad + conv1d recursion with the per-node
+    Welford updates left on, as the reference runs it (wavelet_math.py:182-206), + log + normalise.  The 16 383 node
+    updates of a level-14 transform are bound by per-op overhead, so a batch of 128 costs about what a batch of 1
+    does (round 3 timed B = 1 and understated the host by that factor): up to `fe_batches` batches, at least 3, cut
+    when `fe_budget_s` seconds are used so the default run stays within minutes; the count is on the line.
+    Train workloads add the FULL-WIDTH DCNN step (forward, cross entropy, backward, Adam with coupled L2) at
+    B = `step_frames`: one level-14 frame is 64 GFLOP of fp32 convolutions (~0.3 s on 16 threads, linear in the
+    frames -- the convolutions are compute-bound on the host, so the per-frame time does not depend on B).
+    Threads: `threads`, default one GPU's share of the node's physical cores (16 of 128 on the MI355X box -- the job
+    is one of eight per node); `--cpu-threads 0` uses every physical core.
     """
     import statistics
 
@@ -221,37 +241,40 @@ def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 1
     cores = physical if threads == 0 else max(1, min(threads, physical))
     torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(99)
-    x = (0.1 * torch.randn(frames, 1, 22050, generator=g)).clamp_(-1, 1)
-    labels = torch.randint(0, 2, (frames,), generator=g)
+    x = (0.1 * torch.randn(fe_frames, 1, 22050, generator=g)).clamp_(-1, 1)
     level = scales.bit_length() - 1
 
-    def front_end():
+    def front_end(xx):
         if transform == "packets":
-            feats, _ = torch_ref.packets_torch(x, wpt_oracle.TAPS[wavelet], level, log_scale=True,
+            feats, _ = torch_ref.packets_torch(xx, wpt_oracle.TAPS[wavelet], level, log_scale=True,
                                                compute_welford=True, per_node=True)
         else:
-            feats = torch_ref.stft_torch(x, 2 * scales - 1, 220, log_scale=True)
+            feats = torch_ref.stft_torch(xx, 2 * scales - 1, 220, log_scale=True)
         return torch_ref.normalize_torch(feats, 0.0, 1.0)
 
     fe_times = []
-    for _ in range(fe_batches):
+    t_begin = time.perf_counter()
+    while len(fe_times) < fe_batches:
         t0 = time.perf_counter()
-        feats = front_end()
+        feats = front_end(x)
         fe_times.append(time.perf_counter() - t0)
+        if len(fe_times) >= 3 and time.perf_counter() - t_begin > fe_budget_s:
+            break
     t_fe = statistics.median(fe_times)
-    log(f"cpu baseline: front end {t_fe:.2f} s per batch of {frames} frame(s) ({cores} threads, {fe_batches} batches)")
-    sample = (f"B = {frames} of 128 frames of the same workload on {cpu_model()}, {cores} torch threads "
-              f"(one GPU's share of the host's {physical} physical cores; all {physical} measured slower, "
-              f"see bench.py cpu_baseline): front end "
-              f"{t_fe:.2f} s per batch (median of {fe_batches} timed batches; per-node pad+conv1d recursion, "
-              f"Welford on)")
-    total = t_fe
+    log(f"cpu baseline: front end {t_fe:.2f} s per batch of {fe_frames} frames ({cores} threads, {len(fe_times)} batches)")
+    sample = (f"{cpu_model()}, {cores} torch threads (one GPU's share of the host's {physical} physical cores): "
+              f"front end B = {fe_frames} frames, {t_fe:.2f} s per batch (median of {len(fe_times)} timed batches; "
+              f"per-node pad+conv1d recursion, Welford on)")
+    per_frame = t_fe / fe_frames
+    out = {"front_end_batch": fe_frames, "front_end_s_per_batch": t_fe, "front_end_batches_timed": len(fe_times)}
     if kind == "train" and "lcnn" not in workload:
-        packets = feats.shape[2]
-        net = torch_ref.DCNNRef(feats.shape, time_dim_add=add, flattend_size=40 * (packets // 8 - 24))
+        fc = feats[:step_frames].contiguous()
+        del feats
+        labels = torch.randint(0, 2, (step_frames,), generator=g)
+        packets = fc.shape[2]
+        net = torch_ref.DCNNRef(fc.shape, time_dim_add=add, flattend_size=40 * (packets // 8 - 24))
         opt = torch.optim.Adam(net.parameters(), lr=4e-4, weight_decay=1e-3)
         net.train()
-        fc = feats.contiguous()
         torch_ref.train_step_torch(net, opt, fc, labels)  # untimed: allocator / oneDNN primitive warm-up
         st_times = []
         for _ in range(steps):
@@ -259,12 +282,14 @@ def cpu_baseline(workload: str, frames: int, steps: int = 3, fe_batches: int = 1
             torch_ref.train_step_torch(net, opt, fc, labels)
             st_times.append(time.perf_counter() - t1)
         t_step = statistics.median(st_times)
-        total += t_step
-        sample += (f" + full-width DCNN forward/backward/Adam {t_step:.2f} s per step "
-                   f"(median of {steps} timed steps after 1 untimed)")
+        per_frame += t_step / step_frames
+        sample += (f" + full-width DCNN forward/backward/Adam B = {step_frames} frames, {t_step:.2f} s per step "
+                   f"(median of {steps} timed steps after 1 untimed); frames/s = 1 / (front end per frame + step per frame)")
+        out.update({"step_batch": step_frames, "step_s": t_step})
     elif kind != "frontend":
         sample += "; model step not timed on the CPU for this workload"
-    return {"value": frames / total, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample}
+    out.update({"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port", "sample": sample})
+    return out
 
 
 def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads: int = 16):
@@ -347,10 +372,77 @@ def frontend_lines(device, _native, launches: int = 20):
         _native.timing_reset()
         ms = k["total_ms"] / launches
         gbs = k["work"] / (k["total_ms"] * 1e-3) / 1e9
+        flops = wpt_direct_flops(WORKLOADS[name][1], WORKLOADS[name][2].bit_length() - 1)
         out.append({"workload": WORKLOADS[name][5], "batch": batch, "ms_per_transform": ms,
                     "frames_per_s": batch / (ms * 1e-3), "achieved_GBps": gbs, "frac_of_hbm_peak": gbs / PEAK_HBM_GBS,
-                    "algorithmic_bytes_per_frame": k["work"] / launches / batch})
+                    "algorithmic_bytes_per_frame": k["work"] / launches / batch,
+                    # the other roof: direct-form filter arithmetic over the f32 peak (vector FMA and MFMA alike)
+                    "direct_form_flops_per_frame": flops,
+                    "frac_of_f32_peak": flops * batch / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS})
         del x, transforms
+        torch.cuda.empty_cache()
+    return out
+
+
+def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3):
+    """The other BASELINE configurations measured in this same process after the timed region, so that the driver's
+    own run of the default command records them: configs[2] per GPU (packets-sym5 level 14), the level-8 models the
+    reference ships (coif4, sym5), configs[0] (STFT + DCNN) and configs[4] (STFT + LCNN evaluation, bf16 matrix
+    products).  Per workload: `steps` steps after `warmup` untimed ones, wall clock between device synchronisations;
+    then two instrumented steps for the dominant kernel class and its fraction of the roof that bounds it.
+    Never `value`."""
+    import gc
+
+    out = []
+    for name in ("sym5-l14", "coif4-l8", "sym5-l8", "stft", "stft-lcnn-eval-bf16"):
+        kind = WORKLOADS[name][4]
+        try:
+            torch.manual_seed(0)
+            args, trainer, _ = build(name, 128, False, device)
+            batch = synthetic_batch(128, rank, device)
+            correct = torch.zeros((), dtype=torch.float64, device=device)
+            if kind == "eval":
+                trainer.model.eval()
+            else:
+                trainer.model.train()
+
+            def step():
+                if kind == "train":
+                    trainer._run_batch(0, batch)
+                else:
+                    with torch.no_grad():
+                        o = trainer.model(trainer._features(batch["audio"]))
+                        correct.add_((o.argmax(-1) == (batch["label"] != 0)).sum())
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / steps
+            _native.timing_reset()
+            _native.timing_enable(True)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            _native.timing_enable(False)
+            kernels = collect(_native)
+            _native.timing_reset()
+            cand = [k for k in kernels if k == "wpt" or k in MFMA_CLASSES]
+            dom = max(cand, key=lambda k: kernels[k]["total_ms"])
+            r = roofline_of(dom, kernels[dom], 2, load_pmc(name, 128))
+            out.append({"workload": WORKLOADS[name][5], "batch": 128, "steps": steps, "warmup": warmup, "ms_per_step": ms,
+                        "frames_per_s": 128 / (ms * 1e-3), "dtype": "bf16" if name.endswith("bf16") else "f32",
+                        "dominant_class": dom, "dominant_class_ms_per_step": kernels[dom]["total_ms"] / 2,
+                        "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                        "frac": r["frac"],
+                        "classes_ms_per_step": {k: round(v["total_ms"] / 2, 4) for k, v in kernels.items()}})
+            del trainer, batch, args
+        except Exception as exc:  # noqa: BLE001 - the headline figure does not depend on this leg
+            out.append({"workload": WORKLOADS[name][5], "error": f"{type(exc).__name__}: {exc}"})
+        gc.collect()
         torch.cuda.empty_cache()
     return out
 
@@ -428,11 +520,15 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=None, help="frames per GPU (default 128; 4096 for haar-l14-frontend)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="coif4-l14")
-    ap.add_argument("--cpu-frames", type=int, default=1, help="CPU baseline batch, B_cpu of 128 frames (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=8,
+                    help="CPU baseline: frames per DCNN train step on the host (0 = skip the whole CPU leg)")
+    ap.add_argument("--cpu-fe-frames", type=int, default=128, help="CPU baseline: frames per front-end batch (protocol: 128)")
     ap.add_argument("--cpu-threads", type=int, default=CPU_SHARE_PER_GPU,
                     help="torch threads of the CPU baseline (0 = every physical core)")
     ap.add_argument("--no-frontends", dest="frontends", action="store_false",
                     help="skip the front-end-only measurements appended to the default workload's line")
+    ap.add_argument("--no-secondary", dest="secondary", action="store_false",
+                    help="skip the other BASELINE configurations appended to the default workload's line")
     ap.add_argument("--e2e-steps", type=int, default=10,
                     help="steps of the end-to-end leg (WAV files -> loader -> H2D -> train step; 0 = skip)")
     ap.add_argument("--cpu-only", action="store_true", help="only run the CPU baseline leg")
@@ -443,7 +539,7 @@ def main() -> None:
     kind = WORKLOADS[a.workload][4]
 
     if a.cpu_only:
-        print(json.dumps(cpu_baseline(a.workload, max(1, a.cpu_frames), threads=a.cpu_threads)), flush=True)
+        print(json.dumps(cpu_baseline(a.workload, max(1, a.cpu_frames), a.cpu_fe_frames, threads=a.cpu_threads)), flush=True)
         return
     launched = "WORLD_SIZE" in os.environ  # under torch.distributed.run (the driver's N > 1 form)
     if not launched and (a.gpus > 1 or a.spawn):
@@ -573,6 +669,11 @@ def main() -> None:
                                            f"{f['frac_of_hbm_peak']:.3f}" for f in fe_lines))
         except Exception as exc:  # noqa: BLE001 - the headline figure does not depend on this leg
             fe_lines = [{"error": f"{type(exc).__name__}: {exc}"}]
+    secondary = None
+    if a.workload == "coif4-l14" and world == 1 and a.secondary:
+        secondary = secondary_lines(device, _native, rank)
+        log("secondary: " + "; ".join(f"{f['workload']}: {f['ms_per_step']:.3f} ms" if "ms_per_step" in f else
+                                      f"{f['workload']}: {f['error']}" for f in secondary))
     e2e = None
     # (single-process runs only: with several ranks a failure of this leg on one rank would leave the others
     # waiting in a collective)
@@ -585,7 +686,7 @@ def main() -> None:
     cpu = None
     log(f"kernel classes (ms/step): { {k: round(v['ms_per_step'], 3) for k, v in classes.items()} }")
     if rank == 0 and world == 1 and a.cpu_frames > 0 and kind != "eval":
-        cpu = cpu_baseline(a.workload, a.cpu_frames, threads=a.cpu_threads)
+        cpu = cpu_baseline(a.workload, a.cpu_frames, a.cpu_fe_frames, threads=a.cpu_threads)
         log(f"cpu baseline: {cpu['value']:.4f} frames/s")
 
     devices = [torch.cuda.get_device_name(device)]
@@ -612,7 +713,7 @@ def main() -> None:
                        "optimizer": "Adam lr 4e-4 wd 1e-3" if kind == "train" else None,
                        "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "frontend": frontend, "end_to_end": e2e,
-            "frontend_only": fe_lines,
+            "frontend_only": fe_lines, "secondary": secondary,
             "world": {"size": world, "backend": "rccl (torch.distributed nccl)" if ddp else None,
                       "rccl_version": rccl, "devices": devices,
                       "collectives": "gradient arena all-reduce + packed SyncBN statistics" if ddp and kind == "train" else None},

@@ -42,15 +42,25 @@ def _check_contract(d, steps, warmup):
 @pytest.mark.parametrize("workload", ["sym5-l8", "coif4-l14"])
 def test_bench_line_has_the_contract_fields(workload):
     """The headline workload (coif4-l14) included: its roofline must be a fraction of the peak."""
-    d = _run("--workload", workload, "--steps", "2", "--warmup", "2", "--cpu-frames", "1")
+    d = _run("--workload", workload, "--steps", "2", "--warmup", "2", "--cpu-frames", "1", "--cpu-fe-frames", "2")
     r = _check_contract(d, 2, 2)
     assert r["bound"] == "mfma" and r["algorithmic_TFLOPs"] > 0
     # every matrix-core class reports an issued-flops fraction below the peak
     for name, c in d["classes"].items():
         if "mfma_frac" in c:
             assert 0.0 < c["mfma_frac"] <= 1.0, (name, c)
+    # no hole on the line: every class states its algorithmic bytes, and when a committed counter summary exists for
+    # the workload every class whose kernels the summary knows has its HBM traffic beside them
+    for name, c in d["classes"].items():
+        assert c["algorithmic_bytes_per_step"] > 0, (name, c)
+        assert c.get("mfma_frac") or c.get("achieved_GBps"), (name, c)
+    if r.get("traffic_source"):
+        assert r["traffic"] and r["traffic"] > 0
+        for name, c in d["classes"].items():
+            assert c["hbm_bytes_per_step_pmc"] and c["hbm_bytes_per_step_pmc"] > 0, (name, c)
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["front_end_batch"] == 2 and c["step_batch"] == 1
     assert "cropped" not in c["sample"] and "scaled" not in c["sample"]
     # the same step fed from WAV files through the native loader (host-to-device copy included)
     e = d["end_to_end"]
@@ -60,16 +70,22 @@ def test_bench_line_has_the_contract_fields(workload):
         fe = {(f["workload"], f["batch"]): f for f in d["frontend_only"]}
         haar = fe[("packets-haar level-14 front end only", 4096)]
         assert haar["algorithmic_bytes_per_frame"] == 4 * (22050 + 32768) and 0.3 < haar["frac_of_hbm_peak"] <= 1.0
-        assert all(0.0 < f["frac_of_hbm_peak"] <= 1.0 for f in d["frontend_only"])
+        assert all(0.0 < f["frac_of_hbm_peak"] <= 1.0 and 0.0 < f["frac_of_f32_peak"] <= 1.0 for f in d["frontend_only"])
+        # and so do the other BASELINE configurations (configs[0], [2], [4] and the shipped level-8 models)
+        sec = {f["workload"]: f for f in d["secondary"]}
+        assert len(sec) == 5 and not any("error" in f for f in d["secondary"]), d["secondary"]
+        for f in d["secondary"]:
+            assert f["ms_per_step"] > 0 and 0.0 < f["frac"] <= 1.0 and f["dominant_class"], f
+        assert sec["STFT(n_fft 511, hop 220) + LCNN eval forward (bf16 matrix products)"]["dtype"] == "bf16"
     else:
-        assert d["frontend_only"] is None
+        assert d["frontend_only"] is None and d["secondary"] is None
 
 
 def test_frontend_workload_line():
     """BASELINE configs[3] (Haar level 14, front end only) at a reduced batch: HBM-bound roofline
     from >= 20 timed launches."""
     d = _run("--workload", "haar-l14-frontend", "--batch", "256", "--steps", "5", "--warmup", "2",
-             "--cpu-frames", "1")
+             "--cpu-frames", "1", "--cpu-fe-frames", "2")
     r = _check_contract(d, 5, 2)
     assert r["bound"] == "hbm" and r["kernel"] == "wpt"
     assert d["frontend"]["launches_timed"] >= 20

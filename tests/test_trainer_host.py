@@ -273,10 +273,61 @@ def test_snapshot_name_reproduces_the_reference_file_names():
                 window_size=22050, num_of_scales=256, f_min=1, f_max=11025, learning_rate=0.0004,
                 weight_decay=0.001, batch_size=128, nclasses=2, epochs=10, loss_less="False", aug_contrast=False,
                 aug_noise=False, power=2.0, only_use=["ljspeech", "fbmelgan"], seconds=1, seed=0,
-                data_prefix="/p/data/model_22050_22050_0.7_fbmelgan")
+                data_prefix="/p/data/model_22050_22050_0.7_fbmelgan", model="modules")
     assert snapshot_name(a, M()) == ("model_packetssym5_none_220_22050_22050_256_1-11025_0.7_0.0004_0.001_128_2_10e_"
                                      "DCNN_signsFalse_augcFalse_augnFalse_power2.0_fbmelgan_1secs_0")
     a.transform = "stft"
     assert snapshot_name(a, M()).startswith("model_stft_none_220_")
+    # --model lcnn: the reference writes "customModel" whatever the class calls itself (train_classifier.py:1197)
+    a.model = "lcnn"
+    assert "_10e_customModel_signsFalse_" in snapshot_name(a, M())
+    a.model, a.loss_less = "modules", "True"
+    assert "_10e_DCNN_signsTrue_" in snapshot_name(a, M())
+    a.loss_less = "yes"  # anything but "False" switches the sign channel on (:1167)
+    assert "_signsTrue_" in snapshot_name(a, M())
+    a.loss_less = "False"
     a.data_prefix, a.only_use = "../data/fake", None  # the defaults: fields the reference could not index are left out
     assert snapshot_name(a, M()).startswith("fake_stft_none_220_22050_22050_256_1-11025_0.0004_")
+
+
+def test_tensorboard_scalars_use_the_reference_tags():
+    """With a writer the trainer emits the reference's scalars (train_classifier.py:879-883, :936-943, :991-995);
+    `--tensorboard` without the tensorboard package warns instead of being dropped silently."""
+    import warnings
+
+    from audiofakedetect import train_classifier as tc
+    from audiofakedetect.utils import DotDict
+
+    class W:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, v, step):
+            self.rows.append((tag, v, step))
+
+    t = tc.Trainer.__new__(tc.Trainer)
+    t.args = DotDict(ddp=False)
+    t.writer = W()
+    t.step_total = 7
+    t._scalars({"loss/train": 0.5, "accuracy/train": 0.75})
+    assert t.writer.rows == [("loss/train", 0.5, 7), ("accuracy/train", 0.75, 7)]
+    t.val_data_loader, t.cross_loader_val, t.validation_list = object(), None, []
+    t.val_test_loop = lambda loader, name="": (0.9, 0.1)
+    t._run_validation(3)
+    tags = [r[0] for r in t.writer.rows[2:]]
+    assert tags == ["accuracy/validation", "eer/validation", "accuracy/cross_validation", "eer/cross_validation", "epochs"]
+    t.writer = None
+    t._scalars({"loss/train": 1.0})  # no writer: nothing to do
+
+    a = DotDict(tensorboard=True, ddp=False, log_dir="/tmp/x", transform="stft", wavelet="sym5", features="none",
+                batch_size=2, learning_rate=1e-3, weight_decay=0.0, epochs=1, f_min=1, f_max=2, num_of_scales=256,
+                loss_less="False", aug_contrast=False, aug_noise=False, power=2.0, only_use=None, seed=0)
+    try:
+        import torch.utils.tensorboard  # noqa: F401
+    except Exception:
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            assert tc.make_writer(a, "DCNN") is None
+        assert any("--tensorboard" in str(w.message) for w in rec)
+    a.tensorboard = False
+    assert tc.make_writer(a, "DCNN") is None

@@ -11,7 +11,7 @@ run() {  # name, bench flags...
   cp $O/line.json profiles/${tag}_${name}_line.json
   echo "$name done"
 }
-run bench_coif4l14_b128 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 --no-frontends &&
+run bench_coif4l14_b128 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 --no-frontends --no-secondary &&
 run bench_sym5l14_b128 --workload sym5-l14 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run bench_coif4l8_b128 --workload coif4-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run bench_stft_b128 --workload stft --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
