@@ -45,6 +45,11 @@ struct ScopedTiming {
     }
 };
 
+// wpt4.hip: levels 9..14 of the level-14 packet transform in lattice form (1 = not its case)
+int wpt4_deep(const float* ws, float* out, int B, const float* dec_lo, const float* dec_hi, int L, unsigned flags,
+              float power, float eps, float k1, float k0, float mean, float inv_std, float sgn_neg, float sgn_pos,
+              hipStream_t stream);
+
 // dilconv.hip: direct small-channel convolutions of the dilated stack (C = Cin = Cout <= 4)
 bool dilconv_applicable(int Cin, int Cout, int K, int dil);
 size_t dilconv_workspace_bytes(int C, int K);

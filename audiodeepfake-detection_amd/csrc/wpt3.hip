@@ -27,8 +27,7 @@
 //                  about as much as a matrix instruction (tools/micro), so operands are loaded once and
 //                  reused across as many instructions as the register file allows (2 waves per SIMD).
 //       Matrices are built on the host in double precision from the taps, once per wavelet and device.
-#include "afd_common.h"
-#include "../../include/afd_hip.h"
+#include "wpt_shared.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -37,46 +36,7 @@
 
 namespace {
 
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef float f16v __attribute__((ext_vector_type(16)));
-
-constexpr int kMaxTaps = 32;
-constexpr int kTopThreads = 1024;
-constexpr int kTopLdsFloats = 40960;  // 163 840 B: all of a CU's LDS
-constexpr int kKsMax = 8;
-
-struct Epi {
-    unsigned flags;
-    float power, eps, k1, k0, mean, inv_std, sgn_neg, sgn_pos;
-};
-
-__device__ __noinline__ float pow_log_slow3(float v, float power, float eps) {
-    return logf(powf(fabsf(v), power) + eps);
-}
-
-// log(|v|^power + eps) and (x - mean) / std.  The kernels are compiled per epilogue mode, so that an
-// element costs three vector instructions and no branch (the f32 matrix instructions and the vector ALU
-// share the SIMD's FMA lanes: every vector instruction is time the matrix stream does not get):
-//   EPI_RAW   v * k1 + k0                      (k1 = 1/std, k0 = -mean/std; 1, 0 without AFD_WPT_NORM)
-//   EPI_LOG2  log2(v*v + eps) * k1 + k0        (power == 2: v*v + eps >= 1e-12 is a normal float, the bare
-//             v_log_f32 needs no denormal pre-scaling; k1 = ln 2 / std)
-//   EPI_SLOW  any other power, library pow / log
-enum { EPI_RAW = 0, EPI_LOG2 = 1, EPI_SLOW = 2 };
-
-template <int MODE>
-__device__ __forceinline__ float epi_value(float v, const Epi& e) {
-    if (MODE == EPI_RAW) return fmaf(v, e.k1, e.k0);
-    if (MODE == EPI_LOG2) return fmaf(__builtin_amdgcn_logf(fmaf(v, v, e.eps)), e.k1, e.k0);
-    v = pow_log_slow3(v, e.power, e.eps);
-    if (e.flags & AFD_WPT_NORM) v = (v - e.mean) * e.inv_std;
-    return v;
-}
-
-inline int epi_mode(unsigned flags, float power) {
-    if (!(flags & AFD_WPT_LOG)) return EPI_RAW;
-    return power == 2.0f ? EPI_LOG2 : EPI_SLOW;
-}
+using namespace afd::wptc;
 
 // ------------------------------------------------------------------------------------------------
 // top levels
@@ -91,44 +51,6 @@ struct T3Params {
     unsigned magic[kKsMax + 1];  // floor(2^32 / m) + 1, m = (n[k] + 1) / 2 output pairs per node
     Epi e;
     float rlo[kMaxTaps], rhi[kMaxTaps];  // taps reversed: rlo[t] = dec_lo[L - 1 - t]
-};
-
-// one coefficient of a child node of length n: its own slot and the pad slots that mirror it
-template <int L>
-__device__ __forceinline__ void put(float* node, int i, int n, float v) {
-    constexpr int PAD = L - 2;
-    node[i] = v;
-    if ((unsigned)(i - 1) < (unsigned)PAD) node[-i] = v;
-    if ((unsigned)(n - 2 - i) < (unsigned)(PAD + (n & 1))) node[2 * (n - 1) - i] = v;
-}
-
-// A work item is a PAIR of neighbouring outputs (i, i + 1), i even: their windows share L - 2 of L samples,
-// so the item reads L + 2 samples as 16-byte vectors (7 ds_read_b128 for 24 taps, lanes 16 bytes apart:
-// conflict-free) and both filters run over registers.
-template <int L>
-struct Window {
-    static constexpr int NV = (L + 2 + 3) / 4;
-    float w[4 * NV];
-    __device__ __forceinline__ void load(const float* __restrict__ src) {
-        const f4* s4 = reinterpret_cast<const f4*>(src);
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const f4 x = s4[v];
-            w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
-        }
-    }
-    // filter `taps` (reversed) at output i (O = 0) or i + 1 (O = 1)
-    template <int O>
-    __device__ __forceinline__ float dot(const float* taps) const {
-        f2 acc = {0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < L / 2; ++t) {
-            const f2 tp = {taps[2 * t], taps[2 * t + 1]};
-            const f2 xv = {w[2 * t + 2 * O], w[2 * t + 1 + 2 * O]};
-            acc = __builtin_elementwise_fma(tp, xv, acc);
-        }
-        return acc.x + acc.y;
-    }
 };
 
 // FIN: -1 = the level-Ks image is a hand-off to the deep kernel (no epilogue), else the epilogue mode
@@ -285,21 +207,6 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
 constexpr int kDeepWaves = 8;
 constexpr int kDeepThreads = kDeepWaves * 64;
 constexpr int kGroup = 64;  // level-8 nodes per work item
-
-constexpr int refl_c(int j, int n) {
-    j = j < 0 ? -j : j;
-    return j >= n ? 2 * (n - 1) - j : j;
-}
-
-// node lengths of the standard 1 s frame (N = 22 050) at levels 8..14
-template <int L> struct Shape3;
-template <> struct Shape3<24> { static constexpr int L = 24; static constexpr int n[7] = {109, 66, 44, 33, 28, 25, 24}; };
-template <> struct Shape3<10> { static constexpr int L = 10; static constexpr int n[7] = {95, 52, 30, 19, 14, 11, 10}; };
-template <> struct Shape3<16> { static constexpr int L = 16; static constexpr int n[7] = {101, 58, 36, 25, 20, 17, 16}; };
-template <int L> struct HasShape3 { static constexpr bool value = false; };
-template <> struct HasShape3<24> { static constexpr bool value = true; };
-template <> struct HasShape3<10> { static constexpr bool value = true; };
-template <> struct HasShape3<16> { static constexpr bool value = true; };
 
 // one stepwise level (J = 0: 8 -> 9, J = 1: 9 -> 10): 32-row tiles of A and the band of columns they touch
 template <class SH, int J> struct Band3 {
@@ -701,12 +608,10 @@ int get_tables(const float* lo, const float* hi, hipStream_t stream, const float
 
 // LDS plan of the top kernel; false when a level pair does not fit
 bool plan_top(T3Params& p, int L) {
-    const int PAD = L - 2;
     long size[kKsMax + 1];
     for (int k = 0; k <= p.Ks; ++k) {
         // node = [L-2 left pad | n samples | L-2 (+1) right pad | up to 3 floats an odd node's last item reads]
-        int pitch = p.n[k] + 2 * PAD + 5;
-        while (pitch % 8 != 4) ++pitch;  // 16-byte aligned nodes; pitch / 4 odd: node-strided b128 reads hit distinct banks
+        const int pitch = padded_pitch(p.n[k], L);
         p.pitch[k] = pitch;
         const long nodes = k == 0 ? 1 : (1L << (k - 1));
         size[k] = nodes * pitch;
@@ -771,11 +676,15 @@ int launch3(T3Params& p, const float* dec_lo, const float* dec_hi, float* out, v
     }
     if constexpr (HasShape3<L>::value) {
         using SH = Shape3<L>;
-        D3Params q{};
-        int rc = get_tables<SH>(dec_lo, dec_hi, stream, &q.tab, q.kst1, q.kst2);
-        if (rc != AFD_OK) return rc;
         p.dst = static_cast<float*>(ws);
-        rc = launch_top<L, -1>(p, stream);
+        int rc = launch_top<L, -1>(p, stream);
+        if (rc != AFD_OK) return rc;
+        // levels 9..14: the lattice kernel (wpt4.hip); AFD_WPT_DEEP_MFMA=1 keeps the matrix-core composite below
+        rc = afd::wpt4_deep(static_cast<const float*>(ws), out, p.B, dec_lo, dec_hi, L, p.e.flags, p.e.power, p.e.eps,
+                            p.e.k1, p.e.k0, p.e.mean, p.e.inv_std, p.e.sgn_neg, p.e.sgn_pos, stream);
+        if (rc != 1) return rc;
+        D3Params q{};
+        rc = get_tables<SH>(dec_lo, dec_hi, stream, &q.tab, q.kst1, q.kst2);
         if (rc != AFD_OK) return rc;
         q.ws = static_cast<const float*>(ws);
         q.out = out;

@@ -1,0 +1,115 @@
+// Pieces shared by the wavelet-packet kernels of wpt3.hip (levels 1..8, vector ALU) and wpt4.hip (levels 9..14,
+// lattice form): epilogue, padded-node store, register window.  Reference: src/audiofakedetect/wavelet_math.py:167-263.
+#pragma once
+#include "afd_common.h"
+#include "../../include/afd_hip.h"
+
+namespace afd {
+namespace wptc {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxTaps = 32;
+constexpr int kTopThreads = 1024;
+constexpr int kTopLdsFloats = 40960;  // 163 840 B: all of a CU's LDS
+constexpr int kKsMax = 8;
+
+struct Epi {
+    unsigned flags;
+    float power, eps, k1, k0, mean, inv_std, sgn_neg, sgn_pos;
+};
+
+static __device__ __noinline__ float pow_log_slow3(float v, float power, float eps) {
+    return logf(powf(fabsf(v), power) + eps);
+}
+
+// log(|v|^power + eps) and (x - mean) / std.  The kernels are compiled per epilogue mode, so that an
+// element costs three vector instructions and no branch (the f32 matrix instructions and the vector ALU
+// share the SIMD's FMA lanes: every vector instruction is time the matrix stream does not get):
+//   EPI_RAW   v * k1 + k0                      (k1 = 1/std, k0 = -mean/std; 1, 0 without AFD_WPT_NORM)
+//   EPI_LOG2  log2(v*v + eps) * k1 + k0        (power == 2: v*v + eps >= 1e-12 is a normal float, the bare
+//             v_log_f32 needs no denormal pre-scaling; k1 = ln 2 / std)
+//   EPI_SLOW  any other power, library pow / log
+enum { EPI_RAW = 0, EPI_LOG2 = 1, EPI_SLOW = 2 };
+
+template <int MODE>
+__device__ __forceinline__ float epi_value(float v, const Epi& e) {
+    if (MODE == EPI_RAW) return fmaf(v, e.k1, e.k0);
+    if (MODE == EPI_LOG2) return fmaf(__builtin_amdgcn_logf(fmaf(v, v, e.eps)), e.k1, e.k0);
+    v = pow_log_slow3(v, e.power, e.eps);
+    if (e.flags & AFD_WPT_NORM) v = (v - e.mean) * e.inv_std;
+    return v;
+}
+
+static inline int epi_mode(unsigned flags, float power) {
+    if (!(flags & AFD_WPT_LOG)) return EPI_RAW;
+    return power == 2.0f ? EPI_LOG2 : EPI_SLOW;
+}
+
+// one coefficient of a child node of length n: its own slot and the pad slots that mirror it
+template <int L>
+__device__ __forceinline__ void put(float* node, int i, int n, float v) {
+    constexpr int PAD = L - 2;
+    node[i] = v;
+    if ((unsigned)(i - 1) < (unsigned)PAD) node[-i] = v;
+    if ((unsigned)(n - 2 - i) < (unsigned)(PAD + (n & 1))) node[2 * (n - 1) - i] = v;
+}
+
+// A work item is a PAIR of neighbouring outputs (i, i + 1), i even: their windows share L - 2 of L samples,
+// so the item reads L + 2 samples as 16-byte vectors (7 ds_read_b128 for 24 taps, lanes 16 bytes apart:
+// conflict-free) and both filters run over registers.
+template <int L>
+struct Window {
+    static constexpr int NV = (L + 2 + 3) / 4;
+    float w[4 * NV];
+    __device__ __forceinline__ void load(const float* __restrict__ src) {
+        const f4* s4 = reinterpret_cast<const f4*>(src);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const f4 x = s4[v];
+            w[4 * v] = x.x; w[4 * v + 1] = x.y; w[4 * v + 2] = x.z; w[4 * v + 3] = x.w;
+        }
+    }
+    // filter `taps` (reversed) at output i (O = 0) or i + 1 (O = 1)
+    template <int O>
+    __device__ __forceinline__ float dot(const float* taps) const {
+        f2 acc = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < L / 2; ++t) {
+            const f2 tp = {taps[2 * t], taps[2 * t + 1]};
+            const f2 xv = {w[2 * t + 2 * O], w[2 * t + 1 + 2 * O]};
+            acc = __builtin_elementwise_fma(tp, xv, acc);
+        }
+        return acc.x + acc.y;
+    }
+};
+
+
+constexpr int refl_c(int j, int n) {
+    j = j < 0 ? -j : j;
+    return j >= n ? 2 * (n - 1) - j : j;
+}
+
+// node lengths of the standard 1 s frame (N = 22 050) at levels 8..14
+template <int L> struct Shape3;
+template <> struct Shape3<24> { static constexpr int L = 24; static constexpr int n[7] = {109, 66, 44, 33, 28, 25, 24}; };
+template <> struct Shape3<10> { static constexpr int L = 10; static constexpr int n[7] = {95, 52, 30, 19, 14, 11, 10}; };
+template <> struct Shape3<16> { static constexpr int L = 16; static constexpr int n[7] = {101, 58, 36, 25, 20, 17, 16}; };
+template <int L> struct HasShape3 { static constexpr bool value = false; };
+template <> struct HasShape3<24> { static constexpr bool value = true; };
+template <> struct HasShape3<10> { static constexpr bool value = true; };
+template <> struct HasShape3<16> { static constexpr bool value = true; };
+
+// node pitch (floats) of an LDS image whose nodes carry their reflect pads:
+// [L-2 left pad | n samples | L-2 (+1) right pad | up to 3 floats an odd node's last item reads], 16-byte aligned
+// nodes, pitch / 4 odd (node-strided 16-byte reads hit distinct banks)
+constexpr int padded_pitch(int n, int L) {
+    int pitch = n + 2 * (L - 2) + 5;
+    while (pitch % 8 != 4) ++pitch;
+    return pitch;
+}
+
+}  // namespace wptc
+}  // namespace afd

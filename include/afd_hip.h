@@ -89,6 +89,15 @@ int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo, const flo
                     float std, float sign_mean, float sign_std, float* out, void* ws, size_t ws_bytes,
                     afd_stream_t stream);
 
+/* The orthogonal lattice the level-9..14 kernel runs a filter bank in (host only, no GPU; exported for the tests):
+ * dec_lo, dec_hi [host] L taps -> alpha, beta [L/2] stage coefficients, scales[2] = output scales of (cA, cD),
+ * fit_residual = largest |lattice tap - table tap|.  One analysis step on the polyphase pairs (e_j, o_j) =
+ * (xe[2j], xe[2j+1]) of the reflect-extended node: (A, B)[j] = (e_j + alpha[0] o_j, e_j + beta[0] o_j), then for
+ * s = 1 .. L/2-1: (A, B)[j] <- (A[j] + alpha[s] B[j-1], A[j] + beta[s] B[j-1]); cA[i] = scales[0] A[i],
+ * cD[i] = scales[1] B[i].  AFD_ERR_UNSUPPORTED when the taps are not an orthogonal bank. */
+int afd_wpt_lattice(const float* dec_lo, const float* dec_hi, int L, double* alpha, double* beta, double* scales,
+                    double* fit_residual);
+
 /* ------------------------------------------------------------------------------------
  * STFT power spectrogram front end.
  * Replaces: STFTLayer.forward = torchaudio Spectrogram(n_fft, hop_length, power) + log
