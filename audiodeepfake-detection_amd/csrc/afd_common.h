@@ -45,7 +45,9 @@ struct ScopedTiming {
     }
 };
 
-// wpt4.hip: levels 9..14 of the level-14 packet transform in lattice form (1 = not its case)
+// wpt4.hip: levels 9..14 of the level-14 packet transform in lattice form (1 = not its case);
+// wpt4_available: the taps are an orthogonal bank with a usable lattice (cached per tap table)
+bool wpt4_available(const float* dec_lo, const float* dec_hi, int L);
 int wpt4_deep(const float* ws, float* out, int B, const float* dec_lo, const float* dec_hi, int L, unsigned flags,
               float power, float eps, float k1, float k0, float mean, float inv_std, float sgn_neg, float sgn_pos,
               hipStream_t stream);

@@ -36,12 +36,6 @@ using namespace afd::wptc;
 
 namespace {
 
-constexpr int kMaxStages = kMaxTaps / 2;
-
-struct Lat4 {
-    f2 ab[kMaxStages];  // (alpha_s, beta_s): one aligned scalar register pair per stage
-    f2 sc;              // cA = A * sc.x, cD = B * sc.y after the last stage
-};
 
 struct D4Params {
     const float* ws;  // level-8 hand-off [B][n8][256]
@@ -106,12 +100,7 @@ __device__ __forceinline__ void lattice_level(const float* __restrict__ src, flo
 #pragma unroll
     for (int s = 1; s < K; ++s) {
         const f2 ab = c.ab[s];
-        // B of the position in front of this lane's run.  Inline assembly: given the vector element through
-        // __builtin_amdgcn_update_dpp, hipcc 7.2 takes the pair's LOW half as the DPP source (tools/micro/
-        // dpp_subreg.hip); the s_nop covers the two wait states between a vector write and a DPP read of it, which
-        // the compiler does not track into assembly.  Lane 0 keeps whatever the register held (never used)
-        float pb;
-        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(pb) : "v"(P[R - 1].y));
+        const float pb = lane_below(P[R - 1].y);  // B of the position in front of this lane's run
 #pragma unroll
         for (int r = R - 1; r >= 1; --r)
             P[r] = __builtin_elementwise_fma(ab, f2{P[r - 1].y, P[r - 1].y}, f2{P[r].x, P[r].x});
@@ -477,7 +466,11 @@ std::mutex& lat_mutex() {
     return m;
 }
 
-bool get_lattice(const float* lo, const float* hi, int L, Lat4* out, double* oa, double* ob) {
+}  // namespace
+
+namespace afd {
+namespace wptc {
+bool wpt_get_lattice(const float* lo, const float* hi, int L, Lat4* out, double* oa, double* ob) {
     std::lock_guard<std::mutex> guard(lat_mutex());
     for (const LatEntry& e : lat_cache())
         if (e.L == L && !memcmp(e.lo, lo, L * sizeof(float)) && !memcmp(e.hi, hi, L * sizeof(float))) {
@@ -504,6 +497,10 @@ bool get_lattice(const float* lo, const float* hi, int L, Lat4* out, double* oa,
     *ob = e.ob;
     return e.ok;
 }
+}  // namespace wptc
+}  // namespace afd
+
+namespace {
 
 template <int L, int MODE, bool SIGN, int GRP>
 int launch4g(const D4Params& q, int B, hipStream_t stream) {
@@ -523,11 +520,8 @@ int launch4g(const D4Params& q, int B, hipStream_t stream) {
 
 template <int L, int MODE, bool SIGN>
 int launch4(const D4Params& q, int B, hipStream_t stream) {
-    const char* e = getenv("AFD_D4_GROUP");
-    const int grp = e ? atoi(e) : 16;
-    if (grp == 16) return launch4g<L, MODE, SIGN, 16>(q, B, stream);
-    if (grp == 4) return launch4g<L, MODE, SIGN, 4>(q, B, stream);
-    return launch4g<L, MODE, SIGN, 8>(q, B, stream);
+    // 16 level-8 nodes per workgroup (512 threads): 4 / 8 measured 3-8 % slower at B = 4096, level at B = 128
+    return launch4g<L, MODE, SIGN, 16>(q, B, stream);
 }
 
 template <int L>
@@ -541,17 +535,23 @@ int deep4(D4Params& q, int B, int mode, bool sign, hipStream_t stream) {
 
 namespace afd {
 
+bool wpt4_available(const float* dec_lo, const float* dec_hi, int L) {
+    if (L != 24 && L != 10 && L != 16) return false;
+    wptc::Lat4 lat{};
+    double oa = 0.0, ob = 0.0;
+    return wptc::wpt_get_lattice(dec_lo, dec_hi, L, &lat, &oa, &ob);
+}
+
 // Levels 9..14 from the level-8 hand-off image `ws` [B][n8][256] (wpt3_top_kernel<L, -1>) to the features.
 // Returns AFD_OK, an error, or 1 = not this kernel's case (taps without an orthogonal lattice, other tap counts).
 int wpt4_deep(const float* ws, float* out, int B, const float* dec_lo, const float* dec_hi, int L, unsigned flags,
               float power, float eps, float k1, float k0, float mean, float inv_std, float sgn_neg, float sgn_pos,
               hipStream_t stream) {
-    if (getenv("AFD_WPT_DEEP_MFMA")) return 1;
     if (L != 24 && L != 10 && L != 16) return 1;
     if ((long)B * 64 > 0x7fffffffL) return 1;
     D4Params q{};
     double oa = 0.0, ob = 0.0;
-    if (!get_lattice(dec_lo, dec_hi, L, &q.lat, &oa, &ob)) return 1;
+    if (!wpt_get_lattice(dec_lo, dec_hi, L, &q.lat, &oa, &ob)) return 1;
     q.ws = ws;
     q.out = out;
     q.e.flags = flags;

@@ -87,6 +87,27 @@ struct Window {
 };
 
 
+// Lattice form of an orthogonal two-channel bank (wpt4.hip: wpt_lattice_coefficients): stage s of an analysis step is
+// (A, B)[j] <- (A[j] + ab[s].x B[j-1], A[j] + ab[s].y B[j-1]) (s = 0: on (e_j, o_j) without the delay), and
+// cA = A sc.x, cD = B sc.y.  Kernel argument: every pair is an aligned scalar register pair.
+constexpr int kMaxStages = kMaxTaps / 2;
+struct Lat4 {
+    f2 ab[kMaxStages];
+    f2 sc;
+};
+// the lattice of a tap table, cached per process; false when the taps are not an orthogonal bank (wpt4.hip)
+bool wpt_get_lattice(const float* lo, const float* hi, int L, Lat4* out, double* oa, double* ob);
+
+// B of the position in front of a lane's run: the neighbouring lane's value through DPP (wave_shr:1).  Inline assembly:
+// given a vector element through __builtin_amdgcn_update_dpp, hipcc 7.2 takes the pair's LOW half as the DPP source
+// (tools/micro/dpp_subreg.hip); the s_nop covers the two wait states between a vector write and a DPP read of it,
+// which the compiler does not track into assembly.  Lane 0 keeps whatever the register held (never used).
+__device__ __forceinline__ float lane_below(float v) {
+    float r;
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+
 constexpr int refl_c(int j, int n) {
     j = j < 0 ? -j : j;
     return j >= n ? 2 * (n - 1) - j : j;

@@ -89,7 +89,7 @@ CLASS_KERNELS = {
     "conv_direct": ("dilconv_direct_kernel", "dilconv_wgrad_kernel", "dilconv_reduce_kernel"),
     "conv_wgrad_1x1": ("conv1x1_wgrad_kernel", "conv1x1_fused_bwd_kernel"),
     "wpt": ("wpt2_deep_mfma_kernel", "wpt2_deep_kernel", "wpt2_top_kernel", "wpt_fused_kernel",
-            "wpt_haar14_kernel", "wpt3_kernel", "wpt3_top_kernel", "wpt3_deep_kernel"),
+            "wpt_haar14_kernel", "wpt3_top_kernel", "wpt4_deep_kernel"),
     "stft": ("stft_mfma_kernel",),
     "lcnn_bf16": ("lcnn_conv_nhwc_kernel", "lcnn_conv1_kernel", "gemm_nt_bf16_kernel", "conv_bf16_kernel"),
 }

@@ -2,13 +2,13 @@
 // other work lives in a DIFFERENT wave (role-specialised waves), against the same work fused into the matrix wave.
 //
 // One 512-thread workgroup per CU (8 waves: waves 0-3 land one per SIMD, waves 4-7 likewise).  Roles:
-//   M  matrix wave: per tile 22 x v_mfma_f32_32x32x2_f32 (the 10 -> 14 composite of wpt3_deep_kernel, K = 44)
+//   M  matrix wave: per tile 22 x v_mfma_f32_32x32x2_f32 (the 10 -> 14 composite of the round-3 wpt3_deep_kernel, K = 44)
 //   E  epilogue wave: per tile, for 16 values per lane, log2(v*v + eps)*k1 + k0, four 4x4 quad transposes over DPP
 //      and four 16-byte stores (each instruction = two 512-byte runs of whole lines, streaming to HBM)
 //   V  the epilogue's vector arithmetic only (no stores);  S  the stores only
 //   P  packed-FMA wave: per item 7 ds_read_b128 + 48 v_pk_fma_f32 + 2 ds_write_b64 (one output pair of both
 //      children in wpt3_top_kernel, 24 taps)
-//   F  fused: matrix tile followed by its epilogue in the same wave (what wpt3_deep_kernel does today)
+//   F  fused: matrix tile followed by its epilogue in the same wave (what the round-3 wpt3_deep_kernel did; retired in round 4 for wpt4.hip)
 // A configuration gives the role of waves 0-3 and of waves 4-7 ('-' = the waves exit at once).
 // Build: hipcc -O3 --offload-arch=gfx950 coexec.hip -o coexec ; run on an MI355X.
 #include <hip/hip_runtime.h>
