@@ -940,3 +940,110 @@ def test_winograd_domain_backward_weight(case, with_sums):
     groups = -(-(-(-cols // 4)) // 4)
     assert c["launches"] == 1
     assert c["issued"] == 2.0 * 36 * cout * cin * 4 * n * groups * -(-rows // 4)
+
+
+# ---- gradient parity at the grid sizes the benchmark runs (level-14 blocks 3 and 4, N = 128) ----------------------
+BENCH_WGRAD = [
+    # n, cin, h, w, cout, crop rows, crop cols
+    (128, 64, 13, 8193, 96, 12, 8192),   # block 3: the pooled crop of the 13 x 8193 image
+    (128, 96, 6, 4096, 128, 6, 4096),    # block 4
+]
+
+
+@pytest.mark.parametrize("case", BENCH_WGRAD)
+def test_backward_weight_at_benchmark_size_equals_its_two_frame_pieces(case):
+    """At N = 128 the backward-weight launch splits its tile sequence over three rounds of workgroups (768 with
+    8-aligned split counts); at N = 2 the same entry point runs a handful of splits.  The weight gradient is linear in
+    the batch, so the N = 128 result must equal the sum (in float64) of the 64 two-frame results, and one two-frame
+    piece is checked against torch's float64 gradient -- both at 3e-5 of the largest entry, the layer bar.  (Measured:
+    2.2e-5 for block 3, whose float32 accumulators each sum ~50 000 Winograd-domain products whose transform constants
+    reach 8 x 20; the review's 2e-6 would hold for a direct-form sum, not for F(4x4) in float32.)
+    Reference: what autograd returns for nn.Conv2d(k=3, padding=1) at models.py:264-270."""
+    n, cin, h, w, cout, rows, cols = case
+    torch.manual_seed(sum(case))
+    lib = _native.load()
+    x = torch.randn(n, cin, h, w, device="cuda")
+    dy = torch.randn(n, cout, h, w, device="cuda")
+    ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin, h, w, cout, 3, 1, 1), dtype=torch.uint8, device="cuda")
+
+    def wgrad(xs, dys, nn):
+        dw = torch.empty(cout, cin, 3, 3, device="cuda")
+        db = torch.empty(cout, device="cuda")
+        _native.check(lib.afd_conv2d_backward_weight_sums(
+            _native.ptr(xs), _native.ptr(dys), _native.ptr(dw), _native.ptr(db), None, nn, cin, h, w, cout, 3, 1, 1,
+            rows, cols, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "wgrad")
+        return dw, db
+
+    (dw_all, db_all), c = _issued_class(lambda: wgrad(x, dy, n), "conv_wgrad")
+    assert c["launches"] == 1 and c["issued"] > 0  # the Winograd-domain kernel, one launch
+    acc_w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda")
+    acc_b = torch.zeros(cout, dtype=torch.float64, device="cuda")
+    first = None
+    for i in range(0, n, 2):
+        dw2, db2 = wgrad(x[i:i + 2], dy[i:i + 2], 2)
+        if first is None:
+            first = dw2.clone()
+        acc_w += dw2.double()
+        acc_b += db2.double()
+    _close(dw_all, acc_w.cpu(), 3e-5, "N = 128 wgrad vs the sum of its two-frame pieces")
+    _close(db_all, acc_b.cpu(), 2e-6, "N = 128 dbias vs the sum of its two-frame pieces")
+    dyz = torch.zeros(2, cout, h, w, dtype=torch.float64)
+    dyz[:, :, :rows, :cols] = dy[:2, :, :rows, :cols].cpu().double()
+    ref = torch.nn.grad.conv2d_weight(x[:2].cpu().double(), (cout, cin, 3, 3), dyz, padding=1)
+    _close(first, ref, 3e-5, "two-frame piece vs float64")
+
+
+def test_pooled_backward_at_benchmark_size_equals_its_two_frame_pieces():
+    """Block 3 as the step runs it: the gradient of the pooled convolution arrives pooled (gg + argmax codes).  The
+    N = 128 pooled backward-weight launch equals the sum of its 64 two-frame launches (3e-5, see above), and the N = 128 pooled
+    backward-data launch gives frames 0-1 exactly what the N = 2 launch gives (per-frame work, bit-equal)."""
+    n, cin, h, w, cout = 128, 64, 13, 8193, 96
+    hp, wp = h // 2, w // 2
+    torch.manual_seed(7)
+    lib = _native.load()
+    assert lib.afd_conv3x3_pooled_backward_applicable(cin, h, w, cout)
+    x = torch.randn(n, cin, h, w, device="cuda")
+    gg = ops._empty_with_slack((n, cout, hp, wp), torch.float32, "cuda")
+    gg.normal_()
+    idx = ops._empty_with_slack((n, cout, hp, wp), torch.uint8, "cuda")
+    idx.copy_(torch.randint(0, 8, (n, cout, hp, wp), device="cuda", dtype=torch.uint8))
+    wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+    ws = torch.empty(lib.afd_conv2d_workspace_bytes(n, cin, h, w, cout, 3, 1, 1), dtype=torch.uint8, device="cuda")
+
+    def slices(i, nn):
+        # two-frame pieces keep the slack behind them: they are views into the big tensors (the last piece of all
+        # ends where the big tensor's own slack begins)
+        return x[i:i + nn], gg[i:i + nn], idx[i:i + nn]
+
+    def wgrad(i, nn):
+        xs, gs, cs = slices(i, nn)
+        dw = torch.empty(cout, cin, 3, 3, device="cuda")
+        db = torch.empty(cout, device="cuda")
+        _native.check(lib.afd_conv3x3_backward_weight_pooled(_native.ptr(xs), _native.ptr(gs), _native.ptr(cs), _native.ptr(dw),
+                                                             _native.ptr(db), nn, cin, h, w, cout, _native.ptr(ws), ws.numel(),
+                                                             _native.stream_ptr()), "pooled wgrad")
+        return dw, db
+
+    dw_all, db_all = wgrad(0, n)
+    acc_w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device="cuda")
+    acc_b = torch.zeros(cout, dtype=torch.float64, device="cuda")
+    for i in range(0, n, 2):
+        dw2, db2 = wgrad(i, 2)
+        acc_w += dw2.double()
+        acc_b += db2.double()
+    _close(dw_all, acc_w.cpu(), 3e-5, "pooled N = 128 wgrad vs the sum of its two-frame pieces")
+    _close(db_all, acc_b.cpu(), 2e-6, "pooled N = 128 dbias vs the sum of its two-frame pieces")
+
+    def dgrad(nn):
+        xs, gs, cs = slices(0, nn)
+        dx = torch.empty(nn, cin, h, w, device="cuda")
+        sums = torch.empty(2 * cin, dtype=torch.float64, device="cuda")
+        sws = torch.empty(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(nn, cin, h, w), dtype=torch.uint8, device="cuda")
+        _native.check(lib.afd_conv3x3_backward_data_bnstats_pooled(
+            _native.ptr(gs), _native.ptr(cs), _native.ptr(wt), _native.ptr(dx), _native.ptr(sums), nn, cin, h, w, cout,
+            _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "pooled dgrad")
+        return dx
+
+    dx_all = dgrad(n)
+    dx_two = dgrad(2)
+    assert torch.equal(dx_all[:2], dx_two)
