@@ -501,8 +501,17 @@ def conv3x3_prelu_maxpool(x, w, b, slope, bn_link: Optional[dict] = None, out_li
 
 
 # --------------------------------------------------------------------------------------
+def multi_rank() -> bool:
+    """A process group with more than one rank is up -- or one rank with AFD_FORCE_COLLECTIVES=1, which makes a
+    one-GPU run issue every collective of the data-parallel step (tools/ddp_collectives.py counts and times them:
+    the only multi-GPU evidence a one-GPU box can give)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(os.environ.get("AFD_FORCE_COLLECTIVES"))
+
+
 def _dist_on(sync: bool) -> bool:
-    return sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return sync and multi_rank()
 
 
 def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=None, nbt=None,

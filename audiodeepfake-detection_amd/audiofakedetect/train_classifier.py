@@ -72,7 +72,7 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
     is applied inside the Adam kernel; otherwise gradients are reduced tensor by tensor and
     scaled here (returns 1.0).
     """
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not ops.multi_rank():
         return 1.0
     world = dist.get_world_size()
     if isinstance(optimizer, ops.FusedAdam):
@@ -113,7 +113,7 @@ def start_gradient_allreduce(optimizer) -> None:
     """Arrange for the arena all-reduce to be issued by the autograd engine itself when the coming backward
     pass ends (ops.at_end_of_backward): RCCL gets the collective the moment the last gradient kernel has been
     queued; `sync_gradients` picks the handle up."""
-    if not (dist.is_initialized() and dist.get_world_size() > 1 and isinstance(optimizer, ops.FusedAdam)):
+    if not (ops.multi_rank() and isinstance(optimizer, ops.FusedAdam)):
         return
     # a backward pass that raised never ran its end-of-backward callbacks: drop a hook it left queued (two
     # hooks would issue two all-reduces over the arena, of which only one is waited for and scaled) and
