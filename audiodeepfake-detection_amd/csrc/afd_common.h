@@ -106,12 +106,6 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
                const unsigned char* pooled_codes = nullptr);  // backward-data from the pooled gradient: see G4::pidx
 long wino44_stat_rows(int N, int H, int W);
 bool wino44_pool_applicable(int Cin, int H, int W, int Cout);
-// wino16.hip: the same with 16x16x4 tiles and a register-only output transform
-bool wino16_applicable(int Cin, int H, int W, int Cout);
-size_t wino16_workspace_bytes(int Cin, int Cout);
-int wino16_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
-               int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s);
-
 // wino44_wgrad.hip: 3x3 / pad 1 backward-weight in the Winograd F(4x4, 3x3) domain
 bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 bool wino44_wgrad_crop_ok(int H, int W, int dy_rows, int dy_cols);

@@ -1447,7 +1447,7 @@ extern "C" int afd_conv2d_forward_cropped(const float* x, const float* w, const 
 // pooling window.  Returns AFD_ERR_UNSUPPORTED when the layer is not one the Winograd kernel of
 // wino.hip takes (the caller then runs convolution and pool separately).
 extern "C" int afd_conv3x3_prelu_pool_applicable(int Cin, int H, int W, int Cout) {
-    return afd::wino_applicable(Cin, H, W, Cout) && !afd::wino16_applicable(Cin, H, W, Cout) && H >= 2 && W >= 2 ? 1 : 0;
+    return afd::wino_applicable(Cin, H, W, Cout) && H >= 2 && W >= 2 ? 1 : 0;
 }
 
 extern "C" int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, const float* bias,

@@ -943,7 +943,6 @@ size_t conv3x3_workspace_bytes(int Cin, int Cout) {
     const size_t co_pad = (size_t)(Cout + 31) / 32 * 32;
     const size_t direct = (size_t)(Cin / kCT) * kKsteps * 2 * co_pad * sizeof(float);
     size_t wino = wino_workspace_bytes(Cin, Cout);
-    if (wino16_workspace_bytes(Cin, Cout) > wino) wino = wino16_workspace_bytes(Cin, Cout);
     if (Cin % 8 == 0 && wino44_workspace_bytes(Cin, Cout) > wino) wino = wino44_workspace_bytes(Cin, Cout);
     return direct > wino ? direct : wino;
 }
@@ -960,8 +959,6 @@ int conv3x3_run(const float* x, const float* w, const float* bias, float* y, int
     // (wino.hip's pooling epilogue) and two-launch form are kept bit-identical
     if ((dgrad || Cout == 128 || Cout == 32) && wino44_applicable(Cin, H, W, Cout))
         return wino44_run(x, w, bias, y, N, Cin, H, W, Cout, dgrad, out_rows, out_cols, ws, ws_bytes, s);
-    if (wino16_applicable(Cin, H, W, Cout))
-        return wino16_run(x, w, bias, y, N, Cin, H, W, Cout, dgrad, out_rows, out_cols, ws, ws_bytes, s);
     if (wino_applicable(Cin, H, W, Cout))
         return wino_run(x, w, bias, y, N, Cin, H, W, Cout, dgrad, out_rows, out_cols, ws, ws_bytes, s);
     G3 g{};

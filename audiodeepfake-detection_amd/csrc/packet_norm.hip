@@ -116,7 +116,7 @@ struct BnParams {
 
 __device__ __forceinline__ float bn_value(float v, const BnParams& p) {
     if (p.flags & AFD_WPT_LOG) {
-        // same arithmetic as the fused transform epilogues (wpt2.hip / wpt_haar.hip)
+        // same arithmetic as the fused transform epilogues (wpt3.hip / wpt4.hip / wpt_haar.hip)
         if (p.power == 2.0f) v = __builtin_amdgcn_logf(fmaf(v, v, p.eps)) * 0.6931471805599453f;
         else v = pow_log_precise(v, p.power, p.eps);
     }

@@ -567,7 +567,7 @@ extern "C" int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int 
     // with two or three channel tiles carries the statistics epilogue
     if (getenv("AFD_NO_BWD_BNSTATS")) return 0;
     if (afd::wino44_applicable(Cout, H, W, Cin)) return 1;
-    if (afd::wino16_applicable(Cout, H, W, Cin) || !afd::wino_applicable(Cout, H, W, Cin)) return 0;
+    if (!afd::wino_applicable(Cout, H, W, Cin)) return 0;
     if (getenv("AFD_WINO_NT1")) return 0;
     const int mt = (Cin + 31) / 32;
     return mt == 2 || mt == 3;

@@ -1,5 +1,5 @@
 // Winograd F(4x4, 3x3) forward / backward-data on the f32 MFMA: 36 multiplies per 4x4 output tile and channel
-// pair instead of 64 for four F(2x2, 3x3) tiles (wino.hip, wino16.hip) or 144 direct; arithmetic fp32 end to end
+// pair instead of 64 for four F(2x2, 3x3) tiles (wino.hip) or 144 direct; arithmetic fp32 end to end
 // (transform constants up to 8: measured 7e-6 of the largest output against float64 on a block-3 shaped layer,
 // F(2x2): 4e-7).
 //
@@ -7,7 +7,7 @@
 // (src/audiofakedetect/models.py:263-278) and its backward-data pass.
 //
 //   wave      = 16 output channels x 16 tiles x 36 positions on 16x16x4 tiles: 144 accumulator registers; every
-//               (channel, tile) has its 36 positions in one lane, so A^T M A runs in registers (as in wino16.hip)
+//               (channel, tile) has its 36 positions in one lane, so A^T M A runs in registers
 //   workgroup = CG waves (Cout / 16) over the same 16 tiles of a tile row (4 output rows x 64 columns); 74 KB of
 //               LDS, two workgroups per CU
 //   chunk     = 16 input channels: thread (channel, tile) of the first 256 threads transforms its 6x6 patch

@@ -327,11 +327,7 @@ namespace afd {
 int wpt_haar14_forward(const float* x, int B, int N, const float* dec_lo, int L, int level,
                        unsigned flags, float power, float eps, float mean, float std, float sign_mean,
                        float sign_std, float* out, hipStream_t stream);
-size_t wpt2_workspace_bytes(int B, int N, int L, int level);
-bool wpt2_preferred(int L, int level);
-int wpt2_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
-                 int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
-                 float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t wpt3_workspace_bytes(int B, int N, int L, int level);
 int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
                  int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
                  float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
@@ -339,7 +335,7 @@ int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float*
 
 extern "C" size_t afd_wpt_workspace_bytes(int B, int N, int L, int level) {
     if (B < 1 || N < 2 || L < 2 || (L & 1) || L > kMaxTaps || level < 1 || level > kMaxLevel) return 0;
-    return afd::wpt2_workspace_bytes(B, N, L, level);
+    return afd::wpt3_workspace_bytes(B, N, L, level);
 }
 
 extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo,
@@ -370,18 +366,7 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
                                           sign_mean, sign_std, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
         if (rc3 != 1) return rc3;
     }
-    // Which generation: wpt2.hip (register window + packed FMAs, level-1 subtree per workgroup, MFMA
-    // deep levels) for every level >= 11 and, up to level 10, for the long and the 2-tap filters
-    // (coif4 level 8: 64 vs 92 us, haar level 8 at B = 4096: 0.88 vs 1.23 ms); the single-launch
-    // kernel below stays for 4..10 taps up to level 10 (sym5 level 8: 47 vs 50 us).
-    // AFD_WPT_V1 / AFD_WPT_V2 force one or the other (development).
-    if (afd::wpt2_preferred(L, level)) {
-        // 1 = geometry left to the kernel below
-        const int rc2 = afd::wpt2_forward(x, B, N, dec_lo, dec_hi, L, level, flags, power, eps, mean,
-                                          std, sign_mean, sign_std, out, ws, ws_bytes,
-                                          static_cast<hipStream_t>(stream));
-        if (rc2 != 1) return rc2;
-    }
+    // everything else -- 2, 12, 14, 18.. taps, levels 9..13, other frame lengths -- on the single-launch kernel below
     WptParams p{};
     p.x = x;
     p.out = out;

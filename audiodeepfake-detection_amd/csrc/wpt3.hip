@@ -249,7 +249,18 @@ int launch3(T3Params& p, const float* dec_lo, const float* dec_hi, float* out, v
 
 namespace afd {
 
-// returns AFD_OK, an error, or 1 = "not this generation's case" (the caller falls back to wpt2 / wpt)
+// the level-8 hand-off image [B][n8][256] of the level-14 transform of standard frames; 0 for everything else
+size_t wpt3_workspace_bytes(int B, int N, int L, int level) {
+    if (level != 14 || (L != 24 && L != 10 && L != 16)) return 0;
+    int n = N;
+    for (int k = 1; k <= 8; ++k) {
+        if (L - 2 + (n & 1) >= n) return 0;
+        n = child_len3(n, L);
+    }
+    return (size_t)B * n * 256 * sizeof(float);
+}
+
+// returns AFD_OK, an error, or 1 = "not this generation's case" (the caller falls back to the generic kernel of wpt.hip)
 int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L, int level,
                  unsigned flags, float power, float eps, float mean, float std, float sign_mean, float sign_std,
                  float* out, void* ws, size_t ws_bytes, hipStream_t stream) {
