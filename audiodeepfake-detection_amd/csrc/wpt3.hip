@@ -41,9 +41,19 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PAD = L - 2;
     const int tid = threadIdx.x;
-    // the two halves of a frame are B workgroups apart: with B % 8 == 0 they share an XCD's L2
-    const int b = blockIdx.x % p.B;
-    const int h = blockIdx.x / p.B;
+    // The two halves of a frame read the same 88 KB: they are EIGHT workgroups apart -- same XCD under the round-robin
+    // placement of workgroups over the 8 XCDs, so one L2 serves both, and close enough in dispatch order to run at the
+    // same time, so the second reader hits (rounds 2-3 placed them B apart: at B = 4096 the line had long left the
+    // L2 and every frame came from HBM twice).  Blocks of 16: ids 0..7 = frames 8 g .. 8 g + 7 low halves, 8..15 high.
+    int b, h;
+    if (p.B % 8 == 0) {
+        const int grp = blockIdx.x >> 4, r = blockIdx.x & 15;
+        b = 8 * grp + (r & 7);
+        h = r >> 3;
+    } else {
+        b = blockIdx.x % p.B;
+        h = blockIdx.x / p.B;
+    }
 
     // ---- frame -> level-0 image (with both reflect pads) ----
     {

@@ -37,6 +37,12 @@ CONV_CASES = [
     (2, 12, 64, 32, 12, 3, 1, 1),
     (2, 12, 64, 32, 12, 5, 2, 2),
     (2, 12, 60, 28, 12, 7, 2, 4),
+    # the same stack at time_dim 13 (coif4 level 8) and on odd sizes: narrow-image direct kernel, dilnarrow.hip
+    (3, 13, 64, 32, 13, 3, 1, 1),
+    (3, 13, 64, 32, 13, 5, 2, 2),
+    (3, 13, 60, 28, 13, 7, 2, 4),
+    (2, 13, 37, 30, 13, 7, 2, 4),
+    (2, 12, 33, 41, 12, 5, 2, 2),
     # level-14 shaped (wide) images: RECT tiles
     (1, 1, 24, 1500, 64, 3, 2, 1),
     (1, 64, 6, 2050, 96, 3, 1, 1),
@@ -817,6 +823,9 @@ def _issued_winograd(fn):
     (1, 128, 6, 1030, 96, "dgrad"),   # block 4 backward-data: six matrix waves + two helper waves
     (2, 128, 6, 1027, 32, "fwd"),     # block 5 forward: two waves, 8-channel chunks
     (2, 64, 7, 300, 32, "dgrad"),     # block 6 backward-data
+    (2, 64, 13, 1030, 96, "dgrad"),   # 13 rows: the last tile row has ONE live row
+    (2, 128, 5, 300, 96, "dgrad"),    # five rows: a full tile row and one live row
+    (1, 96, 10, 517, 128, "fwd"),     # ten rows: two full tile rows and a two-row one
 ])
 def test_winograd_f44_layers(case):
     """wino44.hip, Winograd F(4x4, 3x3): against float64 at the stated bar for that kernel -- 2e-5 of the largest
