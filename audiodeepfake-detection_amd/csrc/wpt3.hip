@@ -35,9 +35,32 @@ struct T3Params {
     float rlo[kMaxTaps], rhi[kMaxTaps];  // taps reversed: rlo[t] = dec_lo[L - 1 - t]
 };
 
+// Geometry of the standard 1 s frame (N = 22 050, levels 0..8) at compile time: the same node lengths, pitches and LDS
+// offsets plan_top computes.  The STD instance of the kernel takes them from here, its level loop is unrolled, and
+// every division, pitch product and image offset is a constant: the kernel is bound by instruction issue (64 % of the
+// SIMD cycles vector-ALU busy, 2 358 vector + 675 scalar instructions per wave of which 1 250 are the packed FMAs).
+template <int L> struct Std3 {
+    static constexpr int N = 22050, Ks = kKsMax;
+    static constexpr int n_at(int k) {
+        int n = N;
+        for (int i = 0; i < k; ++i) n = (n + L - 2 + (n & 1)) / 2;
+        return n;
+    }
+    static constexpr int pitch_at(int k) { return padded_pitch(n_at(k), L); }
+    static constexpr long size_at(int k) { return (k == 0 ? 1L : (1L << (k - 1))) * pitch_at(k); }
+    static constexpr int off_at(int k) { return (k & 1) && k < Ks ? (int)((kTopLdsFloats - size_at(k)) & ~3L) : 0; }
+};
+
 // FIN: -1 = the level-Ks image is a hand-off to the deep kernel (no epilogue), else the epilogue mode
-template <int L, int FIN>
+// STD: the standard frame at 8 levels with compile-time geometry (Std3); otherwise everything comes from T3Params
+template <int L, int FIN, bool STD = false>
 __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p) {
+    using SG = Std3<L>;
+    const int pN = STD ? SG::N : p.N;
+    const int pKs = STD ? SG::Ks : p.Ks;
+    auto n_of = [&](int k) { return STD ? SG::n_at(k) : p.n[k]; };
+    auto off_of = [&](int k) { return STD ? SG::off_at(k) : p.off[k]; };
+    auto pitch_of = [&](int k) { return STD ? SG::pitch_at(k) : p.pitch[k]; };
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int PAD = L - 2;
     const int tid = threadIdx.x;
@@ -57,11 +80,11 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
 
     // ---- frame -> level-0 image (with both reflect pads) ----
     {
-        const float* xg = p.x + (size_t)b * p.N;
-        float* X0 = lds + p.off[0] + PAD;
-        if ((p.N & 1) == 0) {
+        const float* xg = p.x + (size_t)b * pN;
+        float* X0 = lds + off_of(0) + PAD;
+        if ((pN & 1) == 0) {
             const float2* xv = reinterpret_cast<const float2*>(xg);  // frames are 8-byte aligned
-            const int n2 = p.N >> 1;
+            const int n2 = pN >> 1;
             // 11 loads in flight per thread: the 22 050-sample frame arrives in ONE round of memory latency
             constexpr int UN = 11;
             for (int base = 0; base < n2; base += kTopThreads * UN) {
@@ -78,20 +101,20 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
                 }
             }
         } else {
-            for (int i = tid; i < p.N; i += kTopThreads) X0[i] = xg[i];
+            for (int i = tid; i < pN; i += kTopThreads) X0[i] = xg[i];
         }
         if (tid >= 1 && tid <= PAD) X0[-tid] = xg[tid];
         const int j = tid - 64;
-        if (j >= 1 && j <= PAD + (p.N & 1)) X0[p.N - 1 + j] = xg[p.N - 1 - j];
+        if (j >= 1 && j <= PAD + (pN & 1)) X0[pN - 1 + j] = xg[pN - 1 - j];
     }
     __syncthreads();
 
     // ---- level 1: this workgroup's child of the frame (h = 0 low-pass, 1 high-pass) ----
-    if (p.Ks == 1) return;  // not built: the caller keeps one-level transforms on the first-generation kernel
+    if (pKs == 1) return;  // not built: the caller keeps one-level transforms on the first-generation kernel
     {
-        const float* src = lds + p.off[0];
-        float* node = lds + p.off[1] + PAD;
-        const int n1 = p.n[1];
+        const float* src = lds + off_of(0);
+        float* node = lds + off_of(1) + PAD;
+        const int n1 = n_of(1);
         const float* taps = h ? p.rhi : p.rlo;
         for (int j = tid; 2 * j < n1; j += kTopThreads) {
             Window<L> win;
@@ -103,57 +126,79 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
     __syncthreads();
 
     // ---- levels 2 .. Ks-1: both children of every node, lanes along the output index ----
-    for (int k = 2; k < p.Ks; ++k) {
+    // W outputs of both children per work item.  W = 4 (index arithmetic, loads and border checks paid once per four
+    // outputs) measured 1-2 % ahead in the STD instance and level with run-time geometry -- not worth reading 8 more
+    // floats past a node's last item
+    constexpr int W = 2;
+    auto level = [&](const int k) {
         const int Mp = 1 << (k - 2);  // parents (nodes of level k-1 in this half)
-        const int nk = p.n[k];
-        const int mk = (nk + 1) >> 1;  // items (output pairs) per node
+        const int nk = n_of(k);
+        const int mk = (nk + W - 1) / W;  // items per node
         const int total = Mp * mk;
-        const float* src0 = lds + p.off[k - 1];
-        float* dst0 = lds + p.off[k] + PAD;
-        const int pin = p.pitch[k - 1], pout = p.pitch[k];
-        const unsigned magic = p.magic[k];
+        const float* src0 = lds + off_of(k - 1);
+        float* dst0 = lds + off_of(k) + PAD;
+        const int pin = pitch_of(k - 1), pout = pitch_of(k);
+        const unsigned magic = STD ? 0u : p.magic[k];
         const int padr = PAD + (nk & 1);
         for (int idx = tid; idx < total; idx += kTopThreads) {
-            const int q = (int)__umulhi((unsigned)idx, magic);
-            const int i = 2 * (idx - q * mk);
-            Window<L> win;
+            const int q = STD ? idx / mk : (int)__umulhi((unsigned)idx, magic);
+            const int i = W * (idx - q * mk);
+            Window<L, W> win;
             win.load(src0 + q * pin + 2 * i);
-            const float ca0 = win.template dot<0>(p.rlo), cd0 = win.template dot<0>(p.rhi);
-            const float ca1 = win.template dot<1>(p.rlo), cd1 = win.template dot<1>(p.rhi);
+            float ca[W], cd[W];
+            ca[0] = win.template dot<0>(p.rlo); cd[0] = win.template dot<0>(p.rhi);
+            ca[1] = win.template dot<1>(p.rlo); cd[1] = win.template dot<1>(p.rhi);
+            if constexpr (W == 4) {
+                ca[2] = win.template dot<2>(p.rlo); cd[2] = win.template dot<2>(p.rhi);
+                ca[3] = win.template dot<3>(p.rlo); cd[3] = win.template dot<3>(p.rhi);
+            }
             // odd-frequency parents list their children (d, a)
             const int par = (k == 2) ? h : (q & 1);
             float* na = dst0 + (2 * q + par) * pout;
             float* nd = dst0 + (2 * q + 1 - par) * pout;
-            const bool two = i + 1 < nk;
-            if (two) {
-                *reinterpret_cast<f2*>(na + i) = f2{ca0, ca1};
-                *reinterpret_cast<f2*>(nd + i) = f2{cd0, cd1};
-            } else {
-                na[i] = ca0;
-                nd[i] = cd0;
+#pragma unroll
+            for (int u = 0; u < W; u += 2) {
+                if (i + u + 1 < nk) {
+                    *reinterpret_cast<f2*>(na + i + u) = f2{ca[u], ca[u + 1]};
+                    *reinterpret_cast<f2*>(nd + i + u) = f2{cd[u], cd[u + 1]};
+                } else if (i + u < nk) {
+                    na[i + u] = ca[u];
+                    nd[i + u] = cd[u];
+                }
             }
             // the L-2 coefficients next to a border also fill the pad slots that mirror them
             if (i <= PAD) {
-                if (i >= 1) { na[-i] = ca0; nd[-i] = cd0; }
-                if (two && i + 1 <= PAD) { na[-i - 1] = ca1; nd[-i - 1] = cd1; }
+#pragma unroll
+                for (int u = 0; u < W; ++u) {
+                    const int iu = i + u;
+                    if (iu >= 1 && iu <= PAD && iu < nk) { na[-iu] = ca[u]; nd[-iu] = cd[u]; }
+                }
             }
-            if (nk - 2 - i < padr + 1) {
-                if ((unsigned)(nk - 2 - i) < (unsigned)padr) { na[2 * (nk - 1) - i] = ca0; nd[2 * (nk - 1) - i] = cd0; }
-                if (two && (unsigned)(nk - 3 - i) < (unsigned)padr) { na[2 * (nk - 1) - i - 1] = ca1; nd[2 * (nk - 1) - i - 1] = cd1; }
+            if (nk - 2 - (i + W - 1) < padr) {
+#pragma unroll
+                for (int u = 0; u < W; ++u) {
+                    const int iu = i + u;
+                    if ((unsigned)(nk - 2 - iu) < (unsigned)padr) { na[2 * (nk - 1) - iu] = ca[u]; nd[2 * (nk - 1) - iu] = cd[u]; }
+                }
             }
         }
         __syncthreads();
+    };
+    if constexpr (STD) {  // six inlined copies with a constant level: every length, pitch and offset folds
+        level(2); level(3); level(4); level(5); level(6); level(7);
+    } else {
+        for (int k = 2; k < pKs; ++k) level(k);
     }
 
     // ---- level Ks: lanes along the nodes, results leave the chip packet-contiguous ----
     {
-        const int k = p.Ks;
+        const int k = pKs;
         const int logM = k - 2;  // parents in this half: 2^(k-2)
         const int Mp = 1 << logM;
-        const int nk = p.n[k];
+        const int nk = n_of(k);
         const int total = ((nk + 1) >> 1) << logM;
-        const float* src0 = lds + p.off[k - 1];
-        const int pin = p.pitch[k - 1];
+        const float* src0 = lds + off_of(k - 1);
+        const int pin = pitch_of(k - 1);
         const size_t P = (size_t)1 << k;
         const size_t chan = (size_t)nk * P;
         const int nch = (FIN >= 0 && (p.e.flags & AFD_WPT_SIGN)) ? 2 : 1;
@@ -216,18 +261,37 @@ bool plan_top(T3Params& p, int L) {
     return true;
 }
 
-template <int L, int FIN>
-int launch_top(const T3Params& p, hipStream_t stream) {
+// the runtime plan is exactly the compile-time geometry of Std3<L> (the standard frame at 8 levels)
+template <int L>
+bool is_std_plan(const T3Params& p) {
+    using SG = Std3<L>;
+    if (p.N != SG::N || p.Ks != SG::Ks || getenv("AFD_WPT_TOP_RUNTIME")) return false;
+    for (int k = 0; k <= SG::Ks; ++k)
+        if (p.n[k] != SG::n_at(k) || p.pitch[k] != SG::pitch_at(k) || p.off[k] != SG::off_at(k)) return false;
+    return true;
+}
+
+template <int L, int FIN, bool STD>
+int launch_top_as(const T3Params& p, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L, FIN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L, FIN, STD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTopLdsFloats * 4);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((wpt3_top_kernel<L, FIN>), dim3((unsigned)p.B * 2), dim3(kTopThreads),
+    hipLaunchKernelGGL((wpt3_top_kernel<L, FIN, STD>), dim3((unsigned)p.B * 2), dim3(kTopThreads),
                        (size_t)kTopLdsFloats * 4, stream, p);
     return afd::check_launch("wpt3_top_kernel");
+}
+
+template <int L, int FIN>
+int launch_top(const T3Params& p, hipStream_t stream) {
+    // the tap counts of the shipped and BASELINE configurations get the compile-time instance
+    if constexpr (L == 24 || L == 10 || L == 16) {
+        if (is_std_plan<L>(p)) return launch_top_as<L, FIN, true>(p, stream);
+    }
+    return launch_top_as<L, FIN, false>(p, stream);
 }
 
 template <int L>

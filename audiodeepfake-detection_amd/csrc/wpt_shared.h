@@ -60,9 +60,10 @@ __device__ __forceinline__ void put(float* node, int i, int n, float v) {
 // A work item is a PAIR of neighbouring outputs (i, i + 1), i even: their windows share L - 2 of L samples,
 // so the item reads L + 2 samples as 16-byte vectors (7 ds_read_b128 for 24 taps, lanes 16 bytes apart:
 // conflict-free) and both filters run over registers.
-template <int L>
+// (W outputs per item: W = 2 above; the compile-time-geometry levels of the top kernel take W = 4 -- L + 6 samples)
+template <int L, int W = 2>
 struct Window {
-    static constexpr int NV = (L + 2 + 3) / 4;
+    static constexpr int NV = (L + 2 * (W - 1) + 3) / 4;
     float w[4 * NV];
     __device__ __forceinline__ void load(const float* __restrict__ src) {
         const f4* s4 = reinterpret_cast<const f4*>(src);
