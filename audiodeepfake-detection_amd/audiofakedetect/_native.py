@@ -39,6 +39,11 @@ _SIGNATURES = {
     "afd_wpt_forward": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i,
                               c_u, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_sz, c_p]),
     "afd_wpt_lattice": (c_i, [ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i] + [ctypes.POINTER(ctypes.c_double)] * 4),
+    "afd_rccl_unique_id": (c_i, [c_p]),
+    "afd_rccl_init": (c_i, [c_p, c_i, c_i]),
+    "afd_rccl_all_reduce_sum": (c_i, [c_p, c_l, c_i, c_p]),
+    "afd_rccl_world": (c_i, []),
+    "afd_rccl_destroy": (c_i, []),
     "afd_stft_dims": (c_i, [c_i, c_i, c_i] + [ctypes.POINTER(c_i)] * 4),
     "afd_stft_basis": (c_i, [c_i, c_p]),
     "afd_stft_forward": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_u, c_f, c_f, c_f, c_f, c_p, c_p]),

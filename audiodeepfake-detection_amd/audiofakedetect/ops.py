@@ -514,6 +514,52 @@ def _dist_on(sync: bool) -> bool:
     return sync and multi_rank()
 
 
+_direct_rccl = False
+
+
+def enable_direct_rccl() -> bool:
+    """OPT-IN (AFD_RCCL_DIRECT=1, called by `ddp_setup` / the tools): a second RCCL communicator inside libafd_hip,
+    created from a unique id that rank 0 draws and the existing process group broadcasts; the in-step collectives
+    (`all_reduce_sum`) then run as ncclAllReduce ON THE COMPUTE STREAM instead of going through c10d's stream hand-off
+    (~55 us of GPU idle per collective, profiles/r04_ddp1_collectives.json).  Validated with one rank only -- no box
+    with two GPUs has run it -- which is why it is not the default.  Returns whether the direct path is up."""
+    global _direct_rccl
+    if _direct_rccl:
+        return True
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+        return False
+    lib = _native.load()
+    import ctypes
+    buf = ctypes.create_string_buffer(128)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if dist.get_rank() == 0:
+        _native.check(lib.afd_rccl_unique_id(buf), "afd_rccl_unique_id")
+        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+    dist.broadcast(uid, src=0)
+    raw = bytes(uid.cpu().tolist())
+    _native.check(lib.afd_rccl_init(ctypes.c_char_p(raw), dist.get_rank(), dist.get_world_size()), "afd_rccl_init")
+    _direct_rccl = True
+    return True
+
+
+def disable_direct_rccl() -> None:
+    global _direct_rccl
+    if _direct_rccl:
+        _native.load().afd_rccl_destroy()
+        _direct_rccl = False
+
+
+def all_reduce_sum(t: torch.Tensor) -> None:
+    """In-place sum of `t` over the ranks: ncclAllReduce on the current stream when the direct communicator is up and
+    the tensor qualifies (contiguous float32 / float64 on the GPU), `dist.all_reduce` otherwise."""
+    if _direct_rccl and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64):
+        _native.check(_native.load().afd_rccl_all_reduce_sum(_native.ptr(t), t.numel(), 1 if t.dtype == torch.float64 else 0,
+                                                             _native.stream_ptr()), "afd_rccl_all_reduce_sum")
+    else:
+        dist.all_reduce(t)
+
+
 def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=None, nbt=None,
                 momentum=0.1):
     """Batch statistics from the packed per-channel [sum | sum of squares | count] vector.
@@ -525,7 +571,7 @@ def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=
     """
     if _dist_on(sync):
         sums[2 * c] = local_count
-        dist.all_reduce(sums)
+        all_reduce_sum(sums)
         cnt = sums[2 * c].clone()
     else:
         cnt = torch.tensor(float(local_count), dtype=torch.float64, device=sums.device)
@@ -571,7 +617,7 @@ class _BatchNorm(torch.autograd.Function):
                 dist_on = _dist_on(sync)
                 if dist_on:
                     sums[2 * c] = count
-                    dist.all_reduce(sums)
+                    all_reduce_sum(sums)
                 mean = torch.empty(c, dtype=torch.float32, device=dev)
                 invstd = torch.empty(c, dtype=torch.float32, device=dev)
                 cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
@@ -652,7 +698,7 @@ class _BatchNorm(torch.autograd.Function):
             dgamma = sums[c:].float()
         if _dist_on(sync):
             sums = sums.clone()
-            dist.all_reduce(sums)
+            all_reduce_sum(sums)
         mdy = torch.empty(c, dtype=torch.float32, device=x.device)
         mdyx = torch.empty(c, dtype=torch.float32, device=x.device)
         on_dev = torch.is_tensor(ctx.count)
@@ -706,7 +752,7 @@ def _fold_backward(gw, db, w2, mean, invstd, count, sync, need_affine):
     if not need_affine:
         return dw, None, None
     if _dist_on(sync):
-        dist.all_reduce(sums)
+        all_reduce_sum(sums)
     alpha = torch.empty(c, dtype=torch.float32, device=w2.device)
     beta = torch.empty(c, dtype=torch.float32, device=w2.device)
     on_dev = torch.is_tensor(count)
@@ -744,7 +790,7 @@ class _BNConv1x1(torch.autograd.Function):
             dist_on = _dist_on(sync)
             if dist_on:
                 sums[2 * c] = count
-                dist.all_reduce(sums)
+                all_reduce_sum(sums)
             mean = torch.empty(c, dtype=torch.float32, device=dev)
             invstd = torch.empty(c, dtype=torch.float32, device=dev)
             cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
@@ -835,7 +881,7 @@ def _bn_finalize_sums(sums, c, count, bn, sync):
     dist_on = _dist_on(sync)
     if dist_on:
         sums[2 * c] = count
-        dist.all_reduce(sums)
+        all_reduce_sum(sums)
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     invstd = torch.empty(c, dtype=torch.float32, device=dev)
     cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
@@ -922,7 +968,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
                 _native.ptr(z), _native.ptr(slope), _native.ptr(g), _native.ptr(mean2), _native.ptr(invstd2),
                 _native.ptr(sums), n, cout, hw, _native.stream_ptr()), "afd_bn_backward_stats")
         if _dist_on(sync):
-            dist.all_reduce(sums)
+            all_reduce_sum(sums)
         mdy = torch.empty(cout, dtype=torch.float32, device=dev)
         mdyx = torch.empty(cout, dtype=torch.float32, device=dev)
         on_dev = torch.is_tensor(cnt2)

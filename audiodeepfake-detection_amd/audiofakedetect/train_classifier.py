@@ -40,6 +40,8 @@ def ddp_setup() -> None:
     """Join the process group (RCCL) and bind this process to its GPU."""
     dist.init_process_group(backend="nccl")
     torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    if os.environ.get("AFD_RCCL_DIRECT"):  # opt-in: the in-step collectives on the compute stream (ops.enable_direct_rccl)
+        ops.enable_direct_rccl()
 
 
 def is_lead(args: DotDict) -> bool:
@@ -82,7 +84,7 @@ def sync_gradients(model: torch.nn.Module, optimizer) -> float:
             work.wait()
             return 1.0 / world
         ops._end_of_backward.clear()  # a hook whose backward never reached the loss node (foreign loss function)
-        dist.all_reduce(optimizer.flat_grad)
+        ops.all_reduce_sum(optimizer.flat_grad)
         return 1.0 / world
     for p in model.parameters():
         if p.grad is not None:
@@ -109,6 +111,13 @@ def _loader(args: DotDict, ds, train: bool):
                       persistent_workers=workers > 0)
 
 
+class _Done:
+    """Stand-in for a c10d work handle of a collective that was issued in stream order."""
+
+    def wait(self) -> None:
+        return None
+
+
 def start_gradient_allreduce(optimizer) -> None:
     """Arrange for the arena all-reduce to be issued by the autograd engine itself when the coming backward
     pass ends (ops.at_end_of_backward): RCCL gets the collective the moment the last gradient kernel has been
@@ -125,7 +134,12 @@ def start_gradient_allreduce(optimizer) -> None:
         stale.wait()
 
     def fire() -> None:
-        optimizer._pending_allreduce = dist.all_reduce(optimizer.flat_grad, async_op=True)
+        if ops._direct_rccl:
+            # on the compute stream, behind the last gradient kernel: nothing to wait for on the host
+            ops.all_reduce_sum(optimizer.flat_grad)
+            optimizer._pending_allreduce = _Done()
+        else:
+            optimizer._pending_allreduce = dist.all_reduce(optimizer.flat_grad, async_op=True)
 
     ops.at_end_of_backward(fire)
 

@@ -502,6 +502,22 @@ int afd_adam_step(float* params, const float* grads, float* m, float* v, size_t 
                   float beta1, float beta2, float eps, float weight_decay, int step,
                   float grad_scale, afd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * The in-step collectives of data-parallel training straight on RCCL, on the caller's stream (opt-in).
+ * Replaces: the NCCL all-reduces DistributedDataParallel and nn.SyncBatchNorm issue per step
+ *           (reference src/audiofakedetect/train_classifier.py:319-323, models.py:260-289), which through
+ *           torch.distributed pay a stream hand-off each.  librccl is taken from the process with dlopen.
+ * afd_rccl_unique_id : rank 0 fills 128 bytes [host]; the host layer broadcasts them to every rank
+ * afd_rccl_init      : every rank, on its own device: ncclCommInitRank(world, id, rank)
+ * afd_rccl_all_reduce_sum : in-place sum over the ranks of count f32 (is_double = 0) / f64 (1) values [dev]
+ * afd_rccl_world     : ranks of the communicator, 0 when none is up
+ * ---------------------------------------------------------------------------------- */
+int afd_rccl_unique_id(void* id128 /* [host] 128 bytes */);
+int afd_rccl_init(const void* id128 /* [host] */, int rank, int world);
+int afd_rccl_all_reduce_sum(void* buf, long count, int is_double, afd_stream_t stream);
+int afd_rccl_world(void);
+int afd_rccl_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

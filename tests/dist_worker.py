@@ -127,16 +127,75 @@ def gpu_dcnn(rank, world):
     assert int((d > 2e-5).sum()) <= d.numel() // 100, "Adam update differs"
 
 
+def gpu_one_rank_direct(rank, world):
+    """One RCCL rank with every collective of the step forced (AFD_FORCE_COLLECTIVES): the step through
+    torch.distributed and the step through the library's own communicator on the compute stream
+    (ops.enable_direct_rccl) give the same loss, gradients and BatchNorm running statistics -- a sum over one rank is
+    the identity either way."""
+    from audiofakedetect import ops
+    from audiofakedetect.models import DCNN
+    from audiofakedetect.train_classifier import DataParallelRCCL, start_gradient_allreduce, sync_gradients
+    from audiofakedetect.utils import DotDict
+
+    assert world == 1
+    os.environ["AFD_FORCE_COLLECTIVES"] = "1"
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 1, 256, 95, generator=g).cuda()
+    y = torch.randint(0, 2, (4,), generator=g).cuda()
+
+    def step():
+        torch.manual_seed(3)
+        a = DotDict(input_dim=[4, 1, 256, 95], ochannels1=64, ochannels2=64, ochannels3=96, ochannels4=128,
+                    ochannels5=32, kernel1=3, dropout_cnn=0.0, dropout_lstm=0.0, time_dim_add=1, flattend_size=320, ddp=True)
+        net = DCNN(a).cuda().train()
+        wrapped = DataParallelRCCL(net)
+        opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=1e-3)
+        opt.zero_grad()
+        loss = ops.CrossEntropyLoss()(wrapped(x), y)
+        start_gradient_allreduce(opt)
+        loss.backward()
+        assert getattr(opt, "_pending_allreduce", None) is not None
+        scale = sync_gradients(wrapped, opt)
+        torch.cuda.synchronize()
+        return loss.detach().clone(), opt.flat_grad.clone(), net.cnn[3].running_mean.clone(), scale
+
+    l0, g0, rm0, s0 = step()
+    assert ops.enable_direct_rccl() and _native_world() == 1
+    l1, g1, rm1, s1 = step()
+    ops.disable_direct_rccl()
+    assert s0 == s1 == 1.0
+    # (not bit for bit: a few sums of the step -- PReLU slope gradients, BatchNorm sums -- are float / double atomics
+    # whose order differs from run to run on either path)
+    assert abs(float(l0) - float(l1)) <= 1e-6, (float(l0), float(l1))
+    rel = ((g0 - g1).norm() / g0.norm()).item()
+    assert rel <= 1e-5, f"gradients through the direct communicator differ from the c10d ones: {rel}"
+    assert torch.allclose(rm0, rm1, atol=1e-6)
+    assert float(g0.abs().sum()) > 0.0
+
+
+def _native_world():
+    from audiofakedetect import _native
+
+    return _native.load().afd_rccl_world()
+
+
 if __name__ == "__main__":
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     # "gpu_dcnn_rccl": one rank per GPU over RCCL (backend "nccl" is RCCL on ROCm); the others over gloo
-    backend = "nccl" if mode.endswith("_rccl") else "gloo"
+    backend = "nccl" if "_rccl" in mode else "gloo"
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     try:
-        {"cpu_sync": cpu_sync, "gpu_dcnn": gpu_dcnn, "gpu_dcnn_rccl": gpu_dcnn}[mode](rank, world)
+        if mode == "gpu_dcnn_rccl_direct":  # the same sharded step with the in-step collectives on the compute stream
+            from audiofakedetect import ops
+
+            assert ops.enable_direct_rccl()
+        {"cpu_sync": cpu_sync, "gpu_dcnn": gpu_dcnn, "gpu_dcnn_rccl": gpu_dcnn, "gpu_dcnn_rccl_direct": gpu_dcnn,
+         "gpu_one_rank_direct_rccl": gpu_one_rank_direct}[mode](rank, world)
+        if mode == "gpu_dcnn_rccl_direct":
+            ops.disable_direct_rccl()
     finally:
         dist.destroy_process_group()
     print(f"rank {rank} ok")

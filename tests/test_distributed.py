@@ -20,12 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world2(mode, timeout=300, one_gpu_per_rank=False):
+def _run_world2(mode, timeout=300, one_gpu_per_rank=False, world=2):
     port = _free_port()
     procs = []
-    for rank in range(2):
+    for rank in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
-                   WORLD_SIZE="2", LOCAL_RANK=str(rank if one_gpu_per_rank else 0), OMP_NUM_THREADS="2",
+                   WORLD_SIZE=str(world), LOCAL_RANK=str(rank if one_gpu_per_rank else 0), OMP_NUM_THREADS="2",
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -64,6 +64,22 @@ def test_world2_rccl_sharded_dcnn_step_equals_full_batch_step():
     """The same check over RCCL (backend "nccl"), one rank per GPU: replica broadcast, packed SyncBN
     statistics and the flat gradient all-reduce travel over xGMI."""
     _run_world2("gpu_dcnn_rccl", one_gpu_per_rank=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two MI355X: one RCCL rank per GPU")
+def test_world2_direct_rccl_sharded_dcnn_step_equals_full_batch_step():
+    """The sharded step with the in-step collectives issued by the library itself on the compute stream
+    (ops.enable_direct_rccl: a second communicator from a broadcast unique id)."""
+    _run_world2("gpu_dcnn_rccl_direct", one_gpu_per_rank=True)
+
+
+@pytest.mark.gpu
+def test_one_rank_direct_rccl_step_equals_the_c10d_step():
+    """What one GPU can check of the direct path: librccl is found in the process, the communicator comes up from a
+    broadcast unique id, ncclAllReduce runs on the compute stream, and the forced-collectives step equals the step
+    through torch.distributed."""
+    _run_world2("gpu_one_rank_direct_rccl", world=1)
 
 
 @pytest.mark.gpu

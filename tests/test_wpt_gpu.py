@@ -43,7 +43,7 @@ def _check_coeffs(got, ref):
     ("haar", 1), ("haar", 2), ("haar", 8), ("haar", 14),
     ("sym5", 3), ("sym5", 8), ("sym5", 14),
     ("coif4", 1), ("coif4", 8), ("coif4", 9), ("coif4", 14),
-    ("db8", 7), ("db2", 10), ("db3", 5),
+    ("db8", 7), ("db8", 8), ("db8", 14), ("db2", 10), ("db3", 5),
 ])
 def test_coefficients_match_oracle(name, level):
     x = _parity_inputs()

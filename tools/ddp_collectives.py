@@ -31,22 +31,41 @@ def counted(t, *a, **kw):
     log.append((t.numel() * t.element_size(), str(t.dtype).replace("torch.", ""), bool(kw.get("async_op")), 1e6 * (time.perf_counter() - t0)))
     return r
 
-dist.all_reduce = counted
+def counted_async_only(t, *a, **kw):
+    # the synchronous calls arrive through ops.all_reduce_sum (counted there); the arena's async call comes straight here
+    return counted(t, *a, **kw) if kw.get("async_op") else real_all_reduce(t, *a, **kw)
+
+dist.all_reduce = counted_async_only
+from audiofakedetect import ops
+real_sum = ops.all_reduce_sum
+
+def counted_sum(t):
+    t0 = time.perf_counter()
+    real_sum(t)
+    log.append((t.numel() * t.element_size(), str(t.dtype).replace("torch.", ""), t.numel() > 100000, 1e6 * (time.perf_counter() - t0)))
+
+ops.all_reduce_sum = counted_sum
 out = {"world": 1, "backend": "rccl " + ".".join(str(v) for v in torch.cuda.nccl.version()),
        "note": "one rank, collectives forced (AFD_FORCE_COLLECTIVES=1): counts, payloads and HOST enqueue time; the device "
-               "cost of an exchange between GPUs is not measurable on one GPU", "workloads": {}}
+               "cost of an exchange between GPUs is not measurable on one GPU.  collectives_on = through torch.distributed "
+               "(c10d hands each to its own stream and back); collectives_on_direct_rccl = ncclAllReduce on the compute "
+               "stream from libafd_hip (ops.enable_direct_rccl, opt-in AFD_RCCL_DIRECT=1)", "workloads": {}}
 for w in ("coif4-l8", "coif4-l14"):
     torch.manual_seed(0)
     args, trainer, _ = bench.build(w, 128, True, dev)
     batch = bench.synthetic_batch(128, 0, dev)
     trainer.model.train()
     res = {}
-    runs = {"collectives_on": [], "collectives_off": []}
-    for forced in (False, True, False, True, False, True):  # alternating; the fastest run of each mode is reported
+    runs = {"collectives_on": [], "collectives_off": [], "collectives_on_direct_rccl": []}
+    for forced in (False, True, "direct", False, True, "direct", False, True, "direct"):  # alternating; the fastest run of each mode is reported
         if forced:
             os.environ["AFD_FORCE_COLLECTIVES"] = "1"
         else:
             os.environ.pop("AFD_FORCE_COLLECTIVES", None)
+        if forced == "direct":
+            assert ops.enable_direct_rccl()
+        else:
+            ops.disable_direct_rccl()
         for _ in range(8):
             trainer._run_batch(0, batch)
         torch.cuda.synchronize()
@@ -58,10 +77,10 @@ for w in ("coif4-l8", "coif4-l14"):
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        key = "collectives_on" if forced else "collectives_off"
+        key = "collectives_on_direct_rccl" if forced == "direct" else "collectives_on" if forced else "collectives_off"
         runs[key].append(1e3 * (t2 - t0) / n)
         res[key] = {"ms_per_step": min(runs[key]), "ms_per_step_runs": runs[key]}
-        if forced:
+        if forced is True:
             per_step = len(log) / n
             kinds2 = {}
             for nbytes, dtype, is_async, us in log:
@@ -74,6 +93,7 @@ for w in ("coif4-l8", "coif4-l14"):
             res["host_us_per_step_in_collective_calls"] = sum(v[3] for v in log) / n
     res["step_cost_of_issuing_them_ms"] = res["collectives_on"]["ms_per_step"] - res["collectives_off"]["ms_per_step"]
     res["share_of_step"] = res["step_cost_of_issuing_them_ms"] / res["collectives_off"]["ms_per_step"]
+    res["step_cost_direct_rccl_ms"] = res["collectives_on_direct_rccl"]["ms_per_step"] - res["collectives_off"]["ms_per_step"]
     out["workloads"][w] = res
     print(w, json.dumps(res), flush=True)
     del trainer, batch
@@ -81,4 +101,5 @@ for w in ("coif4-l8", "coif4-l14"):
 if len(sys.argv) > 1:
     with open(sys.argv[1], "w") as fh:
         json.dump(out, fh, indent=1)
+ops.disable_direct_rccl()
 dist.destroy_process_group()
