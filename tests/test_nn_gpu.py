@@ -1056,3 +1056,33 @@ def test_pooled_backward_at_benchmark_size_equals_its_two_frame_pieces():
     dx_all = dgrad(n)
     dx_two = dgrad(2)
     assert torch.equal(dx_all[:2], dx_two)
+
+
+def test_batchnorm_backward_sums_from_the_weight_gradient_at_full_width(monkeypatch):
+    """the BatchNorm backward's second sum, sum(dx * xhat), comes from the convolution's weights and
+    their fp32 gradient (afd_conv_weight_dot: sum_px dx[c] xhat[c] = sum_{co,k} w dw) instead of a pass over the
+    activations.  At the full level-14 width of block 4 ([N, 96, 6, 4096] -> 128 channels) and a batch of 32 the
+    BatchNorm's input gradient through that identity equals the one with AFD_BNSTATS_FROM_INPUT=1 (the sums taken from
+    the activations in double precision) to 5e-6 of its largest entry -- a precision regression in the weight
+    gradient would show here."""
+    torch.manual_seed(23)
+    n, cin, h, w, cout = 32, 96, 6, 4096, 128
+    x = torch.randn(n, cin, h, w, device="cuda")
+    dy = torch.randn(n, cout, h, w, device="cuda")
+    bn = torch.nn.BatchNorm2d(cin, affine=False).cuda().train()
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    slope = torch.full((1,), 0.25, device="cuda")
+    grads = []
+    for from_input in (True, False):
+        if from_input:
+            monkeypatch.setenv("AFD_BNSTATS_FROM_INPUT", "1")
+        else:
+            monkeypatch.delenv("AFD_BNSTATS_FROM_INPUT", raising=False)
+        conv.zero_grad()
+        z = x.clone().requires_grad_(True)
+        link = {}
+        y = ops.conv2d(ops.batch_norm(z, bn, slope, False, link), conv.weight, conv.bias, 1, 1, bn_link=link)
+        y.backward(dy)
+        grads.append((z.grad.clone(), conv.weight.grad.clone()))
+    _close(grads[1][0], grads[0][0].cpu(), 5e-6, "BatchNorm input gradient: w . dw sums vs activation sums")
+    _close(grads[1][1], grads[0][1].cpu(), 1e-6, "weight gradient on both paths")
