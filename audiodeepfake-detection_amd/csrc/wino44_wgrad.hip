@@ -10,15 +10,20 @@
 //
 //   wave      = one 16 (co) x 16 (ci) block of all 36 positions on v_mfma_f32_16x16x4_f32: 144 accumulator
 //               registers; a k-step is 4 tiles, lane = (channel = lane & 15, tile = lane >> 4) for both operands
-//   workgroup = 8 waves = COB x CIB blocks (2 x 4: 32 co x 64 ci, or 4 x 2: 64 co x 32 ci), one per CU
-//   round     = 2 k-steps (8 tiles).  Transform phase: the 2 (COB + CIB) operand sets of the round (a set = one
-//               16-channel block of one k-step: 64 (channel, tile) pairs, one per lane) are dealt over the waves
-//               -- every wave transforms at most one x patch (B^T d B, 6x6 from 6 rows x 24 bytes) and one dy tile
-//               (A dy A^T, 4x4 -> 6x6) -- and written to LDS as [set][position group of 4][lane][4]: the
-//               producer's lane layout IS the MFMA operand layout, so a consumer reads its own lane's 16 bytes.
+//   workgroup = 4 waves = 2 x 2 blocks (32 co x 32 ci), TWO per CU (74 KB of LDS each).  Round 4: the eight-wave
+//               forms of round 3 (2 x 4 / 4 x 2 blocks, one workgroup per CU) ran their transform and matrix phases
+//               in lockstep over the whole CU, so nothing covered a phase's load and barrier waits; two independent
+//               workgroups drift apart and fill each other's gaps -- block 3 at level 14 6.70 -> 6.06 ms, block 4
+//               4.31 -> 3.92 ms, although the 32 x 32 block transforms every x patch Cout / 32 times and every dy
+//               tile Cin / 32 times (eight waves: 3 x and 1 x on block 3)
+//   round     = 2 k-steps (8 tiles).  Transform phase: the round has 4 x sets and 4 dy sets (a set = one
+//               16-channel block of one k-step: 64 (channel, tile) pairs, one per lane); every wave transforms one
+//               x patch (B^T d B, 6x6 from 6 rows x 24 bytes) and one dy tile (A dy A^T, 4x4 -> 6x6) and writes
+//               them to LDS as [set][position group of 4][lane][4]: the producer's lane layout IS the MFMA operand
+//               layout, so a consumer reads its own lane's 16 bytes.
 //               Matrix phase: per k-step and position group one ds_read_b128 per operand, four MFMAs.
-//               110 KB of LDS, single-buffered (f32 matrix instructions and vector instructions do not overlap on
-//               a SIMD -- tools/micro/coexec.hip -- so running the phases back to back costs nothing extra);
+//               Single-buffered (f32 matrix instructions and vector instructions do not overlap on a SIMD --
+//               tools/micro/coexec.hip -- so within a workgroup the phases run back to back);
 //               the next round's patches are requested from memory before the matrix phase.
 //   grid      = (channel groups) x S splits of the tile sequence (n, column group, tile row), tile row fastest so
 //               that consecutive k-steps share their two halo rows in L1 / L2; every workgroup writes its partial
@@ -47,7 +52,9 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 constexpr int kPos = 36;
 constexpr int kSetFloats = 9 * 64 * 4;  // one operand set: [position group][lane][4]
-constexpr int kThreadsW = 512;
+constexpr int kThreadsW = 256;
+constexpr int COB = 2, CIB = 2, NW = COB * CIB;  // blocks of a workgroup along co / ci, waves
+constexpr int kSets = 2 * (COB + CIB);           // operand sets of a round
 
 struct GW {
     int N, Cin, Cout, H, W;
@@ -112,11 +119,10 @@ __device__ __forceinline__ Unit decode_unit(long u, long end, const GW& g) {
 
 typedef unsigned short u16u __attribute__((aligned(1)));
 
-template <int COB, int CIB, bool PDY = false>
+template <bool PDY = false>
 __global__ void __launch_bounds__(kThreadsW) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __restrict__ dy) {
-    static_assert(COB * CIB == 8, "eight waves");
-    extern __shared__ __attribute__((aligned(16))) float sets[];  // [2 (CIB + COB)][9][64][4]
+    extern __shared__ __attribute__((aligned(16))) float sets[];  // [kSets][9][64][4]
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
@@ -135,14 +141,10 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     long u_end = u_begin + g.units_per_split;
     u_end = u_end < g.units ? u_end : g.units;
 
-    // transform jobs of this wave: at most one x patch set and one dy tile set per round
-    //   2 x 4: x sets 8 (every wave: block w & 3 of k-step w >> 2), dy sets 4 (waves 4-7: block (w - 4) & 1 of k-step (w - 4) >> 1)
-    //   4 x 2: x sets 4 (waves 0-3: block w & 1 of k-step w >> 1), dy sets 8 (every wave: block w & 3 of k-step w >> 2)
-    constexpr bool kAllX = CIB == 4;
-    const bool has_x = kAllX || wave < 4;
-    const bool has_d = !kAllX || wave >= 4;
-    const int xb = kAllX ? (wave & 3) : (wave & 1), xks = kAllX ? (wave >> 2) : (wave >> 1);
-    const int db_ = kAllX ? ((wave - 4) & 1) : (wave & 3), dks = kAllX ? ((wave - 4) >> 1) : (wave >> 2);
+    // transform jobs of this wave: the x set and the dy set (block wave & 1 of k-step wave >> 1)
+    static_assert(COB == 2 && CIB == 2 && NW == 4, "one x set and one dy set per wave and round");
+    const int xb = wave & 1, xks = wave >> 1;
+    const int db_ = wave & 1, dks = wave >> 1;
     // set indices: x sets [ks][b] first, then dy sets [ks][a]
     float* my_xset = sets + (size_t)(xks * CIB + xb) * kSetFloats + lane * 4;
     float* my_dset = sets + (size_t)(2 * CIB + dks * COB + db_) * kSetFloats + lane * 4;
@@ -358,16 +360,24 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     for (int p = 0; p < kPos; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const bool want_bias = g.partb != nullptr && (cg % g.cig) == 0;
-    if (has_x) load_x(u_begin);
+    // A dy tile with at most three live rows (the last tile row of an image whose rows are not a multiple of 4: 6-row
+    // images at level 14) has A dy A^T = 0 at the positions 30..35 (row 5 of A picks dy row 3): those six products of
+    // its k-step are skipped.  ty_first = tile row of the round's first k-step (uniform)
+    const int ty_short = (g.rows & 3) ? g.tilesY - 1 : -1;
+    int ty_first = (int)((unsigned)u_begin % (unsigned)g.tilesY);
+    load_x(u_begin);
     for (long u0 = u_begin; u0 < u_end; u0 += 2) {
+        const int ty_second = ty_first + 1 < g.tilesY ? ty_first + 1 : 0;
+        const bool short0 = ty_first == ty_short, short1 = ty_second == ty_short;
+        ty_first = ty_second + 1 < g.tilesY ? ty_second + 1 : 0;
         // the dy tile (four 16-byte loads) is requested here and arrives during the x transform; only the x patch
         // (36 registers) is held across the matrix phase -- with the dy tile too the kernel spilled
-        if (has_d) load_d(u0);
-        if (has_x) transform_x();
-        if (has_d) transform_d(want_bias);
+        load_d(u0);
+        transform_x();
+        transform_d(want_bias);
         __syncthreads();
         // the coming round's patch travels during the matrix phase
-        if (has_x && u0 + 2 < u_end) load_x(u0 + 2);
+        if (u0 + 2 < u_end) load_x(u0 + 2);
         // operands of position group pg + 1 are requested before the four matrix instructions of group pg
         const float* as0 = sets + (size_t)(2 * CIB + wa) * kSetFloats + lane * 4;
         const float* bs0 = sets + (size_t)wb * kSetFloats + lane * 4;
@@ -382,13 +392,15 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
                 bn = *reinterpret_cast<const f32x4*>(bs0 + (size_t)ks1 * CIB * kSetFloats + pg1 * 256);
             }
             __builtin_amdgcn_sched_barrier(0);
+            const bool short_ks = ks ? short1 : short0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
+                if (4 * pg + q >= 30 && short_ks) continue;  // uniform
                 acc[4 * pg + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], bv[q], acc[4 * pg + q], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             av = an;
             bv = bn;
-            (void)ks;
         }
         __syncthreads();
     }
@@ -400,7 +412,7 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     for (int p = 0; p < kPos; ++p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) sl[((size_t)p * g.Cout + co + j) * g.Cin + ci] = acc[p][j];
-    if (want_bias && has_d) {
+    if (want_bias) {
         // this wave summed dy over the tiles (lane >> 4) of its k-steps for channel lane & 15 of block db_;
         // the partials of the waves holding the same block (other k-step) are added by the reduce kernel
         float s = bsum;
@@ -469,18 +481,15 @@ __global__ void __launch_bounds__(256) wino44_wgrad_g_kernel(const float* __rest
     }
 }
 
-int pick_shape(int Cin, int Cout) {
-    if (Cout % 64 == 0 && Cin % 32 == 0) return 42;
-    if (Cout % 32 == 0 && Cin % 64 == 0) return 24;
-    return 0;
-}
+bool shape_ok(int Cin, int Cout) { return Cout % (16 * COB) == 0 && Cin % (16 * CIB) == 0; }
 
-// workgroups aimed at in all: one is resident per CU (110 KB of LDS) and all do the same work, so the grid should
-// be a whole number of rounds over the 256 CUs -- 264 workgroups take as long as 512 (measured: 256-aimed grids of
-// 264 ran 13.3 ms against 6.6 ms for 768).  AFD_WW_WGS overrides (development); the workspace bound follows it.
+// workgroups aimed at in all: two are resident per CU (74 KB of LDS each) and all do the same work, so the grid
+// should be a whole number of rounds over the 512 slots -- three rounds (measured on block 3 / block 4 at level 14:
+// 1024 6.32 / 4.11 ms, 1536 6.09 / 3.93, 2048 6.14 / 3.98, 3072 6.11 / 3.98).  AFD_WW_WGS overrides (development);
+// the workspace bound follows it.
 int target_wgs() {
     const char* e = getenv("AFD_WW_WGS");
-    const int v = e ? atoi(e) : 768;
+    const int v = e ? atoi(e) : 1536;
     return v < 8 ? 8 : (v > 8192 ? 8192 : v);
 }
 
@@ -492,10 +501,8 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     g.tilesY = (g.rows + 3) / 4;
     g.groupsX = (g.tilesX + 3) / 4;
     g.units = (long)N * g.groupsX * g.tilesY;
-    const int shape = pick_shape(Cin, Cout);
-    const int cob = shape / 10, cib = shape % 10;
-    g.cig = Cin / (16 * cib);
-    const int cgroups = g.cig * (Cout / (16 * cob));
+    g.cig = Cin / (16 * CIB);
+    const int cgroups = g.cig * (Cout / (16 * COB));
     // three, two or one rounds of workgroups over the CUs (see target_wgs), each workgroup with at least 8 rounds
     // of its own; a smaller problem gets as many splits as that allows
     const long max_s = g.units / 16 > 0 ? g.units / 16 : 1;
@@ -530,7 +537,7 @@ bool wino44_wgrad_crop_ok(int H, int W, int dy_rows, int dy_cols) {
 bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil) {
     if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44_WGRAD")) return false;
     if (K != 3 || pad != 1 || dil != 1) return false;
-    if (!pick_shape(Cin, Cout)) return false;
+    if (!shape_ok(Cin, Cout)) return false;
     if (W < 8 || H < 2) return false;
     return (size_t)H * W * 16 < 0x7fffffffULL;  // 32-bit lane offsets inside a 16-channel block
 }
@@ -539,9 +546,8 @@ bool wino44_wgrad_applicable(int Cin, int H, int W, int Cout, int K, int pad, in
 // cropped launch can come out a few higher than the uncropped one's through the rounding of units per split).
 size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols) {
     (void)N; (void)H; (void)W; (void)dy_rows; (void)dy_cols;
-    const int shape = pick_shape(Cin, Cout);
-    if (!shape) return 0;
-    const int cgroups = (Cin / (16 * (shape % 10))) * (Cout / (16 * (shape / 10)));
+    if (!shape_ok(Cin, Cout)) return 0;
+    const int cgroups = (Cin / (16 * CIB)) * (Cout / (16 * COB));
     const size_t smax = (size_t)(target_wgs() / cgroups > 0 ? target_wgs() / cgroups : 1);
     const size_t m = (size_t)kPos * Cout * Cin;
     return smax * m + m + smax * 2 * Cout;
@@ -568,31 +574,27 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     g.slab = static_cast<float*>(ws);
     float* red = g.slab + (size_t)g.S * m;
     g.partb = dbias ? red + m : nullptr;
-    const int shape = pick_shape(Cin, Cout);
-    const int cgroups = g.cig * (Cout / (16 * (shape / 10)));
-    const size_t lds = (size_t)12 * kSetFloats * sizeof(float);
+    const int cgroups = g.cig * (Cout / (16 * COB));
+    const size_t lds = (size_t)kSets * kSetFloats * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipSuccess;
-        const void* fns[4] = {reinterpret_cast<const void*>(&wino44_wgrad_kernel<2, 4>),
-                              reinterpret_cast<const void*>(&wino44_wgrad_kernel<4, 2>),
-                              reinterpret_cast<const void*>(&wino44_wgrad_kernel<2, 4, true>),
-                              reinterpret_cast<const void*>(&wino44_wgrad_kernel<4, 2, true>)};
-        for (int i = 0; i < 4 && e == hipSuccess; ++i)
-            e = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd backward-weight: %s", hipGetErrorString(e));
         attr = true;
     }
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     // 36 GEMMs [Cout x Cin] with K = every tile of every k-step (tile padding included)
-    timing.issued(2.0 * kPos * (double)Cout * Cin * 4.0 * (double)g.units);
+    // (less the six positions skipped per k-step of a short tile row)
+    const double short_units = (g.rows & 3) ? (double)N * g.groupsX : 0.0;
+    timing.issued(2.0 * (double)Cout * Cin * 4.0 * (kPos * (double)g.units - 6.0 * short_units));
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols * (pooled_codes ? 0.3125 : 1.0)));
     const unsigned grid = (unsigned)(cgroups * ((g.S + 7) / 8) * 8);
-    if (pooled_codes) {
-        if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4, true>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
-        else hipLaunchKernelGGL((wino44_wgrad_kernel<4, 2, true>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
-    } else if (shape == 24) hipLaunchKernelGGL((wino44_wgrad_kernel<2, 4>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
-    else hipLaunchKernelGGL((wino44_wgrad_kernel<4, 2>), dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+    if (pooled_codes) hipLaunchKernelGGL(wino44_wgrad_kernel<true>, dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
+    else hipLaunchKernelGGL(wino44_wgrad_kernel<false>, dim3(grid), dim3(kThreadsW), lds, s, g, x, dy);
     int rc = afd::check_launch("wino44_wgrad_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(wino44_wgrad_reduce_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, g.slab, red, (long)m, g.S);
