@@ -289,7 +289,14 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     for (int p = 0; p < kPos; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // U fragments of chunk c, position p (four k-steps): Uw[((c * 36 + p) * CG) * 256]
-    const float* Uw = U + (size_t)wave * PS + lane * KS;
+    // Buffer loads: the table is the buffer, the lane's 4 KS bytes-offset the vector offset, (chunk, position, wave)
+    // the scalar offset -- the 36 offsets of a chunk cost scalar adds.  As 64-bit lane addresses (global_load) they
+    // cost two vector instructions per load, 72 per chunk INSIDE the matrix loop, where vector and f32 matrix
+    // instructions share the issue.  Reads past the table (there are none) would return zero.
+    const unsigned ubytes = (unsigned)g.nchunks * kPos * CG * PS * 4u;
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)ubytes, 0x00020000);
+    const unsigned ulane = (unsigned)lane * KS * 4u;
+    const unsigned Uw = (unsigned)wave * PS * 4u;  // scalar byte offset of this wave's fragments in a position block
     if (xf) {
         load_patch(0);
         store_v(0);
@@ -298,9 +305,13 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // positions in groups of 3: U fragments (L2) are requested two groups ahead of their MFMAs -- the first two groups
     // of a chunk during the previous chunk's last groups, i.e. before the transform -- and V fragments (LDS) one ahead
     vk u[3][3], b[2][3];
-    auto load_u = [&](const float* uc, int grp, int slot) {
+    auto load_u = [&](unsigned uc, int grp, int slot) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) u[slot][q] = *reinterpret_cast<const vk*>(uc + (size_t)(3 * grp + q) * CG * PS);
+        for (int q = 0; q < 3; ++q) {
+            const unsigned so = uc + (unsigned)(3 * grp + q) * CG * PS * 4u;
+            if constexpr (KS == 4) u[slot][q] = __builtin_bit_cast(vk, __builtin_amdgcn_raw_buffer_load_b128(urs, ulane, so, 0));
+            else u[slot][q] = __builtin_bit_cast(vk, __builtin_amdgcn_raw_buffer_load_b64(urs, ulane, so, 0));
+        }
     };
     if (mm) {
         load_u(Uw, 0, 0);
@@ -309,8 +320,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     for (int c = 0; c < g.nchunks; ++c) {
         const bool more = c + 1 < g.nchunks;
         if (xf && more) load_patch(c + 1);
-        const float* uc = Uw + (size_t)c * kPos * CG * PS;
-        const float* un = Uw + (size_t)(more ? c + 1 : c) * kPos * CG * PS;  // (the last chunk re-reads its own)
+        const unsigned uc = Uw + (unsigned)c * kPos * CG * PS * 4u;
+        const unsigned un = Uw + (unsigned)(more ? c + 1 : c) * kPos * CG * PS * 4u;  // (the last chunk re-reads its own)
         const float* vb = V + (c & 1) * VB + lane * KS;
         auto load_b = [&](int grp, int slot) {
 #pragma unroll
