@@ -113,24 +113,13 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
     }
     if (t >= g.ntiles) return;
     f32x16 acc[MW][NW];
-#pragma unroll
-    for (int m = 0; m < MW; ++m)
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
-    vec_t b[KC], bn[KC];
-    load_chunk(t, 0, b);
-    int c = 0;
-    while (true) {
-        // the next chunk (of this tile or of the wave's next tile) is in flight during the MFMAs
-        int tn = t, cn = c + 1;
-        if (cn == nchunks) {
-            cn = 0;
-            tn = t + tstride;
-        }
-        const bool more = tn < g.ntiles;
-        if (more) load_chunk(tn, cn, bn);
+    // Tile loop outside, chunk loop inside: the accumulators are carried (as whole 16-register tuples) through the
+    // chunk loop only and are fresh per tile -- carried through ONE loop together with the epilogue's element-wise
+    // reads they lived as single registers and were copied into tuples and back around every chunk (256
+    // v_accvgpr moves per 64 matrix instructions).  Chunks in pairs on two buffers (the count is even: Kpad % 32 == 0):
+    // the next chunk -- of this tile or of the wave's next tile -- is in flight during the MFMAs of the present one.
+    vec_t b0[KC], b1[KC];
+    auto mma = [&](int c, const vec_t (&b)[KC]) {
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) {
             const float* arow = Ws + ((c * KC + ks) * 2 + half) * CO_PAD + l31;
@@ -143,7 +132,26 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
                 for (int i = 0; i < NW; ++i)
                     acc[m][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[ks][i], acc[m][i], 0, 0, 0);
         }
-        if (c == nchunks - 1) {
+    };
+    load_chunk(t, 0, b0);
+    while (true) {
+#pragma unroll
+        for (int m = 0; m < MW; ++m)
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
+        const int tn = t + tstride;
+        const bool more = tn < g.ntiles;
+        for (int c = 0; c < nchunks; c += 2) {
+            load_chunk(t, c + 1, b1);
+            mma(c, b0);
+            if (c + 2 < nchunks) load_chunk(t, c + 2, b0);
+            else if (more) load_chunk(tn, 0, b0);
+            mma(c + 1, b1);
+        }
+        {
+
             // D layout: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
             const int n = t / g.tiles_per_img;
             const int p = (t - n * g.tiles_per_img) * (32 * NW) + NW * l31;
@@ -232,18 +240,9 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
                     }
                 }
             }
-#pragma unroll
-            for (int m = 0; m < MW; ++m)
-#pragma unroll
-                for (int i = 0; i < NW; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][i][r] = 0.f;
         }
         if (!more) break;
-#pragma unroll
-        for (int ks = 0; ks < KC; ++ks) b[ks] = bn[ks];
         t = tn;
-        c = cn;
     }
     if constexpr (STATS) {
         // a register row is one output channel over the 32 lanes of a wave half
