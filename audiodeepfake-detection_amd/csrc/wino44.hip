@@ -20,6 +20,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -51,6 +52,9 @@ struct G4 {
     const unsigned char* pidx;
     int Hp, Wp;
 };
+
+// slot j' of a transform row holds position kSlotPos[j'] (see bt6h)
+__device__ constexpr int kSlotPos[6] = {0, 5, 1, 3, 2, 4};
 
 // U = G g G^T, G (6x3)
 __device__ __forceinline__ float g_row(int i, float a, float b, float c) {
@@ -87,7 +91,7 @@ __global__ void wino44_weights_kernel(const float* __restrict__ w, float* __rest
                 for (int kx = 0; kx < 3; ++kx)
                     g[ky][kx] = dgrad ? w[((size_t)ci * Cout + co) * 9 + (8 - (ky * 3 + kx))]
                                       : w[((size_t)co * Cin + ci) * 9 + ky * 3 + kx];
-            const int xi = p / 6, nu = p - 6 * xi;
+            const int xi = p / 6, nu = kSlotPos[p - 6 * xi];  // p is a SLOT of the transform row (see bt6h)
             float t[3];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) t[kx] = g_row(xi, g[0][kx], g[1][kx], g[2][kx]);
@@ -97,27 +101,48 @@ __global__ void wino44_weights_kernel(const float* __restrict__ w, float* __rest
     }
 }
 
-// B^T d along one axis
-__device__ __forceinline__ void bt6(const float d0, const float d1, const float d2, const float d3, const float d4,
-                                    const float d5, float* t) {
-    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
-    const float c = d4 - d2, e = d3 - d1;
-    t[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+// The transforms run on packed FMAs (v_pk_fma_f32: two floats per lane and instruction; round 4).  A 6 x 6 patch is
+// three column pairs per row.  The vertical pass is the usual 12-operation form on pairs; the horizontal pass works
+// INSIDE a row, the two halves of an instruction taking different constants:
+//     (a, c) = (-4, -1) t2 + t4,   (b, e) = (-4, -1) t1 + t3,   (o1, o3) = (a, c) + (1, 2) (b, e),
+//     (o2, o4) = (a, c) - (1, 2) (b, e),   (o0, o5) = 4 (t0, t1) - 5 (t2, t3) + (t4, t5)
+// -- 6 instructions per row instead of 12 (B^T d B: 72 instead of 144), every source an aligned register pair whose
+// halves op_sel picks.  The results come out as the pairs (o0, o5), (o1, o3), (o2, o4): the V image, the U table and
+// the accumulators use that SLOT order inside a transform row (slot 6 i + j' = position 6 i + kSlotPos[j']); the
+// output transform reads its columns through kPosSlot.
+__device__ constexpr int kPosSlot[6] = {0, 2, 4, 3, 5, 1};
+
+// B^T d along the rows of a column pair
+__device__ __forceinline__ void bt6v(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4,
+                                     const f32x2 d5, f32x2* t) {
+    const f32x2 a = -4.f * d2 + d4, b = -4.f * d1 + d3;
+    const f32x2 c = d4 - d2, e = d3 - d1;
+    t[0] = 4.f * d0 + (-5.f * d2 + d4);
     t[1] = a + b;
     t[2] = a - b;
-    t[3] = fmaf(2.f, e, c);
-    t[4] = fmaf(-2.f, e, c);
-    t[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    t[3] = 2.f * e + c;
+    t[4] = -2.f * e + c;
+    t[5] = 4.f * d1 + (-5.f * d3 + d5);
 }
 
-// A^T m along one axis
-__device__ __forceinline__ void at6(const float m0, const float m1, const float m2, const float m3, const float m4,
-                                    const float m5, float* y) {
-    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+// (t B) inside one row held as (t0, t1), (t2, t3), (t4, t5) -> slots (o0, o5), (o1, o3), (o2, o4)
+__device__ __forceinline__ void bt6h(const f32x2 p0, const f32x2 p1, const f32x2 p2, f32x2* o) {
+    const f32x2 k41 = {-4.f, -1.f}, k12 = {1.f, 2.f};
+    const f32x2 ac = k41 * p1.xx + p2.xx;
+    const f32x2 be = k41 * p0.yy + p1.yy;
+    o[0] = 4.f * p0 + (-5.f * p1 + p2);
+    o[1] = k12 * be + ac;
+    o[2] = -k12 * be + ac;
+}
+
+// A^T m along one axis, for the two channels of a register pair of the D fragment
+__device__ __forceinline__ void at6v(const f32x2 m0, const f32x2 m1, const f32x2 m2, const f32x2 m3, const f32x2 m4,
+                                     const f32x2 m5, f32x2* y) {
+    const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
     y[0] = m0 + s1 + s2;
-    y[1] = fmaf(2.f, d2, d1);
-    y[2] = fmaf(4.f, s2, s1);
-    y[3] = fmaf(8.f, d2, d1) + m5;
+    y[1] = 2.f * d2 + d1;
+    y[2] = 4.f * s2 + s1;
+    y[3] = (8.f * d2 + d1) + m5;
 }
 
 // HELP = 2 (six matrix waves): waves 6, 7 only load and transform patches, together with waves 2, 3 -- the waves of
@@ -266,21 +291,26 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                     d[r][j] = ok ? d[r][j] : 0.f;
                 }
         }
-        float t[6][6];  // t = B^T d: column j of d -> column j of t
+        f32x2 t[6][3];  // t = B^T d, column pairs
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float o[6];
-            bt6(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], o);
+        for (int c = 0; c < 3; ++c) {
+            f32x2 o[6];
+            bt6v(f32x2{d[0][2 * c], d[0][2 * c + 1]}, f32x2{d[1][2 * c], d[1][2 * c + 1]},
+                 f32x2{d[2][2 * c], d[2][2 * c + 1]}, f32x2{d[3][2 * c], d[3][2 * c + 1]},
+                 f32x2{d[4][2 * c], d[4][2 * c + 1]}, f32x2{d[5][2 * c], d[5][2 * c + 1]}, o);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) t[r][j] = o[r];
+            for (int r = 0; r < 6; ++r) t[r][c] = o[r];
         }
         float* vb = V + buf * VB + (kq_t * 16 + tl) * KS + ksx;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
-            float o[6];
-            bt6(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o);
+            f32x2 o[3];
+            bt6h(t[r][0], t[r][1], t[r][2], o);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) vb[(r * 6 + j) * PS] = o[j];
+            for (int q = 0; q < 3; ++q) {
+                vb[(r * 6 + 2 * q) * PS] = o[q].x;
+                vb[(r * 6 + 2 * q + 1) * PS] = o[q].y;
+            }
         }
     };
 
@@ -382,7 +412,28 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         if (have_x) load_xhat(0);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int jp = 0; jp < 2; ++jp) {
+    // Y = A^T M A for the channels 2 jp, 2 jp + 1 of the D fragment at once: acc[p][2 jp], acc[p][2 jp + 1] are a
+    // register pair, so both passes are packed instructions (100 per pair instead of 100 per channel)
+    f32x2 o2[4][4];
+    {
+        f32x2 sp[4][6];  // A^T M: rows of outputs x 6 slot columns
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            f32x2 o[4];
+            auto A = [&](int p) { return f32x2{acc[p][2 * jp], acc[p][2 * jp + 1]}; };
+            at6v(A(q), A(6 + q), A(12 + q), A(18 + q), A(24 + q), A(30 + q), o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[r][q] = o[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            at6v(sp[r][kPosSlot[0]], sp[r][kPosSlot[1]], sp[r][kPosSlot[2]], sp[r][kPosSlot[3]], sp[r][kPosSlot[4]],
+                 sp[r][kPosSlot[5]], o2[r]);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = 2 * jp + h;
         const int co = 16 * wave + 4 * kq + j;
         f4u zq[BST ? 4 : 1];
         if constexpr (BST) {
@@ -392,14 +443,6 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             sg[j] = sgv[j] = 0.f;
         }
         if constexpr (FST) sg[j] = sgv[j] = 0.f;
-        float s[4][6];  // A^T M: rows of outputs x 6 position columns
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            float o[4];
-            at6(acc[q][j], acc[6 + q][j], acc[12 + q][j], acc[18 + q][j], acc[24 + q][j], acc[30 + q][j], o);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[r][q] = o[r];
-        }
         const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
         if constexpr (POOL) {
             // same order and tie rule as prelu_pool_fwd_kernel (nn.hip): first maximum wins
@@ -410,9 +453,11 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     float o0[4], o1[4];
-                    at6(s[2 * pr][0], s[2 * pr][1], s[2 * pr][2], s[2 * pr][3], s[2 * pr][4], s[2 * pr][5], o0);
-                    at6(s[2 * pr + 1][0], s[2 * pr + 1][1], s[2 * pr + 1][2], s[2 * pr + 1][3], s[2 * pr + 1][4],
-                        s[2 * pr + 1][5], o1);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o0[q] = o2[2 * pr][q][h];
+                        o1[q] = o2[2 * pr + 1][q][h];
+                    }
                     const int py = 2 * ty + pr;
                     if (py < PH) {
                         float ub[2];
@@ -457,7 +502,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float o[4];
-                at6(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], s[r][5], o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = o2[r][q][h];
                 if (oy + r < g.rows) {
                     if constexpr (BST) {
                         // (interior columns: ox + 3 < cols and the clamped column is ox itself; the edge workgroups'
@@ -499,6 +545,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                 }
             }
         }
+    }
     }
     if constexpr (BST || FST) {
         // a channel's outputs of this workgroup sit in the 16 lanes of one quarter wave

@@ -46,6 +46,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -73,30 +74,61 @@ struct GW {
     int Hp, Wp;
 };
 
-// B^T d along one axis (wino44.hip)
-__device__ __forceinline__ void bt6w(const float d0, const float d1, const float d2, const float d3, const float d4,
-                                     const float d5, float* t) {
-    const float a = fmaf(-4.f, d2, d4), b = fmaf(-4.f, d1, d3);
-    const float c = d4 - d2, e = d3 - d1;
-    t[0] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+// The transforms run on packed FMAs (v_pk_fma_f32: two floats per lane and instruction).  A 6 x 6 patch is held as
+// three column pairs per row.  The vertical pass is the usual 12-operation form on pairs (both halves do the same);
+// the horizontal pass works INSIDE a row, where the two halves of an instruction take different constants:
+//     (a, c) = (-4, -1) t2 + t4,   (b, e) = (-4, -1) t1 + t3,   (o1, o3) = (a, c) + (1, 2) (b, e),
+//     (o2, o4) = (a, c) - (1, 2) (b, e),   (o0, o5) = 4 (t0, t1) - 5 (t2, t3) + (t4, t5)
+// -- 6 instructions per row instead of 12, every source an aligned register pair with its halves picked by op_sel.
+// Its results come out as the pairs (o0, o5), (o1, o3), (o2, o4): the operand sets, the accumulators and the products
+// use that SLOT order inside a transform row (slot 6 i + j' holds position 6 i + kSlotPos[j']); only the slab
+// store at the end of the kernel maps back.  B^T d B: 72 instructions (144 unpacked), A dy A^T: 46 (80).
+__device__ constexpr int kSlotPos[6] = {0, 5, 1, 3, 2, 4};
+
+// B^T d along the rows of a column pair
+__device__ __forceinline__ void bt6v(const f32x2 d0, const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4,
+                                     const f32x2 d5, f32x2* t) {
+    const f32x2 a = -4.f * d2 + d4, b = -4.f * d1 + d3;
+    const f32x2 c = d4 - d2, e = d3 - d1;
+    t[0] = 4.f * d0 + (-5.f * d2 + d4);
     t[1] = a + b;
     t[2] = a - b;
-    t[3] = fmaf(2.f, e, c);
-    t[4] = fmaf(-2.f, e, c);
-    t[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+    t[3] = 2.f * e + c;
+    t[4] = -2.f * e + c;
+    t[5] = 4.f * d1 + (-5.f * d3 + d5);
 }
 
-// A y along one axis: A = (A^T)^T of wino44.hip's at6, rows [1 0 0 0], [1 1 1 1], [1 -1 1 -1], [1 2 4 8],
-// [1 -2 4 -8], [0 0 0 1]
-__device__ __forceinline__ void a6w(const float y0, const float y1, const float y2, const float y3, float* t) {
-    const float s02 = y0 + y2, s13 = y1 + y3;
-    const float e = fmaf(4.f, y2, y0), o = fmaf(4.f, y3, y1);
+// (t B) inside one row held as (t0, t1), (t2, t3), (t4, t5) -> slots (o0, o5), (o1, o3), (o2, o4)
+__device__ __forceinline__ void bt6h(const f32x2 p0, const f32x2 p1, const f32x2 p2, f32x2* o) {
+    const f32x2 k41 = {-4.f, -1.f}, k12 = {1.f, 2.f};
+    const f32x2 ac = k41 * p1.xx + p2.xx;
+    const f32x2 be = k41 * p0.yy + p1.yy;
+    o[0] = 4.f * p0 + (-5.f * p1 + p2);
+    o[1] = k12 * be + ac;
+    o[2] = -k12 * be + ac;
+}
+
+// A y along the rows of a column pair: A = (A^T)^T of wino44.hip's at6, rows [1 0 0 0], [1 1 1 1], [1 -1 1 -1],
+// [1 2 4 8], [1 -2 4 -8], [0 0 0 1]
+__device__ __forceinline__ void a6v(const f32x2 y0, const f32x2 y1, const f32x2 y2, const f32x2 y3, f32x2* t) {
+    const f32x2 s02 = y0 + y2, s13 = y1 + y3;
+    const f32x2 e = 4.f * y2 + y0, o = 4.f * y3 + y1;
     t[0] = y0;
     t[1] = s02 + s13;
     t[2] = s02 - s13;
-    t[3] = fmaf(2.f, o, e);
-    t[4] = fmaf(-2.f, o, e);
+    t[3] = 2.f * o + e;
+    t[4] = -2.f * o + e;
     t[5] = y3;
+}
+
+// (t A^T) inside one row held as (y0, y1), (y2, y3) -> slots (o0, o5), (o1, o3), (o2, o4)
+__device__ __forceinline__ void a6h(const f32x2 p0, const f32x2 p1, f32x2* o) {
+    const f32x2 k14 = {1.f, 4.f}, k12 = {1.f, 2.f};
+    const f32x2 se = k14 * p1.xx + p0.xx;  // (y0 + y2, y0 + 4 y2)
+    const f32x2 so = k14 * p1.yy + p0.yy;  // (y1 + y3, y1 + 4 y3)
+    o[0] = f32x2{p0.x, p1.y};
+    o[1] = k12 * so + se;
+    o[2] = -k12 * so + se;
 }
 
 struct Unit {
@@ -274,29 +306,26 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
                 for (int j = 0; j < 6; ++j) d[r][j] = 0.f;
             }
         }
-        float t[6][6];  // t = B^T d
+        f32x2 t[6][3];  // t = B^T d, column pairs
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            float o[6];
-            bt6w(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j], o);
+        for (int c = 0; c < 3; ++c) {
+            f32x2 o[6];
+            bt6v(f32x2{d[0][2 * c], d[0][2 * c + 1]}, f32x2{d[1][2 * c], d[1][2 * c + 1]},
+                 f32x2{d[2][2 * c], d[2][2 * c + 1]}, f32x2{d[3][2 * c], d[3][2 * c + 1]},
+                 f32x2{d[4][2 * c], d[4][2 * c + 1]}, f32x2{d[5][2 * c], d[5][2 * c + 1]}, o);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) t[r][j] = o[r];
+            for (int r = 0; r < 6; ++r) t[r][c] = o[r];
         }
-        // second pass two rows at a time: 12 positions = three 16-byte stores, so only 12 results are live
+        // second pass two rows at a time: 12 slots = three 16-byte stores, so only 12 results are live
 #pragma unroll
         for (int r2 = 0; r2 < 3; ++r2) {
-            float v[12];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = 2 * r2 + h;
-                float o[6];
-                bt6w(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], t[r][5], o);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) v[6 * h + j] = o[j];
-            }
+            f32x2 o[6];
+            bt6h(t[2 * r2][0], t[2 * r2][1], t[2 * r2][2], o);
+            bt6h(t[2 * r2 + 1][0], t[2 * r2 + 1][1], t[2 * r2 + 1][2], o + 3);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                *reinterpret_cast<f32x4*>(my_xset + (3 * r2 + q) * 256) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(my_xset + (3 * r2 + q) * 256) =
+                    f32x4{o[2 * q].x, o[2 * q].y, o[2 * q + 1].x, o[2 * q + 1].y};
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -329,28 +358,24 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
             for (int r = 0; r < 4; ++r) s += (e[r][0] + e[r][1]) + (e[r][2] + e[r][3]);
             bsum += s;
         }
-        float t[6][4];  // t = A e
+        f32x2 t[6][2];  // t = A e, column pairs
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float o[6];
-            a6w(e[0][j], e[1][j], e[2][j], e[3][j], o);
+        for (int c = 0; c < 2; ++c) {
+            f32x2 o[6];
+            a6v(f32x2{e[0][2 * c], e[0][2 * c + 1]}, f32x2{e[1][2 * c], e[1][2 * c + 1]},
+                f32x2{e[2][2 * c], e[2][2 * c + 1]}, f32x2{e[3][2 * c], e[3][2 * c + 1]}, o);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) t[r][j] = o[r];
+            for (int r = 0; r < 6; ++r) t[r][c] = o[r];
         }
 #pragma unroll
         for (int r2 = 0; r2 < 3; ++r2) {
-            float v[12];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int r = 2 * r2 + h;
-                float o[6];
-                a6w(t[r][0], t[r][1], t[r][2], t[r][3], o);
-#pragma unroll
-                for (int j = 0; j < 6; ++j) v[6 * h + j] = o[j];
-            }
+            f32x2 o[6];
+            a6h(t[2 * r2][0], t[2 * r2][1], o);
+            a6h(t[2 * r2 + 1][0], t[2 * r2 + 1][1], o + 3);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                *reinterpret_cast<f32x4*>(my_dset + (3 * r2 + q) * 256) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(my_dset + (3 * r2 + q) * 256) =
+                    f32x4{o[2 * q].x, o[2 * q].y, o[2 * q + 1].x, o[2 * q + 1].y};
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -409,9 +434,11 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     float* sl = g.slab + (size_t)split * kPos * g.Cout * g.Cin;
     const int co = co0 + 16 * wa + 4 * lt, ci = ci0 + 16 * wb + lc;
 #pragma unroll
-    for (int p = 0; p < kPos; ++p)
+    for (int p = 0; p < kPos; ++p) {
+        const int pos = 6 * (p / 6) + kSlotPos[p % 6];  // accumulator slot -> transform position
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sl[((size_t)p * g.Cout + co + j) * g.Cin + ci] = acc[p][j];
+        for (int j = 0; j < 4; ++j) sl[((size_t)pos * g.Cout + co + j) * g.Cin + ci] = acc[p][j];
+    }
     if (want_bias) {
         // this wave summed dy over the tiles (lane >> 4) of its k-steps for channel lane & 15 of block db_;
         // the partials of the waves holding the same block (other k-step) are added by the reduce kernel
