@@ -15,6 +15,8 @@ input, dropout folded into the cnn->dil_conv permute, Linear+mean in one kernel.
 
 from __future__ import annotations
 
+from types import SimpleNamespace
+
 import torch
 import torch.nn as nn
 
@@ -58,6 +60,28 @@ class DCNN(nn.Module):
         self.single_gpu = not args.ddp
         self.sync_bn = bool(args.ddp)
 
+    def _next_normalises(self, step: int, shape) -> bool:
+        """May the BatchNorm that ends block `step`, applied to a tensor of `shape`, leave its normalisation to the
+        next block's 3x3 convolution (ops.batch_norm(defer=True))?  Mirrors the branch that block takes in `forward`."""
+        plan, cnn = self._cnn_plan, self.cnn
+        if not self.training or step + 1 >= len(plan) or plan[step][3] is None:
+            return False
+        conv_i, _, pooled, bn_i = plan[step + 1]
+        conv = cnn[conv_i]
+        after = plan[step + 2] if step + 2 < len(plan) else None
+        lib = ops._lib()
+        n, cin, h, w = shape
+        if pooled:
+            probe = SimpleNamespace(is_cuda=True, shape=shape)
+            if conv.in_channels == 1 or not ops.conv3x3_prelu_maxpool_applicable(probe, conv):
+                return False
+            folds_on = bn_i is not None and after is not None and ops.bn_conv1x1_applicable(cnn[bn_i], cnn[after[0]])
+            want_stats = (bn_i is not None and not folds_on
+                          and bool(lib.afd_conv3x3_forward_stats_applicable(cin, h, w, conv.out_channels, 1)))
+        else:
+            want_stats = bn_i is not None and conv.bias is not None
+        return ops.conv3x3_input_fold_applicable(cnn[plan[step][3]], conv, shape, pooled, want_stats)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # [batch, channels, packets, time] -> NCHW [batch, channels, time, packets]
         h = x.permute(0, 1, 3, 2)
@@ -90,8 +114,10 @@ class DCNN(nn.Module):
                     and ops.bn_conv1x1_prelu_bn_applicable(pending_bn, conv, cnn[bn_i])):
                 # training step of block 2: BatchNorm -> 1x1 convolution -> PReLU -> BatchNorm with a one-pass backward
                 bn_link = {}
+                # (the second BatchNorm's result is not stored when block 3's convolution can build it while it loads)
+                zshape = (h.shape[0], conv.out_channels, h.shape[2], h.shape[3])
                 h = ops.bn_conv1x1_prelu_bn(h, pending_bn, conv.weight, conv.bias, slope, cnn[bn_i],
-                                            self.sync_bn, link, bn_link)
+                                            self.sync_bn, link, bn_link, self._next_normalises(step, zshape))
                 pending_bn = link = None
                 continue
             link = None
@@ -125,10 +151,12 @@ class DCNN(nn.Module):
                     pending_bn = cnn[bn_i]
                 elif bn_i is not None:
                     bn_link = {}
-                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link, pool_link)
+                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link, pool_link,
+                                       defer=self._next_normalises(step, tuple(h.shape)))
             else:
                 bn_link = {}
-                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link, sum_link=sum_link)
+                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link, sum_link=sum_link,
+                                   defer=self._next_normalises(step, tuple(z.shape)))
         # Dropout + [batch, channels, time, packets] -> [batch, time, channels, packets]
         h = ops.dropout_permute(h, cnn[-1].p, self.training)
         dil = self.dil_conv

@@ -178,17 +178,60 @@ def transpose_contiguous(x: torch.Tensor) -> torch.Tensor:
     return _Transpose.apply(x)
 
 
-def _conv3x3_forward_stats(lib, x, w, b, slope, y, u, idx, geom, ws, link):
+def _conv3x3_forward_stats(lib, x, w, b, slope, y, u, idx, geom, ws, link, fold=None):
     """Runs the forward 3x3 convolution through `afd_conv3x3_forward_stats` and leaves the BatchNorm batch sums of
-    its result (packed [sum | sum of squares | count slot], as afd_bn_stats) in link["fwd_sums"]."""
+    its result (packed [sum | sum of squares | count slot], as afd_bn_stats) in link["fwd_sums"].  `fold`: see
+    `_take_fold`."""
     n, cin, h, wd, cout = geom
     sums = torch.empty(2 * cout + 1, dtype=torch.float64, device=x.device)
     sws = _ws(lib.afd_conv3x3_forward_stats_workspace_bytes(n, h, wd, cout), x.device, "fwdstats")
-    _native.check(lib.afd_conv3x3_forward_stats(
-        _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(y), _native.ptr(u),
-        _native.ptr(idx), _native.ptr(sums), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws),
-        sws.numel(), _native.stream_ptr()), "afd_conv3x3_forward_stats")
+    if fold is not None:
+        _native.check(lib.afd_conv3x3_forward_fold(
+            _native.ptr(x), _native.ptr(fold[0]), _native.ptr(fold[1]), _native.ptr(w), _native.ptr(b), _native.ptr(slope),
+            _native.ptr(y), _native.ptr(u), _native.ptr(idx), _native.ptr(sums), n, cin, h, wd, cout, _native.ptr(ws),
+            ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()), "afd_conv3x3_forward_fold")
+    else:
+        _native.check(lib.afd_conv3x3_forward_stats(
+            _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(y), _native.ptr(u),
+            _native.ptr(idx), _native.ptr(sums), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws),
+            sws.numel(), _native.stream_ptr()), "afd_conv3x3_forward_stats")
     link["fwd_sums"] = sums
+
+
+def _take_fold(bn_link, lib, geom, pooled: bool, want_stats: bool):
+    """The (aff, slope) pair a deferred BatchNorm left for this convolution (`batch_norm(..., defer=True)`): x is then
+    that BatchNorm's INPUT and the launches normalise it while they load.  Fails loudly when the layer is not on the
+    kernels that can (the caller asked `conv3x3_input_fold_applicable` before deferring)."""
+    fold = bn_link.pop("fold", None) if bn_link is not None else None
+    if fold is None:
+        return None
+    n, cin, h, wd, cout, k, pad, dil = geom
+    if not (k == 3 and pad == 1 and dil == 1
+            and lib.afd_conv3x3_input_fold_applicable(cin, h, wd, cout, int(pooled), int(want_stats))):
+        raise RuntimeError("a BatchNorm deferred its normalisation to a convolution that cannot apply it: "
+                           f"geometry {geom}, pooled={pooled}, statistics={want_stats}")
+    return fold
+
+
+def conv3x3_input_fold_applicable(bn: torch.nn.Module, conv: torch.nn.Module, shape, pooled: bool,
+                                  want_stats: bool) -> bool:
+    """May a training-mode BatchNorm(affine=False) on a tensor of `shape` leave its normalisation to `conv`, its only
+    consumer (`batch_norm(..., defer=True)`)?"""
+    import os
+    if os.environ.get("AFD_NO_INPUT_FOLD") or not torch.is_grad_enabled():
+        return False
+    if not (bn.training and bn.weight is None and bn.bias is None and bn.running_mean is not None):
+        return False
+    if (conv.kernel_size != (3, 3) or conv.padding != (1, 1) or conv.dilation != (1, 1) or conv.stride != (1, 1)
+            or conv.bias is None or not conv.weight.requires_grad):
+        return False
+    n, cin, h, w = shape
+    return bool(_lib().afd_conv3x3_input_fold_applicable(cin, h, w, conv.out_channels, int(pooled), int(want_stats)))
+
+
+def _pack_fold(mean, invstd):
+    """[C][2] = (mean, invstd): the table the folded launches read."""
+    return torch.stack((mean, invstd), dim=1).contiguous()
 
 
 # --------------------------------------------------------------------------------------
@@ -212,11 +255,16 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((n, cout, ho, wo), dtype=torch.float32, device=x.device)
         nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, k, pad, dil)
         ws = _ws(nbytes, x.device)
-        if (out_link is not None and out_link.get("want_stats") and k == 3 and pad == 1 and dil == 1 and not pooled
-                and x.is_cuda and lib.afd_conv3x3_forward_stats_applicable(cin, h, wd, cout, 0)):
+        want_stats = bool(out_link is not None and out_link.get("want_stats") and k == 3 and pad == 1 and dil == 1
+                          and not pooled and x.is_cuda and lib.afd_conv3x3_forward_stats_applicable(cin, h, wd, cout, 0))
+        fold = _take_fold(bn_link, lib, (n, cin, h, wd, cout, k, pad, dil), False, True)
+        if fold is not None and not want_stats:
+            raise RuntimeError("a BatchNorm deferred its normalisation to a convolution launch that cannot apply it")
+        ctx.fold = fold
+        if want_stats:
             # the only consumer is a training-mode BatchNorm of PReLU(y): its batch sums from this launch's epilogue
             _conv3x3_forward_stats(lib, x, w, b, out_link.get("stats_slope"), y, None, None, (n, cin, h, wd, cout), ws,
-                                   out_link)
+                                   out_link, fold)
         else:
             _native.check(lib.afd_conv2d_forward_cropped(
                 _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(y), n, cin, h, wd, cout, k,
@@ -236,11 +284,12 @@ class _Conv2d(torch.autograd.Function):
         dy_sums = ctx.out_link.pop("dy_sums", None) if ctx.out_link is not None else None
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dy,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link, dy_sums)
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link, dy_sums, ctx.fold)
         return dx, dw, db, None, None, None, None, None
 
 
-def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None, dy_sums=None):
+def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None, dy_sums=None,
+                     fold=None):
     """Backward-data on the current stream; backward-weight on the second stream, added straight into
     the FusedAdam gradient arena, when the parameters live there (see `_Conv2d`).  `bn_link`: when x was the
     output of a training-mode BatchNorm (which set "bn" there), the backward-data launch also produces that
@@ -261,12 +310,16 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
         # sum(dx * x) per channel equals sum over (cout, taps) of w * dw: with the weight gradient coming anyway, the
         # launch need not read x again
         dot_sums = need_dw and not lib.afd_conv3x3_backward_data_bnstats_needs_input(cin, h, wd, cout)
+        if fold is not None and not dot_sums:
+            raise RuntimeError("input fold: the backward-data launch of this layer needs the normalised tensor")
         _native.check(lib.afd_conv3x3_backward_data_bnstats(
             _native.ptr(dy), _native.ptr(w), _native.ptr(dx), None if dot_sums else _native.ptr(x), _native.ptr(sums),
             n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(), _native.stream_ptr()),
             "afd_conv3x3_backward_data_bnstats")
         bn_link["bwd_sums"] = sums
     elif need_dx:
+        if fold is not None:
+            raise RuntimeError("input fold: the BatchNorm in front of this layer gets no backward sums")
         dx = torch.empty_like(x)
         _native.check(lib.afd_conv2d_backward_data(
             _native.ptr(dy), _native.ptr(w), _native.ptr(dx), n, cin, h, wd, cout, k, pad, dil,
@@ -274,10 +327,17 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
     if need_dw or need_db:
         dw = torch.empty_like(w)
         db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-        _native.check(lib.afd_conv2d_backward_weight_sums(
-            _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), _native.ptr(dy_sums), n, cin, h,
-            wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
-            _native.stream_ptr()), "afd_conv2d_backward_weight")
+        if fold is not None:
+            # x is the input of the BatchNorm in front of this layer: normalised while the launch loads it
+            _native.check(lib.afd_conv3x3_backward_weight_fold(
+                _native.ptr(x), _native.ptr(fold[0]), _native.ptr(fold[1]), _native.ptr(dy), None, _native.ptr(dw),
+                _native.ptr(db), _native.ptr(dy_sums), n, cin, h, wd, cout, crop[0], crop[1], _native.ptr(ws), ws.numel(),
+                _native.stream_ptr()), "afd_conv3x3_backward_weight_fold")
+        else:
+            _native.check(lib.afd_conv2d_backward_weight_sums(
+                _native.ptr(x), _native.ptr(dy), _native.ptr(dw), _native.ptr(db), _native.ptr(dy_sums), n, cin, h,
+                wd, cout, k, pad, dil, crop[0], crop[1], _native.ptr(ws), ws.numel(),
+                _native.stream_ptr()), "afd_conv2d_backward_weight")
         if dot_sums:
             _native.check(lib.afd_conv_weight_dot(_native.ptr(w), _native.ptr(dw), cout, cin, k * k,
                                                   sums.data_ptr() + 8 * cin, _native.stream_ptr()), "afd_conv_weight_dot")
@@ -424,10 +484,18 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
         idx = _empty_with_slack((n, cout, h // 2, wd // 2), torch.uint8, x.device)
         nbytes = lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1)
         ws = _ws(nbytes, x.device)
-        if (out_link is not None and out_link.get("want_stats")
-                and lib.afd_conv3x3_forward_stats_applicable(cin, h, wd, cout, 1)):
+        want_stats = bool(out_link is not None and out_link.get("want_stats")
+                          and lib.afd_conv3x3_forward_stats_applicable(cin, h, wd, cout, 1))
+        fold = _take_fold(bn_link, lib, (n, cin, h, wd, cout, 3, 1, 1), True, want_stats)
+        ctx.fold = fold
+        if want_stats:
             # the only consumer is a training-mode BatchNorm of u: its batch sums from this launch's epilogue
-            _conv3x3_forward_stats(lib, x, w, b, slope, None, u, idx, (n, cin, h, wd, cout), ws, out_link)
+            _conv3x3_forward_stats(lib, x, w, b, slope, None, u, idx, (n, cin, h, wd, cout), ws, out_link, fold)
+        elif fold is not None:
+            _native.check(lib.afd_conv3x3_forward_fold(
+                _native.ptr(x), _native.ptr(fold[0]), _native.ptr(fold[1]), _native.ptr(w), _native.ptr(b),
+                _native.ptr(slope), None, _native.ptr(u), _native.ptr(idx), None, n, cin, h, wd, cout, _native.ptr(ws),
+                ws.numel(), None, 0, _native.stream_ptr()), "afd_conv3x3_forward_fold")
         else:
             _native.check(lib.afd_conv3x3_prelu_pool_forward(
                 _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
@@ -469,9 +537,15 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
                 "afd_conv3x3_backward_data_bnstats_pooled")
             dw = torch.empty_like(w)
             db = torch.empty(cout, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            _native.check(lib.afd_conv3x3_backward_weight_pooled(
-                _native.ptr(x), _native.ptr(gg), _native.ptr(idx), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
-                cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv3x3_backward_weight_pooled")
+            if ctx.fold is not None:
+                _native.check(lib.afd_conv3x3_backward_weight_fold(
+                    _native.ptr(x), _native.ptr(ctx.fold[0]), _native.ptr(ctx.fold[1]), _native.ptr(gg), _native.ptr(idx),
+                    _native.ptr(dw), _native.ptr(db), None, n, cin, h, wd, cout, h, wd, _native.ptr(ws), ws.numel(),
+                    _native.stream_ptr()), "afd_conv3x3_backward_weight_fold")
+            else:
+                _native.check(lib.afd_conv3x3_backward_weight_pooled(
+                    _native.ptr(x), _native.ptr(gg), _native.ptr(idx), _native.ptr(dw), _native.ptr(db), n, cin, h, wd,
+                    cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()), "afd_conv3x3_backward_weight_pooled")
             _native.check(lib.afd_conv_weight_dot(_native.ptr(w), _native.ptr(dw), cout, cin, 9,
                                                   sums.data_ptr() + 8 * cin, _native.stream_ptr()), "afd_conv_weight_dot")
             ctx.bn_link["bwd_sums"] = sums
@@ -479,7 +553,7 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
         dz, dslope = _pool_backward(u, slope, idx, du, (n, cout, h, wd), ctx.out_link)
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dz,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link)
+                                      ctx.has_bias and ctx.needs_input_grad[2], ctx.bn_link, None, ctx.fold)
         return dx, dw, db, dslope, None, None
 
 
@@ -595,7 +669,7 @@ def bn_finalize(sums, c, local_count, eps, sync, running_mean=None, running_var=
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, slope, gamma, beta, running_mean, running_var, nbt, training, momentum,
-                eps, sync, link=None, prod_link=None, sum_link=None, pre_sums=None):
+                eps, sync, link=None, prod_link=None, sum_link=None, pre_sums=None, defer=False):
         ctx.link = link
         ctx.prod_link = prod_link
         ctx.sum_link = sum_link
@@ -638,6 +712,18 @@ class _BatchNorm(torch.autograd.Function):
         else:
             mean = running_mean
             invstd = torch.rsqrt(running_var + eps)
+        if defer and training and gamma is None and link is not None and x.is_cuda:
+            # the convolution that consumes the result normalises x while it loads (`_take_fold`): no pass here, the
+            # result is never stored.  The backward below is unchanged: it takes the gradient of the normalised
+            # tensor from that convolution's backward-data launch, and never read the normalised tensor itself.
+            link["fold"] = (_pack_fold(mean, invstd), slope)
+            link["bn"] = True
+            empty = torch.empty(0)
+            if slope is not None:
+                _tap("prelu", x)
+            ctx.save_for_backward(x, slope if slope is not None else empty, mean, invstd, empty)
+            ctx.flags = (slope is not None, False, training, sync)
+            return x
         y = torch.empty_like(x)
         _native.check(lib.afd_bn_apply_forward(
             _native.ptr(x), _native.ptr(slope), _native.ptr(mean), _native.ptr(invstd),
@@ -679,7 +765,7 @@ class _BatchNorm(torch.autograd.Function):
                 neg = x <= 0
                 dslope = (g * x * neg).sum().reshape(1)
                 g = torch.where(neg, g * slope, g)
-            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+            return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]
@@ -713,7 +799,7 @@ class _BatchNorm(torch.autograd.Function):
                                                    _native.ptr(mdyx), _native.ptr(coef), c, _native.stream_ptr()),
                           "afd_bn_backward_coef")
             ctx.prod_link["affine_coef"] = coef
-            return dy, None, None, None, None, None, None, None, None, None, None, None, None, None, None
+            return dy, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         dx = torch.empty_like(x)
         dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
         # the per-channel sums of dx for the convolution that produced x (its bias gradient), from the same pass
@@ -725,7 +811,7 @@ class _BatchNorm(torch.autograd.Function):
             "afd_bn_backward_apply")
         if dxs is not None:
             ctx.sum_link["dy_sums"] = dxs
-        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _fold_forward(w2, b, mean, invstd):
@@ -918,7 +1004,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
     producer of u through `link` (or added here when there is no such producer)."""
 
     @staticmethod
-    def forward(ctx, u, w, b, slope, bn1, bn2, sync, link, out_link=None):
+    def forward(ctx, u, w, b, slope, bn1, bn2, sync, link, out_link=None, defer=False):
         ctx.out_link = out_link
         lib = _lib()
         u = _f32c(u)
@@ -938,10 +1024,15 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
             _native.ptr(sums2), n, c, cout, hw, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
             "afd_conv1x1_forward_stats")
         mean2, invstd2, cnt2 = _bn_finalize_sums(sums2, cout, float(n * hw), bn2, sync)
-        y = torch.empty_like(z)
-        _native.check(lib.afd_bn_apply_forward(
-            _native.ptr(z), _native.ptr(slope), _native.ptr(mean2), _native.ptr(invstd2), None, None,
-            _native.ptr(y), n, cout, hw, _native.stream_ptr()), "afd_bn_apply_forward")
+        if defer and out_link is not None:
+            # the 3x3 convolution behind the second BatchNorm applies PReLU and the normalisation while it loads z
+            out_link["fold"] = (_pack_fold(mean2, invstd2), slope)
+            y = z
+        else:
+            y = torch.empty_like(z)
+            _native.check(lib.afd_bn_apply_forward(
+                _native.ptr(z), _native.ptr(slope), _native.ptr(mean2), _native.ptr(invstd2), None, None,
+                _native.ptr(y), n, cout, hw, _native.stream_ptr()), "afd_bn_apply_forward")
         _tap("prelu", z)
         if out_link is not None:
             out_link["bn"] = True
@@ -1000,7 +1091,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
                 du = torch.addcmul(t + beta.view(1, -1, 1, 1), u, alpha.view(1, -1, 1, 1))
         return (du, dw.reshape(wshape) if ctx.needs_input_grad[1] else None,
                 db if (has_bias and ctx.needs_input_grad[2]) else None,
-                dslope if ctx.needs_input_grad[3] else None, None, None, None, None, None)
+                dslope if ctx.needs_input_grad[3] else None, None, None, None, None, None, None)
 
 
 def bn_conv1x1_prelu_bn_applicable(bn1: torch.nn.Module, conv: torch.nn.Module, bn2: torch.nn.Module) -> bool:
@@ -1013,15 +1104,17 @@ def bn_conv1x1_prelu_bn_applicable(bn1: torch.nn.Module, conv: torch.nn.Module, 
 
 
 def bn_conv1x1_prelu_bn(u, bn1, w, b, slope, bn2, sync: bool = True, link: Optional[dict] = None,
-                        out_link: Optional[dict] = None):
+                        out_link: Optional[dict] = None, defer: bool = False):
     """batch_norm2(PReLU(conv1x1(batch_norm1(u)))) in training mode with the one-pass backward of
     `_BNConv1x1PReLUBN`.  `link`: the dict given to `conv1_prelu_maxpool` when that call produced u;
-    `out_link`: as `batch_norm`'s `link`, for the second BatchNorm and the convolution that consumes the result."""
-    return _BNConv1x1PReLUBN.apply(u, w, b, slope, bn1, bn2, sync, link, out_link)
+    `out_link`: as `batch_norm`'s `link`, for the second BatchNorm and the convolution that consumes the result;
+    `defer`: as `batch_norm`'s, for the second BatchNorm (z comes back instead of the normalised tensor)."""
+    return _BNConv1x1PReLUBN.apply(u, w, b, slope, bn1, bn2, sync, link, out_link, bool(defer))
 
 
 def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, sync: bool = True,
-               link: Optional[dict] = None, prod_link: Optional[dict] = None, sum_link: Optional[dict] = None):
+               link: Optional[dict] = None, prod_link: Optional[dict] = None, sum_link: Optional[dict] = None,
+               defer: bool = False):
     """BatchNorm (batch statistics across all ranks when a process group is up) of
     PReLU(x) if `slope` is given, else of x.  `bn` carries weight/bias/running stats.  `link`: a dict shared with
     the convolution that is the ONLY consumer of the result (its `bn_link`): that layer's backward-data launch
@@ -1029,7 +1122,9 @@ def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, syn
     produced x (its `out_link`, this layer being the ONLY consumer of x): in training mode and without affine
     parameters this layer's backward is then applied inside the pool's backward.  `sum_link`: a dict shared with the
     convolution that produced x (its `out_link`, this layer being the ONLY consumer of x): the backward pass leaves
-    the per-channel sums of its result there -- that convolution's bias gradient."""
+    the per-channel sums of its result there -- that convolution's bias gradient.  `defer` (with `link`; the caller
+    asked `conv3x3_input_fold_applicable`): the result is NOT computed -- x itself comes back, and the consuming
+    convolution, handed `link` as its `bn_link`, normalises it while it loads."""
     training = bn.training or bn.running_mean is None
     # batch sums left by the producer of x (`afd_conv3x3_forward_stats`, asked for through "want_stats")
     pre = None
@@ -1041,7 +1136,8 @@ def batch_norm(x, bn: torch.nn.Module, slope: Optional[torch.Tensor] = None, syn
     if not training:
         sum_link = pre = None
     return _BatchNorm.apply(x, slope, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link, sum_link, pre)
+                            bn.num_batches_tracked, training, bn.momentum, bn.eps, sync, link, prod_link, sum_link, pre,
+                            bool(defer))
 
 
 # --------------------------------------------------------------------------------------

@@ -103,7 +103,8 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
                const float* bn_in = nullptr, float* stat_part = nullptr, const float* slope = nullptr,
                float* u = nullptr, unsigned char* idx = nullptr, int fwd_stats = 0,
-               const unsigned char* pooled_codes = nullptr);  // backward-data from the pooled gradient: see G4::pidx
+               const unsigned char* pooled_codes = nullptr,  // backward-data from the pooled gradient: see G4::pidx
+               const float* in_aff = nullptr, const float* in_slope = nullptr);  // input fold: see G4::in_aff
 long wino44_stat_rows(int N, int H, int W);
 bool wino44_pool_applicable(int Cin, int H, int W, int Cout);
 // wino44_wgrad.hip: 3x3 / pad 1 backward-weight in the Winograd F(4x4, 3x3) domain
@@ -114,7 +115,8 @@ size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int
 // convolution (afd_prelu_pool_backward_compact) and pooled_codes the pool's argmax codes; the crop is 2 (H/2) x 2 (W/2)
 int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
                      int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s,
-                     const unsigned char* pooled_codes = nullptr);
+                     const unsigned char* pooled_codes = nullptr, const float* in_aff = nullptr,
+                     const float* in_slope = nullptr);  // input fold: x is the input of the BatchNorm in front (GW::in_aff)
 
 bool wgrad3x3_applicable(int Cin, int H, int W, int Cout, int K, int pad, int dil);
 void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int dz_cols, int* S,

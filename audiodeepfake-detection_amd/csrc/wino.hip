@@ -714,10 +714,10 @@ extern "C" size_t afd_conv3x3_forward_stats_workspace_bytes(int N, int H, int W,
     return (size_t)fwd_stat_rows(N, H, W) * slots * sizeof(float) + (size_t)kStatBlocks * slots * sizeof(double) + 64;
 }
 
-extern "C" int afd_conv3x3_forward_stats(const float* x, const float* w, const float* bias, const float* slope,
-                                         float* y, float* u, uint8_t* idx, double* sums, int N, int Cin, int H,
-                                         int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
-                                         size_t stat_ws_bytes, afd_stream_t stream) {
+static int forward_stats_impl(const float* x, const float* w, const float* bias, const float* slope,
+                              float* y, float* u, uint8_t* idx, double* sums, int N, int Cin, int H,
+                              int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
+                              size_t stat_ws_bytes, afd_stream_t stream, const float* in_aff, const float* in_slope) {
     if (!x || !w || !sums || !ws || !stat_ws || (!y && !u) || (u && (!idx || !slope)))
         return afd::fail(AFD_ERR_ARG, "conv3x3 + bn sums: null pointer");
     const int pooled = u != nullptr;
@@ -733,11 +733,91 @@ extern "C" int afd_conv3x3_forward_stats(const float* x, const float* w, const f
     float* part = static_cast<float*>(stat_ws);
     double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
     int rc = afd::wino44_run(x, w, bias, y, N, Cin, H, W, Cout, 0, rows_out, cols_out, ws, ws_bytes, s, nullptr, part, slope,
-                             u, idx, 1);
+                             u, idx, 1, nullptr, in_aff, in_slope);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
     hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cout,
                        sums);
     return afd::check_launch("conv3x3 forward statistics reduce kernels");
+}
+
+extern "C" int afd_conv3x3_forward_stats(const float* x, const float* w, const float* bias, const float* slope,
+                                         float* y, float* u, uint8_t* idx, double* sums, int N, int Cin, int H,
+                                         int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
+                                         size_t stat_ws_bytes, afd_stream_t stream) {
+    return forward_stats_impl(x, w, bias, slope, y, u, idx, sums, N, Cin, H, W, Cout, ws, ws_bytes, stat_ws, stat_ws_bytes,
+                              stream, nullptr, nullptr);
+}
+
+// ---- the BatchNorm in FRONT of a 3x3 convolution applied while the convolution loads (round 4) ----
+// A training-mode BatchNorm(affine=False) whose only consumer is a 3x3 / pad 1 convolution on the F(4x4) kernels need
+// not write its result: the convolution's forward and backward-weight launches take the BatchNorm's INPUT (z and the
+// PReLU slope between them, or the tensor itself) and (mean, invstd) per channel and build (PReLU(z) - mean) * invstd
+// in registers, with the arithmetic of afd_bn_apply_forward (bit-identical values): one read and one write of the
+// activation tensor less per BatchNorm and step (7 GB for DCNN block 2 -> 3 at level 14), and the tensor is never
+// stored.  The backward-data launch does not read the convolution's input (afd_conv_weight_dot supplies the BatchNorm's
+// second backward sum), so it is the launch of the unfolded layer.
+//   pooled = the convolution is followed by PReLU + MaxPool2d(2, 2) in the same launch; want_stats = the launch also
+//   sums its result for the BatchNorm behind it (afd_conv3x3_forward_stats)
+extern "C" int afd_conv3x3_input_fold_applicable(int Cin, int H, int W, int Cout, int pooled, int want_stats) {
+    if (getenv("AFD_NO_INPUT_FOLD")) return 0;
+    if (H < 2 || W < 2) return 0;
+    if (want_stats ? !afd_conv3x3_forward_stats_applicable(Cin, H, W, Cout, pooled)
+                   : !(pooled && afd::wino44_pool_applicable(Cin, H, W, Cout)))
+        return 0;
+    if (!afd_conv3x3_backward_data_bnstats_applicable(Cin, H, W, Cout) ||
+        afd_conv3x3_backward_data_bnstats_needs_input(Cin, H, W, Cout))
+        return 0;
+    if (!afd::wino44_wgrad_applicable(Cin, H, W, Cout, 3, 1, 1)) return 0;
+    return afd::wino44_wgrad_crop_ok(H, W, pooled ? 2 * (H / 2) : H, pooled ? 2 * (W / 2) : W) ? 1 : 0;
+}
+
+// forward: afd_conv3x3_forward_stats (sums != null) or afd_conv3x3_prelu_pool_forward (sums == null, u != null) with x
+// the BatchNorm's input; in_aff [Cin][2] = (mean, invstd), in_slope the PReLU slope in front of the BatchNorm or null
+extern "C" int afd_conv3x3_forward_fold(const float* x, const float* in_aff, const float* in_slope, const float* w,
+                                        const float* bias, const float* slope, float* y, float* u, uint8_t* idx,
+                                        double* sums, int N, int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes,
+                                        void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream) {
+    if (!in_aff) return afd::fail(AFD_ERR_ARG, "conv3x3 with input fold: null pointer");
+    const int pooled = u != nullptr;
+    if (N < 1 || !afd_conv3x3_input_fold_applicable(Cin, H, W, Cout, pooled, sums != nullptr))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 with input fold: layer not on the F(4x4) Winograd kernels");
+    if (sums)
+        return forward_stats_impl(x, w, bias, slope, y, u, idx, sums, N, Cin, H, W, Cout, ws, ws_bytes, stat_ws,
+                                  stat_ws_bytes, stream, in_aff, in_slope);
+    if (!x || !w || !ws || !idx || !slope) return afd::fail(AFD_ERR_ARG, "conv3x3 with input fold: null pointer");
+    return afd::wino44_run(x, w, bias, nullptr, N, Cin, H, W, Cout, 0, 2 * (H / 2), 2 * (W / 2), ws, ws_bytes,
+                           static_cast<hipStream_t>(stream), nullptr, nullptr, slope, u, idx, 0, nullptr, in_aff, in_slope);
+}
+
+// backward-weight: dy the dense gradient (codes == null; rows / columns past dy_rows x dy_cols are not read) or the
+// pooled gradient with the pool's codes; dbias as afd_conv2d_backward_weight_sums (dy_sums: the per-channel sums of dy
+// when its producer has them)
+__global__ void fold_bias_from_sums_kernel(const double* __restrict__ sums, float* __restrict__ db, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) db[c] = (float)sums[c];
+}
+
+extern "C" int afd_conv3x3_backward_weight_fold(const float* x, const float* in_aff, const float* in_slope,
+                                                const float* dy, const uint8_t* codes, float* dw, float* dbias,
+                                                const double* dy_sums, int N, int Cin, int H, int W, int Cout,
+                                                int dy_rows, int dy_cols, void* ws, size_t ws_bytes,
+                                                afd_stream_t stream) {
+    if (!x || !in_aff || !dy || !dw || !ws) return afd::fail(AFD_ERR_ARG, "conv3x3 wgrad with input fold: null pointer");
+    if (codes) {
+        dy_rows = 2 * (H / 2);
+        dy_cols = 2 * (W / 2);
+    }
+    if (N < 1 || !afd::wino44_wgrad_applicable(Cin, H, W, Cout, 3, 1, 1) || !afd::wino44_wgrad_crop_ok(H, W, dy_rows, dy_cols))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 wgrad with input fold: shape not on the Winograd-domain kernel");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = afd::wino44_wgrad_run(x, dy, dw, (dbias && !dy_sums) ? dbias : nullptr, N, Cin, H, W, Cout, dy_rows, dy_cols, ws,
+                                   ws_bytes, s, codes, in_aff, in_slope);
+    if (rc) return rc;
+    if (dbias && dy_sums) {
+        hipLaunchKernelGGL(fold_bias_from_sums_kernel, dim3((Cout + 63) / 64), dim3(64), 0, s, dy_sums, dbias, Cout);
+        return afd::check_launch("fold_bias_from_sums_kernel");
+    }
+    return AFD_OK;
 }

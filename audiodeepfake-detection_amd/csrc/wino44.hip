@@ -51,6 +51,12 @@ struct G4 {
     // position of each window, zero elsewhere -- is built in registers when a patch is consumed
     const unsigned char* pidx;
     int Hp, Wp;
+    // input fold (forward launches; round 4): x is the INPUT of a training-mode BatchNorm(affine=False) in front of the
+    // convolution -- z with the PReLU slope in_slope between them, or the tensor itself (in_slope null) -- and
+    // in_aff [Cin][2] = (mean, invstd): a patch becomes (PReLU(z) - mean) * invstd while it is consumed, with
+    // bn_apply_fwd_kernel's arithmetic (bit-identical values), so the normalised tensor is never written or read
+    const float* in_aff;
+    const float* in_slope;
 };
 
 // slot j' of a transform row holds position kSlotPos[j'] (see bt6h)
@@ -195,6 +201,11 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const float* xn = x + (size_t)n * g.Cin * plane;
     const bool rows_in = iy0 >= 0 && iy0 + 5 < g.H;  // uniform
     float d[6][6];
+    const bool fold = !PIN && !BST && g.in_aff != nullptr;      // uniform (forward launches only)
+    const bool in_act = fold && g.in_slope != nullptr;
+    const float in_a = in_act ? g.in_slope[0] : 1.f;
+    const bool in_fast = in_a >= 0.f && in_a <= 1.f;
+    f32x2 aff = {0.f, 1.f};  // (mean, invstd) of the channel whose patch is in d
     // PIN: the patch's rows 4 ty - 1 .. + 4 lie in the pooled rows 2 ty - 1 .. + 2, its columns in the pooled columns
     // 2 tx - 1 .. + 2: 4 x 4 pooled values and codes travel (20 registers across the matrix loop instead of 36)
     float pq[PIN ? 4 : 1][4];
@@ -228,6 +239,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             return;
         }
         const float* xc = xn + (size_t)(c * CHK + ch) * plane;
+        if (fold) aff = *reinterpret_cast<const f32x2*>(g.in_aff + 2 * (c * CHK + ch));
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int iy = iy0 + r;
@@ -280,7 +292,24 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                     const unsigned pos = (pcd[pr] >> (8 * pc)) & 3u;
                     d[r][j] = pos == want ? pq[pr][pc] : 0.f;
                 }
-        } else
+        } else {
+        if (fold) {  // uniform
+            auto norm = [&](auto&& act) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        f32x2 v = act(f32x2{d[r][2 * c], d[r][2 * c + 1]});
+                        v = (v - aff.x) * aff.y;
+                        d[r][2 * c] = v.x;
+                        d[r][2 * c + 1] = v.y;
+                    }
+            };
+            // PReLU as nn.hip computes it (z > 0 ? z : a z); with 0 <= a <= 1 that is max(z, a z), bit for bit
+            if (!in_act) norm([](f32x2 v) { return v; });
+            else if (in_fast) norm([&](f32x2 v) { return __builtin_elementwise_max(v, v * in_a); });
+            else norm([&](f32x2 v) { return f32x2{v.x > 0.f ? v.x : in_a * v.x, v.y > 0.f ? v.y : in_a * v.y}; });
+        }
         if (!rows_in || BORDER) {
 #pragma unroll
             for (int r = 0; r < 6; ++r)
@@ -290,6 +319,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                     const bool ok = iy >= 0 && iy < g.H && (!BORDER || (txp < g.tilesX && ix >= 0 && ix < g.W));
                     d[r][j] = ok ? d[r][j] : 0.f;
                 }
+        }
         }
         f32x2 t[6][3];  // t = B^T d, column pairs
 #pragma unroll
@@ -659,7 +689,7 @@ long wino44_stat_rows(int N, int H, int W) {
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
                const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx, int fwd_stats,
-               const unsigned char* pooled_codes) {
+               const unsigned char* pooled_codes, const float* in_aff, const float* in_slope) {
     if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
     G4 g{};
@@ -674,6 +704,9 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.x_end = x + (size_t)N * Cin * H * W;
     g.slope = slope; g.u = u; g.idx = idx;
     g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
+    g.in_aff = in_aff; g.in_slope = in_slope;
+    if (in_aff && (dgrad || pooled_codes))
+        return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the input fold is built for forward launches");
     if (pooled_codes && (!dgrad || !stat_part || fwd_stats || u || g.rows != H || g.cols != W || (Cout != 64 && Cout != 32)))
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: pooled input is built for the backward-data launches with "
                                               "BatchNorm sums of 64 / 32 result channels");

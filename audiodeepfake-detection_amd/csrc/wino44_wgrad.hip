@@ -72,6 +72,11 @@ struct GW {
     // pooled values while it loads (rows = 2 Hp, cols = 2 Wp)
     const unsigned char* didx;
     int Hp, Wp;
+    // input fold (round 4, as wino44.hip's G4::in_aff): x is the INPUT of the training-mode BatchNorm(affine=False) in
+    // front of the convolution (z with the PReLU slope in_slope between them, or the tensor itself), in_aff [Cin][2] =
+    // (mean, invstd): the patch becomes (PReLU(z) - mean) * invstd before it is transformed
+    const float* in_aff;
+    const float* in_slope;
 };
 
 // The transforms run on packed FMAs (v_pk_fma_f32: two floats per lane and instruction).  A 6 x 6 patch is held as
@@ -195,6 +200,12 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     unsigned pcd[2];
     int pleft = 2;       // PDY: valid pooled columns of the tile (edge groups)
 
+    const bool fold = g.in_aff != nullptr;  // uniform
+    const bool in_act = fold && g.in_slope != nullptr;
+    const float in_a = in_act ? g.in_slope[0] : 1.f;
+    const bool in_fast = in_a >= 0.f && in_a <= 1.f;
+    // (mean, invstd) of this lane's x channel: loop-invariant
+    const f32x2 aff = fold ? *reinterpret_cast<const f32x2*>(g.in_aff + 2 * (ci0 + 16 * xb + lc)) : f32x2{0.f, 1.f};
     float d[6][6];   // x patch of the coming round
     float e[4][4];   // dy tile of the coming round
     bool x_edge = false, d_edge = false;
@@ -298,6 +309,36 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     float bsum = 0.f;  // bias partial of this lane's channel (dy lanes)
     auto transform_x = [&]() {
         const int iy0 = 4 * ux.ty - 1;
+        if (fold) {  // uniform
+            auto norm = [&](auto&& act) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        f32x2 v = act(f32x2{d[r][2 * c], d[r][2 * c + 1]});
+                        v = (v - aff.x) * aff.y;
+                        d[r][2 * c] = v.x;
+                        d[r][2 * c + 1] = v.y;
+                    }
+            };
+            // PReLU as nn.hip computes it (z > 0 ? z : a z); with 0 <= a <= 1 that is max(z, a z), bit for bit
+            if (!in_act) norm([](f32x2 v) { return v; });
+            else if (in_fast) norm([&](f32x2 v) { return __builtin_elementwise_max(v, v * in_a); });
+            else norm([&](f32x2 v) { return f32x2{v.x > 0.f ? v.x : in_a * v.x, v.y > 0.f ? v.y : in_a * v.y}; });
+            if (x_edge) {  // the zeros load_x put at the image's left / right border and in tiles past tilesX
+                const int tx = 4 * ux.xg + lt;
+                const bool tile_ok = tx < g.tilesX;
+                const int ix0 = tile_ok ? 4 * tx - 1 : 16 * ux.xg - 1;
+                const bool L = ix0 < 0, R = ix0 + 5 >= g.W;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    d[r][0] = (L || !tile_ok) ? 0.f : d[r][0];
+                    d[r][5] = (R || !tile_ok) ? 0.f : d[r][5];
+#pragma unroll
+                    for (int j = 1; j < 5; ++j) d[r][j] = tile_ok ? d[r][j] : 0.f;
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int iy = iy0 + r;
@@ -581,7 +622,8 @@ size_t wino44_wgrad_workspace_floats(int N, int Cin, int H, int W, int Cout, int
 }
 
 int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, int N, int Cin, int H, int W, int Cout,
-                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s, const unsigned char* pooled_codes) {
+                     int dy_rows, int dy_cols, void* ws, size_t ws_bytes, hipStream_t s, const unsigned char* pooled_codes,
+                     const float* in_aff, const float* in_slope) {
     GW g{};
     if (pooled_codes) {  // dy is the pooled gradient [N][Cout][H / 2][W / 2]: the crop is the pooled region
         dy_rows = 2 * (H / 2);
@@ -589,6 +631,8 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     }
     plan(g, N, Cin, H, W, Cout, dy_rows, dy_cols);
     g.didx = pooled_codes;
+    g.in_aff = in_aff;
+    g.in_slope = in_slope;
     g.Hp = H / 2;
     g.Wp = W / 2;
     if (!wino44_wgrad_crop_ok(H, W, dy_rows, dy_cols) || g.units >= 0x7fffffffL)

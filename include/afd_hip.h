@@ -226,6 +226,28 @@ size_t afd_conv3x3_forward_stats_workspace_bytes(int N, int H, int W, int Cout);
 int afd_conv3x3_forward_stats(const float* x, const float* w, const float* bias, const float* slope, float* y,
                               float* u, uint8_t* idx, double* sums, int N, int Cin, int H, int W, int Cout,
                               void* ws, size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
+
+/* The training-mode BatchNorm(affine=False) in FRONT of a 3x3 / pad 1 convolution applied while the convolution loads
+ * (nn.[PReLU ->] nn.SyncBatchNorm(affine=False) -> nn.Conv2d(k=3, padding=1) of DCNN blocks 2->3, 3->4, 4->5, 5->6,
+ * src/audiofakedetect/models.py:261-276): x is the BatchNorm's INPUT, in_aff [Cin][2] = (mean, invstd) of the batch,
+ * in_slope the PReLU slope in front of the BatchNorm or NULL; a patch becomes (PReLU(x) - mean) * invstd in registers,
+ * with afd_bn_apply_forward's arithmetic, so the normalised tensor is never written.
+ *   afd_conv3x3_forward_fold: afd_conv3x3_forward_stats (sums != NULL) or afd_conv3x3_prelu_pool_forward (sums == NULL,
+ *     u / idx given) on that input;
+ *   afd_conv3x3_backward_weight_fold: afd_conv2d_backward_weight_sums (codes == NULL: dy dense, read up to
+ *     dy_rows x dy_cols) or afd_conv3x3_backward_weight_pooled (codes != NULL: dy the pooled gradient);
+ *   the backward-data launch of the layer does not read its input and is unchanged.
+ * Only for layers on the F(4x4) Winograd kernels (afd_conv3x3_input_fold_applicable); AFD_ERR_UNSUPPORTED otherwise. */
+int afd_conv3x3_input_fold_applicable(int Cin, int H, int W, int Cout, int pooled, int want_stats);
+int afd_conv3x3_forward_fold(const float* x, const float* in_aff, const float* in_slope /* may be NULL */,
+                             const float* w, const float* bias, const float* slope, float* y, float* u, uint8_t* idx,
+                             double* sums /* may be NULL */, int N, int Cin, int H, int W, int Cout, void* ws,
+                             size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
+int afd_conv3x3_backward_weight_fold(const float* x, const float* in_aff, const float* in_slope /* may be NULL */,
+                                     const float* dy, const uint8_t* codes /* may be NULL */, float* dw,
+                                     float* dbias /* may be NULL */, const double* dy_sums /* may be NULL */, int N,
+                                     int Cin, int H, int W, int Cout, int dy_rows, int dy_cols, void* ws,
+                                     size_t ws_bytes, afd_stream_t stream);
 int afd_conv2d_backward_weight(const float* x, const float* dy, float* dw,
                                float* dbias /* may be NULL */, int N, int Cin, int H, int W,
                                int Cout, int K, int pad, int dil, void* ws, size_t ws_bytes,

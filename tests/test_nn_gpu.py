@@ -1091,3 +1091,78 @@ def test_batchnorm_backward_sums_from_the_weight_gradient_at_full_width(monkeypa
         grads.append((z.grad.clone(), conv.weight.grad.clone()))
     _close(grads[1][0], grads[0][0].cpu(), 5e-6, "BatchNorm input gradient: w . dw sums vs activation sums")
     _close(grads[1][1], grads[0][1].cpu(), 1e-6, "weight gradient on both paths")
+
+
+FOLD_CASES = [
+    # shape of the BatchNorm's input, slope in front of it (None: no PReLU), cout, pooled, statistics behind the conv
+    ((2, 64, 13, 1029), 0.25, 96, True, True),     # block 2 -> 3 (z2, PReLU, pooled convolution + sums)
+    ((2, 96, 6, 1100), None, 128, False, True),    # block 3 -> 4 (pooled tensor, no PReLU)
+    ((2, 128, 6, 1028), 1.7, 32, False, True),     # block 4 -> 5, slope above 1 (the general PReLU form)
+    ((2, 32, 6, 1029), -0.2, 64, True, False),     # block 5 -> 6, negative slope
+    ((1, 64, 13, 261), 0.0, 96, True, True),       # ragged last workgroup column, slope 0
+    ((3, 64, 51, 129), 0.25, 96, True, True),      # level-8 / STFT geometry: every workgroup a border workgroup
+    ((3, 96, 25, 64), None, 128, False, True),
+    ((2, 128, 25, 64), 0.6, 32, False, True),
+]
+
+
+@pytest.mark.parametrize("shape,slope_in,cout,pooled,stats", FOLD_CASES)
+def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, pooled, stats):
+    """`batch_norm(defer=True)` -> 3x3 convolution (`afd_conv3x3_forward_fold` / `afd_conv3x3_backward_weight_fold`):
+    the BatchNorm's result is never stored, the convolution's forward and backward-weight launches build
+    (PReLU(z) - mean) * invstd from z while they load -- with afd_bn_apply_forward's arithmetic, so outputs and
+    gradients equal the two-pass chain bit for bit (the PReLU slope's gradient ends in float atomics: tolerance)."""
+    torch.manual_seed(41)
+    n, cin, h, w = shape
+    x = torch.randn(shape, device="cuda") * 1.5 + 0.3
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).cuda()
+    bn_in = torch.nn.BatchNorm2d(cin, affine=False).cuda().train()
+    bn_out = torch.nn.BatchNorm2d(cout, affine=False).cuda().train()
+    a_in = None if slope_in is None else torch.full((1,), float(slope_in), device="cuda", requires_grad=True)
+    a_out = torch.full((1,), 0.25, device="cuda")
+    assert ops.conv3x3_input_fold_applicable(bn_in, conv, shape, pooled, stats)
+    res = []
+    for defer in (False, True):
+        bn_in.reset_running_stats()
+        bn_out.reset_running_stats()
+        conv.zero_grad()
+        if a_in is not None:
+            a_in.grad = None
+        xg = x.clone().requires_grad_(True)
+        link = {}
+        hh = ops.batch_norm(xg, bn_in, a_in, False, link, defer=defer)
+        assert ("fold" in link) == defer
+        if defer:
+            assert hh.data_ptr() == xg.data_ptr()  # nothing was written
+        if pooled:
+            out_link = {"want_stats": True} if stats else None
+            u = ops.conv3x3_prelu_maxpool(hh, conv.weight, conv.bias, a_out, link, out_link)
+            y = ops.batch_norm(u, bn_out, None, False, None, out_link) if stats else u
+            mid = u
+        else:
+            out_link = {"want_stats": True, "stats_slope": a_out}
+            z = ops.conv2d(hh, conv.weight, conv.bias, 1, 1, bn_link=link, out_link=out_link)
+            y = ops.batch_norm(z, bn_out, a_out, False, None, sum_link=out_link)
+            mid = z
+        assert "fold" not in link  # taken by the convolution
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        y.backward(torch.randn(y.shape, device="cuda", generator=gen))
+        res.append((mid.detach().clone(), y.detach().clone(), xg.grad.clone(), conv.weight.grad.clone(),
+                    conv.bias.grad.clone(), None if a_in is None else a_in.grad.clone(), bn_in.running_var.clone()))
+    names = ("convolution output", "output", "input gradient", "weight gradient", "bias gradient", "slope gradient",
+             "running variance")
+    for got, want, what in zip(res[1], res[0], names):
+        if want is None:
+            continue
+        if what == "slope gradient":
+            _close(got, want.cpu(), 3e-4, what)
+        else:
+            assert torch.equal(got, want), f"{what}: {(got - want).abs().max().item():.3e}"
+    # and the chain against float64
+    xd = x.double().cpu()
+    v = xd if slope_in is None else torch.where(xd > 0, xd, float(slope_in) * xd)
+    xh = (v - v.mean((0, 2, 3), keepdim=True)) / torch.sqrt(v.var((0, 2, 3), unbiased=False, keepdim=True) + bn_in.eps)
+    zr = F.conv2d(xh, conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), padding=1)
+    if pooled:
+        zr = F.max_pool2d(torch.where(zr > 0, zr, 0.25 * zr), 2, 2)
+    _close(res[1][0], zr, 2e-5, "folded convolution against float64")
