@@ -36,6 +36,7 @@ using namespace afd::wptc;
 
 namespace {
 
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 struct D4Params {
     const float* ws;  // level-8 hand-off [B][n8][256]
@@ -80,8 +81,7 @@ template <int L, int GRP> struct Plan4 {
 // Positions in front of a stage's valid range and behind the node's last output carry garbage that never reaches
 // a valid position (a position only reads positions below it, and those are valid whenever it is).
 template <int L, int NIN, int G, int PIN, int POUT, bool PADDED>
-__device__ __forceinline__ void lattice_level(const float* __restrict__ src, float* __restrict__ dst, const Lat4& c,
-                                              int tid) {
+__device__ __forceinline__ void lattice_level(float* lds0, const float* src, float* dst, const Lat4& c, int tid) {
     constexpr int K = L / 2, PAD = L - 2;
     constexpr int NOUT = (NIN + L - 2 + (NIN & 1)) / 2;
     constexpr int J = NOUT + K - 1, R = (J + G - 1) / G;
@@ -107,20 +107,35 @@ __device__ __forceinline__ void lattice_level(const float* __restrict__ src, flo
         P[0] = __builtin_elementwise_fma(ab, f2{pb, pb}, f2{P[0].x, P[0].x});
     }
     const int par = q & 1;  // odd-frequency parents list their children (d, a)
-    float* na = dst + (PADDED ? PAD : 0) + (2 * q + par) * POUT;
-    float* nd = dst + (PADDED ? PAD : 0) + (2 * q + 1 - par) * POUT;
     const int i0 = seg * R - (K - 1);
+    // Store addresses: every slot is (a base that holds all lane-dependent terms) + (a compile-time offset in the
+    // instruction).  Coefficient i = i0 + r of a child goes to node[i], its left mirror to node[-i] and its right mirror
+    // to node[2 (NOUT - 1) - i]: bases node + i0 (offset r) and node - i0 - (R - 1), node + 2 (NOUT - 1) - i0 - (R - 1)
+    // (offset R - 1 - r).  The bases are made opaque: left to itself the compiler rebuilt each address from i with a
+    // shift and a subtraction per store (the kernel is bound by its vector instruction count).
+    const int ca = (int)(dst - lds0) + (PADDED ? PAD : 0) + (2 * q + par) * POUT;
+    const int cd = (int)(dst - lds0) + (PADDED ? PAD : 0) + (2 * q + 1 - par) * POUT;
+    int ma = ca + i0, md = cd + i0;
+    int la = ca - i0 - (R - 1), ld = cd - i0 - (R - 1);
+    int ra = la + 2 * (NOUT - 1), rd = ld + 2 * (NOUT - 1);
+    asm volatile("" : "+v"(ma), "+v"(md));
+    if (PADDED) asm volatile("" : "+v"(la), "+v"(ld), "+v"(ra), "+v"(rd));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const int i = i0 + r;
         if ((unsigned)i < (unsigned)NOUT) {
             const f2 v = P[r] * c.sc;
+            lds0[ma + r] = v.x;
+            lds0[md + r] = v.y;
             if (PADDED) {
-                put<L>(na, i, NOUT, v.x);
-                put<L>(nd, i, NOUT, v.y);
-            } else {
-                na[i] = v.x;
-                nd[i] = v.y;
+                if ((unsigned)(i - 1) < (unsigned)PAD) {
+                    lds0[la + (R - 1 - r)] = v.x;
+                    lds0[ld + (R - 1 - r)] = v.y;
+                }
+                if ((unsigned)(NOUT - 2 - i) < (unsigned)(PAD + (NOUT & 1))) {
+                    lds0[ra + (R - 1 - r)] = v.x;
+                    lds0[rd + (R - 1 - r)] = v.y;
+                }
             }
         }
     }
@@ -191,13 +206,13 @@ __global__ void __launch_bounds__(32 * GRP) wpt4_deep_kernel(const D4Params p) {
     __syncthreads();
     // ---- S1 .. S4: 8 -> 9 -> 10 -> 11 -> 12, lattice with 32 / 16 / 8 / 4 lanes per node ----
     {
-        lattice_level<L, SH::n[0], 32, PL::p8, PL::p9, true>(R0, R1, p.lat, tid);
+        lattice_level<L, SH::n[0], 32, PL::p8, PL::p9, true>(lds, R0, R1, p.lat, tid);
         __syncthreads();
-        lattice_level<L, SH::n[1], 16, PL::p9, PL::p10, true>(R1, R0, p.lat, tid);
+        lattice_level<L, SH::n[1], 16, PL::p9, PL::p10, true>(lds, R1, R0, p.lat, tid);
         __syncthreads();
-        lattice_level<L, SH::n[2], 8, PL::p10, PL::p11, true>(R0, R1, p.lat, tid);
+        lattice_level<L, SH::n[2], 8, PL::p10, PL::p11, true>(lds, R0, R1, p.lat, tid);
         __syncthreads();
-        lattice_level<L, SH::n[3], 4, PL::p11, PL::p12, false>(R1, R0, p.lat, tid);
+        lattice_level<L, SH::n[3], 4, PL::p11, PL::p12, false>(lds, R1, R0, p.lat, tid);
         __syncthreads();
     }
     // ---- S5: 12 -> 13, thread = level-12 node ----
@@ -209,8 +224,13 @@ __global__ void __launch_bounds__(32 * GRP) wpt4_deep_kernel(const D4Params p) {
         LatticeNode<L, n12> lt;
         lt.run(x, p.lat, p.lat.ab[L / 2 - 1]);
         const int par = tid & 1;
-        float* na = R1 + (2 * tid + par) * PL::p13;
-        float* ndd = R1 + (2 * tid + 1 - par) * PL::p13;
+        // (float offsets from the start of LDS, opaque to the compiler: the region offset then sits in the base register
+        // and the element index in the instruction's 8-bit offset field -- given the constant, it re-adds region + element
+        // in a vector instruction per ds_write2)
+        int oa = PL::r0 + (2 * tid + par) * PL::p13, od = PL::r0 + (2 * tid + 1 - par) * PL::p13;
+        asm volatile("" : "+v"(oa), "+v"(od));
+        float* na = lds + oa;
+        float* ndd = lds + od;
         const f2 sc = p.lat.sc;
 #pragma unroll
         for (int i = 0; i < n13; ++i) {
@@ -223,7 +243,9 @@ __global__ void __launch_bounds__(32 * GRP) wpt4_deep_kernel(const D4Params p) {
     // ---- S6: 13 -> 14, thread = level-13 node; children = packets 2 q13, 2 q13 + 1 ----
     {
         float x[n13];
-        const float* nd = R1 + tid * PL::p13;
+        int on = PL::r0 + tid * PL::p13;
+        asm volatile("" : "+v"(on));
+        const float* nd = lds + on;
 #pragma unroll
         for (int i = 0; i < n13; ++i) x[i] = nd[i];
         LatticeNode<L, n13> lt;
@@ -232,14 +254,11 @@ __global__ void __launch_bounds__(32 * GRP) wpt4_deep_kernel(const D4Params p) {
         const bool par = tid & 1;
         const f2 abl = p.lat.ab[L / 2 - 1];
         lt.run(x, p.lat, par ? f2{abl.y, abl.x} : abl);
-        const size_t P = 16384;
-        const size_t chan = (size_t)n14 * P;
-        float* o = p.out + (size_t)b * (SIGN ? 2 : 1) * chan + 2 * ((size_t)g * 32 * kD4Group + tid);
+        constexpr unsigned P = 16384;
+        constexpr unsigned chan = (unsigned)n14 * P;
         const f2 fk1 = par ? f2{p.fk1.y, p.fk1.x} : p.fk1, fk0 = par ? f2{p.fk0.y, p.fk0.x} : p.fk0;
         const f2 feps = par ? f2{p.feps.y, p.feps.x} : p.feps, sc = par ? f2{p.lat.sc.y, p.lat.sc.x} : p.lat.sc;
-#pragma unroll
-        for (int i = 0; i < n14; ++i) {
-            const f2 ab = lt.P[lt.K - 1 + i];
+        auto value = [&](const f2 ab) {
             f2 r;
             if (MODE == EPI_RAW) {
                 r = __builtin_elementwise_fma(ab, fk1, fk0);
@@ -252,12 +271,27 @@ __global__ void __launch_bounds__(32 * GRP) wpt4_deep_kernel(const D4Params p) {
                 r.x = epi_value<EPI_SLOW>(v.x, p.e);
                 r.y = epi_value<EPI_SLOW>(v.y, p.e);
             }
-            __builtin_nontemporal_store(r, reinterpret_cast<f2*>(o + (size_t)i * P));
-            if (SIGN) {
-                const f2 v = ab * sc;
-                const f2 sg = {v.x < 0.f ? p.e.sgn_neg : p.e.sgn_pos, v.y < 0.f ? p.e.sgn_neg : p.e.sgn_pos};
-                __builtin_nontemporal_store(sg, reinterpret_cast<f2*>(o + chan + (size_t)i * P));
-            }
+            return r;
+        };
+        auto sign = [&](const f2 ab) {
+            const f2 v = ab * sc;
+            return f2{v.x < 0.f ? p.e.sgn_neg : p.e.sgn_pos, v.y < 0.f ? p.e.sgn_neg : p.e.sgn_pos};
+        };
+        // Stores: the frame is the buffer, the lane's two packets the vector offset and the time step the scalar offset
+        // of a buffer store -- no vector address arithmetic (as 64-bit lane addresses every store cost an add /
+        // add-with-carry pair; this kernel is bound by its vector instruction count: measured 1.3 us per instruction
+        // and thread at B = 4096).  Measured and not kept: the lanes of a pair trading halves through DPP selects so
+        // that a lane stores 16 bytes (12 stores instead of 24, +56 vector instructions): 2 493 -> 2 553 us.
+        float* frame = p.out + (size_t)b * (SIGN ? 2 : 1) * chan;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(frame, 0, (int)((SIGN ? 2u : 1u) * chan * 4u), 0x00020000);
+        const unsigned vo = 8u * ((unsigned)g * 32u * kD4Group + (unsigned)tid);  // this node's two packets
+#pragma unroll
+        for (int i = 0; i < n14; ++i) {
+            const f2 ab = lt.P[lt.K - 1 + i];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, value(ab)), rs, vo, (unsigned)i * P * 4u, 2);
+            if (SIGN)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, sign(ab)), rs, vo, (chan + (unsigned)i * P) * 4u, 2);
         }
     }
 }
