@@ -183,6 +183,45 @@ def test_level14_coif4_shape_runs():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+@pytest.mark.parametrize("input_dim,flat,expect", [((3, 1, 16384, 24), 80960, 4), ((3, 1, 256, 101), 384, 4)])
+def test_training_step_without_the_normalised_tensors(input_dim, flat, expect, monkeypatch):
+    """The BatchNorms in front of blocks 3-6 hand their statistics to the next convolution instead of writing their
+    result (ops.batch_norm(defer=True), DCNN._next_normalises): at the level-14 and the level-8 geometry all four do,
+    and loss, logits and every gradient equal the step with AFD_NO_INPUT_FOLD=1 (same arithmetic; the PReLU slopes end
+    in float atomics, the BatchNorm sums in double atomics)."""
+    torch.manual_seed(3)
+    args = _args(input_dim, flattend_size=flat, dropout_cnn=0.0, dropout_lstm=0.0)
+    net = DCNN(args).cuda().train()
+    n, _, p, t = input_dim
+    x = torch.randn(n, 1, t, p, device="cuda").permute(0, 1, 3, 2)
+    labels = torch.tensor([0, 1, 1][:n], device="cuda")
+    taken = []
+    pack = ops._pack_fold
+    monkeypatch.setattr(ops, "_pack_fold", lambda m, i: taken.append(1) or pack(m, i))
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("AFD_NO_INPUT_FOLD", "1")
+        taken.clear()
+        net.zero_grad()
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        out = net(x)
+        loss = ops.CrossEntropyLoss()(out, labels)
+        loss.backward()
+        assert len(taken) == (0 if off else expect)
+        res.append((out.detach().clone(), {k: v.grad.clone() for k, v in net.named_parameters()},
+                    {k: v.clone() for k, v in net.named_buffers() if "running" in k}))
+    assert torch.equal(res[0][0], res[1][0]) or (res[0][0] - res[1][0]).abs().max().item() < 1e-6
+    for k in res[0][1]:
+        a, b = res[0][1][k].double(), res[1][1][k].double()
+        tol = 3e-4 if a.numel() == 1 else 2e-6
+        assert (a - b).abs().max().item() <= tol * (b.abs().max().item() + 1e-30), k
+    for k in res[0][2]:
+        assert torch.allclose(res[0][2][k], res[1][2][k], rtol=1e-6, atol=1e-7), k
+
+
 @pytest.mark.parametrize("wavelet,t_len", [("coif4", 24), ("sym5", 10)])
 def test_full_width_level14_step_matches_cpu_restatement(wavelet, t_len):
     """BASELINE configs[1] / configs[2] geometry at full width (16384 packets x 24 time steps for
