@@ -177,6 +177,12 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const int n = id / g.tilesY;
     const int tx0 = wx * kTiles;
     const bool skip5 = g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
+    // PIN: the dense gradient has 2 Hp live rows; a tile row whose patches start on the last of them (4 ty - 1 =
+    // 2 Hp - 1: the fourth tile row of block 3's 13-row backward-data at level 14, one output row) has a single
+    // non-zero patch row, row 0, and column 0 of B^T is (4, 0, 0, 0, 0, 0): only transform row 0 -- positions 0..5 --
+    // is non-zero.  Those workgroups run 6 of the 36 products per chunk (they ran 30) and fetch only those operands:
+    // block 3's backward-data 5.50 -> 5.23 ms (a shorter transform for them on top measured level, with spills).
+    const bool row0_only = PIN && 4 * ty - 1 == 2 * g.Hp - 1;  // uniform
 
     // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
     // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
@@ -391,13 +397,17 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
             load_b(0, 0);
 #pragma unroll
             for (int grp = 0; grp < 12; ++grp) {
-                if (grp + 2 < 12) load_u(uc, grp + 2, (grp + 2) % 3);
-                else load_u(un, grp + 2 - 12, (grp + 2) % 3);
-                if (grp + 1 < 12) load_b(grp + 1, (grp + 1) & 1);
+                // (row0_only: groups 0 and 1 are all that is multiplied -- the other groups' operands are not fetched)
+                if (grp + 2 < 12) {
+                    if (!row0_only) load_u(uc, grp + 2, (grp + 2) % 3);
+                } else {
+                    load_u(un, grp + 2 - 12, (grp + 2) % 3);
+                }
+                if (grp + 1 < 12 && (grp + 1 < 2 || !row0_only)) load_b(grp + 1, (grp + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // positions 30..35 (transform row 5) only enter output row 3 of the tile (A^T row 3): a tile row with
                 // at most three live output rows -- the last one of the 13- and 6-row level-14 images -- skips them
-                if (grp < 10 || !skip5) {
+                if ((grp < 2 || !row0_only) && (grp < 10 || !skip5)) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
