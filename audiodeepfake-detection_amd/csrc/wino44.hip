@@ -57,7 +57,9 @@ struct G4 {
     // bn_apply_fwd_kernel's arithmetic (bit-identical values), so the normalised tensor is never written or read
     const float* in_aff;
     const float* in_slope;
+    int noflip;  // development switch AFD_WINO44_NO_FLIP: see the kernel's wave roles
 };
+__device__ __forceinline__ bool getenv_noflip(const G4& g) { return g.noflip != 0; }
 
 // slot j' of a transform row holds position kSlotPos[j'] (see bt6h)
 __device__ constexpr int kSlotPos[6] = {0, 5, 1, 3, 2, 4};
@@ -168,7 +170,14 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (HELP == 2 && !getenv_noflip(g)) {
+        // Six matrix waves on four SIMDs (wave w runs on SIMD w & 3): SIMDs 0, 1 carry two of them, SIMDs 2, 3 one and a
+        // helper.  Two workgroups share a CU; if the second one takes its helpers FIRST (physical waves 0, 1 = logical
+        // 6, 7) its matrix waves double up on SIMDs 2, 3 and every SIMD carries three matrix waves instead of four on
+        // two of them.  Workgroups 256 apart are the ones that meet on a CU (8 XCDs x 32 CUs, dispatched in order).
+        if ((blockIdx.x >> 8) & 1) wave = (wave + 6) & 7;
+    }
     int id = blockIdx.x;
     const int wi = id % g.wxCount;
     id /= g.wxCount;
@@ -715,6 +724,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.slope = slope; g.u = u; g.idx = idx;
     g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
     g.in_aff = in_aff; g.in_slope = in_slope;
+    g.noflip = getenv("AFD_WINO44_NO_FLIP") != nullptr;
     if (in_aff && (dgrad || pooled_codes))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the input fold is built for forward launches");
     if (pooled_codes && (!dgrad || !stat_part || fwd_stats || u || g.rows != H || g.cols != W || (Cout != 64 && Cout != 32)))
