@@ -1447,7 +1447,8 @@ extern "C" int afd_conv2d_forward_cropped(const float* x, const float* w, const 
 // pooling window.  Returns AFD_ERR_UNSUPPORTED when the layer is not one the Winograd kernel of
 // wino.hip takes (the caller then runs convolution and pool separately).
 extern "C" int afd_conv3x3_prelu_pool_applicable(int Cin, int H, int W, int Cout) {
-    return afd::wino_applicable(Cin, H, W, Cout) && H >= 2 && W >= 2 ? 1 : 0;
+    // (either Winograd kernel: the F(4x4) form takes images from 48 columns up, the F(2x2) form from 64)
+    return (afd::wino44_pool_applicable(Cin, H, W, Cout) || afd::wino_applicable(Cin, H, W, Cout)) && H >= 2 && W >= 2 ? 1 : 0;
 }
 
 extern "C" int afd_conv3x3_prelu_pool_forward(const float* x, const float* w, const float* bias,
