@@ -14,7 +14,8 @@ from typing import Optional
 import torch
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libafd_hip.so")
+# AFD_LIB: another build of the same library (A/B runs of bench.py, tools/ab_*.py); the in-tree build otherwise
+LIB_PATH = os.environ.get("AFD_LIB") or os.path.join(_PKG, "lib", "libafd_hip.so")
 
 _lib: Optional[ctypes.CDLL] = None
 

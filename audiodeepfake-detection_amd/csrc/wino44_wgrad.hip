@@ -49,6 +49,14 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// v_max_f32 as is: through fmaxf the compiler first canonicalises an operand it cannot prove quiet (a value straight
+// from memory) with a v_max_f32 x, x of its own -- two instructions per element in the input fold's PReLU
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 
 constexpr int kPos = 36;
@@ -323,7 +331,7 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
             };
             // PReLU as nn.hip computes it (z > 0 ? z : a z); with 0 <= a <= 1 that is max(z, a z), bit for bit
             if (!in_act) norm([](f32x2 v) { return v; });
-            else if (in_fast) norm([&](f32x2 v) { return __builtin_elementwise_max(v, v * in_a); });
+            else if (in_fast) norm([&](f32x2 v) { const f32x2 av = v * in_a; return f32x2{vmax(v.x, av.x), vmax(v.y, av.y)}; });
             else norm([&](f32x2 v) { return f32x2{v.x > 0.f ? v.x : in_a * v.x, v.y > 0.f ? v.y : in_a * v.y}; });
             if (x_edge) {  // the zeros load_x put at the image's left / right border and in tiles past tilesX
                 const int tx = 4 * ux.xg + lt;

@@ -55,6 +55,8 @@ def child(lib_path):
         a = torch.full((1,), 0.25, device="cuda")
         res["b3 wgrad pooled fold"] = timeit(lambda: _native.check(lib.afd_conv3x3_backward_weight_fold(
             P(x), P(aff), P(a), P(gg), P(idx), P(dw), P(db), None, n, cin, h, w, cout, h, w, P(ws), ws.numel(), S()), "wf"))
+        res["b3 wgrad pooled fold, no PReLU"] = timeit(lambda: _native.check(lib.afd_conv3x3_backward_weight_fold(
+            P(x), P(aff), None, P(gg), P(idx), P(dw), P(db), None, n, cin, h, w, cout, h, w, P(ws), ws.numel(), S()), "wf"))
         u = torch.empty(n, cout, h // 2, w // 2, device="cuda")
         b = torch.zeros(cout, device="cuda")
         fs = torch.empty(2 * cout + 1, dtype=torch.float64, device="cuda")
@@ -63,6 +65,10 @@ def child(lib_path):
             P(x), P(wt), P(b), P(a), None, P(u), P(idx), P(fs), n, cin, h, w, cout, P(ws), ws.numel(), P(fws), fws.numel(), S()), "f"))
         res["b3 fwd pool stats fold"] = timeit(lambda: _native.check(lib.afd_conv3x3_forward_fold(
             P(x), P(aff), P(a), P(wt), P(b), P(a), None, P(u), P(idx), P(fs), n, cin, h, w, cout, P(ws), ws.numel(), P(fws),
+            fws.numel(), S()), "ff"))
+    if hasattr(lib, "afd_conv3x3_forward_fold"):
+        res["b3 fwd pool stats fold, no PReLU"] = timeit(lambda: _native.check(lib.afd_conv3x3_forward_fold(
+            P(x), P(aff), None, P(wt), P(b), P(a), None, P(u), P(idx), P(fs), n, cin, h, w, cout, P(ws), ws.numel(), P(fws),
             fws.numel(), S()), "ff"))
     print(json.dumps(res))
 
