@@ -288,6 +288,52 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+def _bn_backward_in_dgrad_ok(lib, bn_link, fold, geom, pooled: bool) -> bool:
+    if bn_link is None or fold is None or "bn_ctx" not in bn_link:
+        return False
+    n, cin, h, wd, cout, k, pad, dil = geom
+    return bool(k == 3 and pad == 1 and dil == 1
+                and lib.afd_conv3x3_backward_data_bnapply_applicable(cin, h, wd, cout, int(pooled)))
+
+
+def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, fold, bn_ctx, ws):
+    """Backward-data of a 3x3 convolution whose input was a deferred BatchNorm (`batch_norm(defer=True)`), with that
+    BatchNorm's -- and the PReLU's in front of it -- backward applied in the launch's epilogue
+    (`afd_conv3x3_backward_data_bnapply`): returns (dL/dz, its per-channel sums (double), dslope or None).  The two batch
+    sums the BatchNorm backward needs come from small tensors: sum(g * xhat) = w . dw (so the weight gradient must exist),
+    sum(g) from the weights and the border sums of dy (`afd_conv3x3_input_grad_sums`)."""
+    n, cin, h, wd, cout = geom[:5]
+    aff, slope = fold
+    mean, invstd, count, sync = bn_ctx
+    dev = z.device
+    buf = torch.empty(max(2 * cin, cin + 8 * cout), dtype=torch.float64, device=dev)
+    _native.check(lib.afd_conv3x3_input_grad_sums(
+        _native.ptr(dy), _native.ptr(codes), _native.ptr(w), _native.ptr(dy_sums), None if dy_sums is not None else _native.ptr(db),
+        _native.ptr(buf), n, cin, h, wd, cout, crop[0], crop[1], _native.stream_ptr()), "afd_conv3x3_input_grad_sums")
+    _native.check(lib.afd_conv_weight_dot(_native.ptr(w), _native.ptr(dw), cout, cin, 9, buf.data_ptr() + 8 * cin,
+                                          _native.stream_ptr()), "afd_conv_weight_dot")
+    sums = buf[:2 * cin]
+    if _dist_on(sync):
+        sums = sums.clone()
+        all_reduce_sum(sums)
+    mdy = torch.empty(cin, dtype=torch.float32, device=dev)
+    mdyx = torch.empty(cin, dtype=torch.float32, device=dev)
+    on_dev = torch.is_tensor(count)
+    _native.check(lib.afd_bn_backward_means(
+        _native.ptr(sums), cin, -1.0 if on_dev else float(count), _native.ptr(count) if on_dev else None,
+        _native.ptr(mdy), _native.ptr(mdyx), _native.stream_ptr()), "afd_bn_backward_means")
+    tab = torch.stack((mean, invstd, mdy, mdyx), dim=1).contiguous()
+    dz = torch.empty_like(z)
+    out = torch.empty(2 * cin, dtype=torch.float64, device=dev)
+    sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), dev, "bnstats")
+    _native.check(lib.afd_conv3x3_backward_data_bnapply(
+        _native.ptr(dy), _native.ptr(codes), _native.ptr(w), _native.ptr(z), _native.ptr(tab), _native.ptr(slope),
+        _native.ptr(dz), _native.ptr(out), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(),
+        _native.stream_ptr()), "afd_conv3x3_backward_data_bnapply")
+    dslope = out[cin:].sum().float().reshape(1) if slope is not None else None
+    return dz, out[:cin], dslope
+
+
 def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None, dy_sums=None,
                      fold=None):
     """Backward-data on the current stream; backward-weight on the second stream, added straight into
@@ -302,6 +348,20 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
     dx = dw = db = None
     dot_sums = False
     bn = bn_link.get("bn") if bn_link is not None else None
+    if (need_dx and need_dw and (dy_sums is not None or (has_bias and need_db))
+            and _bn_backward_in_dgrad_ok(lib, bn_link, fold, geom, False)):
+        # backward-weight first: its result gives the BatchNorm's second backward sum, and the backward-data launch then
+        # applies the BatchNorm / PReLU backward to its own result (no pass over the activations for them)
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        _native.check(lib.afd_conv3x3_backward_weight_fold(
+            _native.ptr(x), _native.ptr(fold[0]), _native.ptr(fold[1]), _native.ptr(dy), None, _native.ptr(dw),
+            _native.ptr(db), _native.ptr(dy_sums), n, cin, h, wd, cout, crop[0], crop[1], _native.ptr(ws), ws.numel(),
+            _native.stream_ptr()), "afd_conv3x3_backward_weight_fold")
+        dz, dxs, dslope = _dgrad_with_bn_backward(lib, x, w, dw, dy, None, dy_sums, db, geom, crop, fold,
+                                                  bn_link.pop("bn_ctx"), ws)
+        bn_link["applied"] = (dslope, dxs)
+        return dz, dw, db
     if (need_dx and bn is not None and k == 3 and pad == 1 and dil == 1
             and lib.afd_conv3x3_backward_data_bnstats_applicable(cin, h, wd, cout)):
         dx = torch.empty_like(x)
@@ -528,6 +588,19 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
                 _native.ptr(gg), _native.ptr(dslope), n * cout, h // 2, wd // 2, _native.stream_ptr()),
                 "afd_prelu_pool_backward_compact")
             ws = _ws(lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1), x.device)
+            if ctx.has_bias and _bn_backward_in_dgrad_ok(lib, ctx.bn_link, ctx.fold, ctx.geom, True):
+                # as in `_conv2d_backward`: backward-weight first, then backward-data with the BatchNorm / PReLU
+                # backward of its result in the epilogue
+                dw = torch.empty_like(w)
+                db = torch.empty(cout, dtype=torch.float32, device=x.device)
+                _native.check(lib.afd_conv3x3_backward_weight_fold(
+                    _native.ptr(x), _native.ptr(ctx.fold[0]), _native.ptr(ctx.fold[1]), _native.ptr(gg), _native.ptr(idx),
+                    _native.ptr(dw), _native.ptr(db), None, n, cin, h, wd, cout, h, wd, _native.ptr(ws), ws.numel(),
+                    _native.stream_ptr()), "afd_conv3x3_backward_weight_fold")
+                dz, dxs, dsl_in = _dgrad_with_bn_backward(lib, x, w, dw, gg, idx, None, db, ctx.geom, ctx.crop, ctx.fold,
+                                                         ctx.bn_link.pop("bn_ctx"), ws)
+                ctx.bn_link["applied"] = (dsl_in, dxs)
+                return dz, dw, db, dslope, None, None
             dx = torch.empty_like(x)
             sums = torch.empty(2 * cin, dtype=torch.float64, device=x.device)
             sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), x.device, "bnstats")
@@ -718,6 +791,10 @@ class _BatchNorm(torch.autograd.Function):
             # tensor from that convolution's backward-data launch, and never read the normalised tensor itself.
             link["fold"] = (_pack_fold(mean, invstd), slope)
             link["bn"] = True
+            if prod_link is None:
+                # the consumer's backward-data launch may apply this layer's (and the PReLU's) backward itself
+                # (`_dgrad_with_bn_backward`); a BatchNorm behind a pool hands its backward to the pool instead
+                link["bn_ctx"] = (mean, invstd, ctx.count, sync)
             empty = torch.empty(0)
             if slope is not None:
                 _tap("prelu", x)
@@ -766,6 +843,13 @@ class _BatchNorm(torch.autograd.Function):
                 dslope = (g * x * neg).sum().reshape(1)
                 g = torch.where(neg, g * slope, g)
             return g, dslope, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None, None
+        applied = ctx.link.pop("applied", None) if ctx.link is not None else None
+        if applied is not None:
+            # the consumer's backward-data launch has applied this layer's and the PReLU's backward: dy IS dL/dx
+            dslope, dxs = applied
+            if ctx.sum_link is not None:
+                ctx.sum_link["dy_sums"] = dxs
+            return dy, dslope, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None
         gamma = gamma if has_gamma else None
         n, c = x.shape[0], x.shape[1]
@@ -1208,6 +1292,9 @@ class _LinearMean(torch.autograd.Function):
         x = _f32c(x)
         bsz, td, f = x.shape
         o = w.shape[0]
+        if w.dim() != 2 or w.shape[1] != f or (b is not None and b.numel() != o):
+            # (nn.Linear raises here too: a wrong `flattend_size` must not read past the weight)
+            raise RuntimeError(f"linear_mean: features of width {f} against a weight of shape {tuple(w.shape)}")
         y = torch.empty((bsz, o), dtype=torch.float32, device=x.device)
         _native.check(_lib().afd_linear_mean_forward(_native.ptr(x), _native.ptr(_f32c(w)),
                                                      _native.ptr(b), _native.ptr(y), bsz, td, f, o,

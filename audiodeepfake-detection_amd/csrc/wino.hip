@@ -750,6 +750,182 @@ extern "C" int afd_conv3x3_forward_stats(const float* x, const float* w, const f
                               stream, nullptr, nullptr);
 }
 
+// ---- backward of the BatchNorm in front of a 3x3 convolution inside that convolution's backward-data launch (round 4) ----
+// g = dL/d(xhat) = w^T * dy is the gradient of a training-mode BatchNorm(affine=False) output.  Its backward needs the batch
+// sums of g and of g * xhat BEFORE it can touch an element -- which is why it used to be a pass of its own after the
+// backward-data launch (bn_bwd_apply: read z, read g, write dz).  Both sums can be had without g:
+//   sum_px g[ci] xhat[ci]  = sum_{co,k} w[co][ci][k] dw[co][ci][k]                          (afd_conv_weight_dot)
+//   sum_px g[ci]           = sum_{co,k} w[co][ci][k] R[co][k],  R[co][ky][kx] = sum of dy[co] over the rows / columns tap
+//                            (ky, kx) reaches inside the image: everything, less row 0 for ky = 0, the last row for ky = 2,
+//                            column 0 for kx = 0, the last column for kx = 2, plus the corner counted twice
+// so with the backward-weight launch run FIRST the backward-data epilogue applies the BatchNorm and PReLU backward to its
+// own result and writes dz: one read and one write of the activation tensor less per BatchNorm (4.8 GB behind block 4).
+namespace {
+
+// border sums of dy per channel: out[c][8] = row 0, last row, column 0, last column, and the four corners
+// (0,0), (0,W-1), (H-1,0), (H-1,W-1) of the H x W image; dy is dense [N][C][H][W] with a live region rows x cols, or
+// (codes != null) the pooled gradient [N][C][H/2][W/2] with the pool's codes (dense value at 2 pr + bit 1, 2 pc + bit 0)
+__global__ void __launch_bounds__(256)
+conv_border_sums_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ codes, int C, int H, int W, int rows,
+                        int cols, double* __restrict__ out) {
+    const int c = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (codes) {
+        const int Hp = H / 2, Wp = W / 2;
+        const size_t base = ((size_t)n * C + c) * Hp * Wp;
+        auto at = [&](int pr, int pc, int& y, int& x) {
+            const unsigned cd = codes[base + (size_t)pr * Wp + pc];
+            y = 2 * pr + ((cd >> 1) & 1);
+            x = 2 * pc + (cd & 1);
+            return dy[base + (size_t)pr * Wp + pc];
+        };
+        for (int pc = tid; pc < Wp; pc += 256) {
+            int y, x;
+            float v = at(0, pc, y, x);
+            if (y == 0) {
+                s[0] += v;
+                if (x == 0) s[4] += v;
+                if (x == W - 1) s[5] += v;
+            }
+            if (Hp > 1 || true) {
+                v = at(Hp - 1, pc, y, x);
+                if (y == H - 1) {
+                    s[1] += v;
+                    if (x == 0) s[6] += v;
+                    if (x == W - 1) s[7] += v;
+                }
+            }
+        }
+        for (int pr = tid; pr < Hp; pr += 256) {
+            int y, x;
+            float v = at(pr, 0, y, x);
+            if (x == 0) s[2] += v;
+            v = at(pr, Wp - 1, y, x);
+            if (x == W - 1) s[3] += v;
+        }
+    } else {
+        const float* p = dy + ((size_t)n * C + c) * H * W;
+        for (int x = tid; x < cols; x += 256) {
+            if (rows > 0) s[0] += p[x];
+            if (H - 1 < rows) s[1] += p[(size_t)(H - 1) * W + x];
+        }
+        for (int y = tid; y < rows; y += 256) {
+            s[2] += p[(size_t)y * W];
+            if (W - 1 < cols) s[3] += p[(size_t)y * W + W - 1];
+        }
+        if (tid == 0 && rows > 0) {
+            s[4] = p[0];
+            if (W - 1 < cols) s[5] = p[W - 1];
+            if (H - 1 < rows) {
+                s[6] = p[(size_t)(H - 1) * W];
+                if (W - 1 < cols) s[7] = p[(size_t)(H - 1) * W + W - 1];
+            }
+        }
+    }
+    __shared__ float red[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float v = s[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 8) atomicAdd(out + (size_t)c * 8 + tid, (double)((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])));
+}
+
+// sums[ci] = sum_{co,k} w[co][ci][k] R[co][k] (see above); total[co] = sum of dy[co] (double, or the float bias gradient)
+__global__ void __launch_bounds__(256)
+conv_input_grad_sums_kernel(const float* __restrict__ w, const double* __restrict__ total_d, const float* __restrict__ total_f,
+                            const double* __restrict__ bs, int Cout, int Cin, double* __restrict__ sums) {
+    __shared__ double red[256];
+    const int ci = blockIdx.x;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < Cout * 9; e += 256) {
+        const int co = e / 9, k = e - 9 * co, ky = k / 3, kx = k - 3 * ky;
+        const double* b = bs + (size_t)co * 8;
+        double r = total_d ? total_d[co] : (double)total_f[co];
+        if (ky == 0) r -= b[0];
+        if (ky == 2) r -= b[1];
+        if (kx == 0) r -= b[2];
+        if (kx == 2) r -= b[3];
+        if (ky == 0 && kx == 0) r += b[4];
+        if (ky == 0 && kx == 2) r += b[5];
+        if (ky == 2 && kx == 0) r += b[6];
+        if (ky == 2 && kx == 2) r += b[7];
+        acc += (double)w[((size_t)co * Cin + ci) * 9 + k] * r;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[ci] = red[0];
+}
+
+}  // namespace
+
+extern "C" int afd_conv3x3_backward_data_bnapply_applicable(int Cin, int H, int W, int Cout, int pooled) {
+    if (getenv("AFD_NO_BWD_BNAPPLY")) return 0;
+    if (H < 2 || W < 2 || !afd::wino44_applicable(Cout, H, W, Cin)) return 0;
+    if (afd_conv3x3_backward_data_bnstats_needs_input(Cin, H, W, Cout)) return 0;
+    return pooled ? afd_conv3x3_pooled_backward_applicable(Cin, H, W, Cout) : 1;
+}
+
+// sums[0 .. Cin) = sum over the batch and the pixels of g = w^T * dy per input channel, from the weights and the border
+// sums of dy (sums must hold Cin + 8 Cout doubles: the tail is scratch); dy dense with its live region dy_rows x dy_cols,
+// or pooled with codes; dy_sums (double) or dbias (float): the per-channel sums of dy, whichever the caller has
+extern "C" int afd_conv3x3_input_grad_sums(const float* dy, const uint8_t* codes, const float* w, const double* dy_sums,
+                                           const float* dbias, double* sums, int N, int Cin, int H, int W, int Cout,
+                                           int dy_rows, int dy_cols, afd_stream_t stream) {
+    if (!dy || !w || !sums || (!dy_sums && !dbias) || N < 1 || Cin < 1 || Cout < 1 || H < 2 || W < 2)
+        return afd::fail(AFD_ERR_ARG, "conv3x3 input-gradient sums: bad argument");
+    if (N > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 input-gradient sums: N > 65535");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* bs = sums + Cin;
+    hipError_t e = hipMemsetAsync(bs, 0, sizeof(double) * 8 * Cout, s);
+    if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "conv3x3 input-gradient sums: memset: %s", hipGetErrorString(e));
+    if (codes) {
+        dy_rows = 2 * (H / 2);
+        dy_cols = 2 * (W / 2);
+    }
+    const int rows = dy_rows < H ? dy_rows : H, cols = dy_cols < W ? dy_cols : W;
+    hipLaunchKernelGGL(conv_border_sums_kernel, dim3(Cout, N), dim3(256), 0, s, dy, codes, Cout, H, W, rows, cols, bs);
+    hipLaunchKernelGGL(conv_input_grad_sums_kernel, dim3(Cin), dim3(256), 0, s, w, dy_sums, dbias, bs, Cout, Cin, sums);
+    return afd::check_launch("conv3x3 input-gradient sums kernels");
+}
+
+// backward-data with the BatchNorm (+ PReLU) backward of its result in the epilogue: dz [N][Cin][H][W] instead of g; z the
+// BatchNorm's input, bn_tab [Cin][4] = (mean, invstd, mean of g, mean of g * xhat), bn_slope the PReLU slope or null;
+// sums[0 .. Cin) = sum(dz) per channel, sums[Cin .. 2 Cin) = the slope's partial gradients (their sum is dslope);
+// dy dense, or (codes != null) the pooled gradient of the convolution's PReLU + max-pool
+extern "C" int afd_conv3x3_backward_data_bnapply(const float* dy, const uint8_t* codes, const float* w, const float* z,
+                                                 const float* bn_tab, const float* bn_slope, float* dz, double* sums, int N,
+                                                 int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
+                                                 size_t stat_ws_bytes, afd_stream_t stream) {
+    if (!dy || !w || !z || !bn_tab || !dz || !sums || !ws || !stat_ws)
+        return afd::fail(AFD_ERR_ARG, "conv3x3 dgrad + bn backward: null pointer");
+    if (N < 1 || !afd_conv3x3_backward_data_bnapply_applicable(Cin, H, W, Cout, codes != nullptr))
+        return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3 dgrad + bn backward: shape not on the F(4x4) kernel");
+    if (stat_ws_bytes < afd_conv3x3_backward_data_bnstats_workspace_bytes(N, Cin, H, W))
+        return afd::fail(AFD_ERR_WORKSPACE, "conv3x3 dgrad + bn backward: statistics workspace too small");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int co_pad = (Cin + 31) / 32 * 32;
+    const int slots = 2 * co_pad;
+    const long rows = afd::wino44_stat_rows(N, H, W);
+    float* part = static_cast<float*>(stat_ws);
+    double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
+    int rc = afd::wino44_run(dy, w, nullptr, dz, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, z, part, nullptr, nullptr, nullptr,
+                             0, codes, nullptr, nullptr, bn_tab, bn_slope);
+    if (rc) return rc;
+    const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
+    hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cin,
+                       sums);
+    return afd::check_launch("wino_bnstats_reduce kernels");
+}
+
 // ---- the BatchNorm in FRONT of a 3x3 convolution applied while the convolution loads (round 4) ----
 // A training-mode BatchNorm(affine=False) whose only consumer is a 3x3 / pad 1 convolution on the F(4x4) kernels need
 // not write its result: the convolution's forward and backward-weight launches take the BatchNorm's INPUT (z and the

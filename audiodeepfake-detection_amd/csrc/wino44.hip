@@ -66,6 +66,14 @@ struct G4 {
     const float* in_aff;
     const float* in_slope;
     int noflip;  // development switch AFD_WINO44_NO_FLIP: see the kernel's wave roles
+    // BatchNorm backward in the epilogue (backward-data launches with the statistics epilogue; round 4): the result g is the
+    // gradient of a training-mode BatchNorm(affine=False) output whose backward sums are known BEFORE the launch
+    // (afd_conv3x3_input_grad_sums, afd_conv_weight_dot): bn_tab [C][4] = (mean, invstd, mean of g, mean of g * xhat),
+    // bn_in the BatchNorm's INPUT z, bn_slope the PReLU slope in front of it or null.  The launch then writes
+    // dz = PReLU'(z) * invstd * (g - mdy - xhat * mdyx) -- bn_bwd_apply_kernel's arithmetic -- instead of g, and its two
+    // sums per channel are sum(dz) (the bias gradient of the convolution in front) and the PReLU slope's partial gradient
+    const float* bn_tab;
+    const float* bn_slope;
 };
 __device__ __forceinline__ bool getenv_noflip(const G4& g) { return g.noflip != 0; }
 
@@ -463,6 +471,9 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // bn_in == nullptr: only the sums of the result are wanted (the caller takes sum(g * x) from the weight gradient:
     // sum_px g[ci] x[ci] = sum_{co,k} w[co][ci][k] dw[co][ci][k], afd_conv_weight_dot) -- no loads, 3.5 GB less per launch
     const bool have_x = BST && g.bn_in != nullptr;  // uniform
+    const bool bnb = BST && have_x && g.bn_tab != nullptr;  // uniform: see G4::bn_tab
+    const bool bn_act = bnb && g.bn_slope != nullptr;
+    const float bn_a = bn_act ? g.bn_slope[0] : 1.f;
     if constexpr (BST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) zn[r] = f4u{0.f, 0.f, 0.f, 0.f};
@@ -501,6 +512,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         }
         if constexpr (FST) sg[j] = sgv[j] = 0.f;
         const float bv = (bias && co < g.Cout) ? bias[co] : 0.f;
+        f32x4 bt = {0.f, 1.f, 0.f, 0.f};
+        if (BST && bnb) bt = *reinterpret_cast<const f32x4*>(g.bn_tab + 4 * min(co, g.Cout - 1));
         if constexpr (POOL) {
             // same order and tie rule as prelu_pool_fwd_kernel (nn.hip): first maximum wins
             if (co < g.Cout && txe < g.tilesX) {
@@ -576,8 +589,26 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                                 zv[q] = e == 0 ? zq[r][0] : e == 1 ? zq[r][1] : e == 2 ? zq[r][2] : e == 3 ? zq[r][3] : 0.f;
                             }
                         }
-                        sg[j] += (gq[0] + gq[1]) + (gq[2] + gq[3]);
-                        sgv[j] += fmaf(gq[0], zv[0], gq[1] * zv[1]) + fmaf(gq[2], zv[2], gq[3] * zv[3]);
+                        if (bnb) {  // uniform: the BatchNorm (+ PReLU) backward of the result, as bn_bwd_apply_kernel does it
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float zz = zv[q];
+                                const float v = bn_act ? (zz > 0.f ? zz : bn_a * zz) : zz;
+                                const float xh = (v - bt[0]) * bt[1];
+                                float gg = bt[1] * (gq[q] - bt[2] - xh * bt[3]);
+                                const bool live = !BORDER || ox + q < g.cols;
+                                gg = live ? gg : 0.f;
+                                if (bn_act && zz <= 0.f) {
+                                    sgv[j] = fmaf(gg, zz, sgv[j]);
+                                    gg *= bn_a;
+                                }
+                                sg[j] += gg;
+                                o[q] = gg - bv;  // (stored as o + bv below)
+                            }
+                        } else {
+                            sg[j] += (gq[0] + gq[1]) + (gq[2] + gq[3]);
+                            sgv[j] += fmaf(gq[0], zv[0], gq[1] * zv[1]) + fmaf(gq[2], zv[2], gq[3] * zv[3]);
+                        }
                     }
                     if constexpr (FST) {
                         const bool act = g.slope != nullptr;
@@ -716,7 +747,8 @@ long wino44_stat_rows(int N, int H, int W) {
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
                const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx, int fwd_stats,
-               const unsigned char* pooled_codes, const float* in_aff, const float* in_slope) {
+               const unsigned char* pooled_codes, const float* in_aff, const float* in_slope, const float* bn_tab,
+               const float* bn_slope) {
     if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
     G4 g{};
@@ -733,6 +765,10 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
     g.in_aff = in_aff; g.in_slope = in_slope;
     g.noflip = getenv("AFD_WINO44_NO_FLIP") != nullptr;
+    g.bn_tab = bn_tab; g.bn_slope = bn_slope;
+    if (bn_tab && (!dgrad || !bn_in || !stat_part || fwd_stats))
+        return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the BatchNorm backward epilogue belongs to backward-data launches "
+                                      "with the statistics epilogue and the BatchNorm's input");
     if (in_aff && (dgrad || pooled_codes))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the input fold is built for forward launches");
     if (pooled_codes && (!dgrad || !stat_part || fwd_stats || u || g.rows != H || g.cols != W || (Cout != 64 && Cout != 32)))

@@ -239,6 +239,27 @@ int afd_conv3x3_forward_stats(const float* x, const float* w, const float* bias,
  *   the backward-data launch of the layer does not read its input and is unchanged.
  * Only for layers on the F(4x4) Winograd kernels (afd_conv3x3_input_fold_applicable); AFD_ERR_UNSUPPORTED otherwise. */
 int afd_conv3x3_input_fold_applicable(int Cin, int H, int W, int Cout, int pooled, int want_stats);
+
+/* The BACKWARD of that BatchNorm (and of the PReLU in front of it) inside the convolution's backward-data launch
+ * (models.py:267-276, what autograd runs for nn.PReLU -> nn.SyncBatchNorm(affine=False) -> nn.Conv2d(k=3, padding=1)).
+ * The BatchNorm backward needs the batch sums of g = dL/d(its output) and of g * xhat before it touches an element; both
+ * follow from small tensors once the convolution's backward-weight launch has run:
+ *   sum g * xhat = afd_conv_weight_dot(w, dw);  sum g = afd_conv3x3_input_grad_sums (weights x border-aware sums of dy).
+ * afd_conv3x3_backward_data_bnapply then writes dz = PReLU'(z) * invstd * (g - mean(g) - xhat * mean(g * xhat)) instead of g:
+ * z the BatchNorm's input, bn_tab [Cin][4] = (mean, invstd, mean(g), mean(g * xhat)), bn_slope the PReLU slope or NULL;
+ * sums[0 .. Cin) = sum(dz) per channel (the bias gradient of the convolution that produced z), sums[Cin .. 2 Cin) =
+ * per-channel partial gradients of the slope.  dy dense, or (codes != NULL) the pooled gradient with the pool's codes.
+ * afd_conv3x3_input_grad_sums: sums must hold Cin + 8 Cout doubles (the tail is scratch); dy_sums (double) or dbias
+ * (float) = the per-channel sums of dy, whichever the caller has. */
+int afd_conv3x3_backward_data_bnapply_applicable(int Cin, int H, int W, int Cout, int pooled);
+int afd_conv3x3_input_grad_sums(const float* dy, const uint8_t* codes /* may be NULL */, const float* w,
+                                const double* dy_sums /* may be NULL */, const float* dbias /* may be NULL */,
+                                double* sums, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols,
+                                afd_stream_t stream);
+int afd_conv3x3_backward_data_bnapply(const float* dy, const uint8_t* codes /* may be NULL */, const float* w,
+                                      const float* z, const float* bn_tab, const float* bn_slope /* may be NULL */,
+                                      float* dz, double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
+                                      size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
 int afd_conv3x3_forward_fold(const float* x, const float* in_aff, const float* in_slope /* may be NULL */,
                              const float* w, const float* bias, const float* slope, float* y, float* u, uint8_t* idx,
                              double* sums /* may be NULL */, int N, int Cin, int H, int W, int Cout, void* ws,

@@ -1107,7 +1107,7 @@ FOLD_CASES = [
 
 
 @pytest.mark.parametrize("shape,slope_in,cout,pooled,stats", FOLD_CASES)
-def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, pooled, stats):
+def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, pooled, stats, monkeypatch):
     """`batch_norm(defer=True)` -> 3x3 convolution (`afd_conv3x3_forward_fold` / `afd_conv3x3_backward_weight_fold`):
     the BatchNorm's result is never stored, the convolution's forward and backward-weight launches build
     (PReLU(z) - mean) * invstd from z while they load -- with afd_bn_apply_forward's arithmetic, so outputs and
@@ -1122,7 +1122,13 @@ def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, po
     a_out = torch.full((1,), 0.25, device="cuda")
     assert ops.conv3x3_input_fold_applicable(bn_in, conv, shape, pooled, stats)
     res = []
-    for defer in (False, True):
+    for defer in (False, True, "and the backward in the backward-data launch"):
+        # (second run: the BatchNorm's backward is its own pass, as in the two-pass chain; third run: the default --
+        # the convolution's backward-data launch applies it, `afd_conv3x3_backward_data_bnapply`)
+        if defer is True:
+            monkeypatch.setenv("AFD_NO_BWD_BNAPPLY", "1")
+        else:
+            monkeypatch.delenv("AFD_NO_BWD_BNAPPLY", raising=False)
         bn_in.reset_running_stats()
         bn_out.reset_running_stats()
         conv.zero_grad()
@@ -1131,7 +1137,7 @@ def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, po
         xg = x.clone().requires_grad_(True)
         link = {}
         hh = ops.batch_norm(xg, bn_in, a_in, False, link, defer=defer)
-        assert ("fold" in link) == defer
+        assert ("fold" in link) == bool(defer)
         if defer:
             assert hh.data_ptr() == xg.data_ptr()  # nothing was written
         if pooled:
@@ -1158,6 +1164,15 @@ def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, po
             _close(got, want.cpu(), 3e-4, what)
         else:
             assert torch.equal(got, want), f"{what}: {(got - want).abs().max().item():.3e}"
+    # with the BatchNorm's backward inside the backward-data launch its two batch sums come from the weights, the weight
+    # gradient and the border sums of the output gradient instead of a sum over g: the input gradient agrees to rounding
+    for got, want, what in zip(res[2], res[0], names):
+        if want is None:
+            continue
+        if what in ("input gradient", "slope gradient"):
+            _close(got, want.cpu(), 3e-4 if what == "slope gradient" else 3e-6, what + " (backward in the launch)")
+        else:
+            assert torch.equal(got, want), f"{what} (backward in the launch): {(got - want).abs().max().item():.3e}"
     # and the chain against float64
     xd = x.double().cpu()
     v = xd if slope_in is None else torch.where(xd > 0, xd, float(slope_in) * xd)
