@@ -70,7 +70,7 @@ _SIGNATURES = {
     "afd_conv3x3_input_fold_applicable": (c_i, [c_i] * 6),
     "afd_conv3x3_backward_data_bnapply_applicable": (c_i, [c_i] * 5),
     "afd_conv3x3_input_grad_sums": (c_i, [c_p] * 6 + [c_i] * 7 + [c_p]),
-    "afd_conv3x3_backward_data_bnapply": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p, c_sz, c_p]),
+    "afd_conv3x3_backward_data_bnapply": (c_i, [c_p] * 9 + [c_i] * 5 + [c_p, c_sz, c_p, c_sz, c_p]),
     "afd_conv3x3_forward_fold": (c_i, [c_p] * 10 + [c_i] * 5 + [c_p, c_sz, c_p, c_sz, c_p]),
     "afd_conv3x3_backward_weight_fold": (c_i, [c_p] * 8 + [c_i] * 7 + [c_p, c_sz, c_p]),
     "afd_bn_fold_forward": (c_i, [c_p] * 6 + [c_i, c_i, c_p]),

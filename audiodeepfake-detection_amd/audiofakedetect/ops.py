@@ -296,7 +296,7 @@ def _bn_backward_in_dgrad_ok(lib, bn_link, fold, geom, pooled: bool) -> bool:
                 and lib.afd_conv3x3_backward_data_bnapply_applicable(cin, h, wd, cout, int(pooled)))
 
 
-def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, fold, bn_ctx, ws):
+def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, fold, bn_ctx, ws, pool=None):
     """Backward-data of a 3x3 convolution whose input was a deferred BatchNorm (`batch_norm(defer=True)`), with that
     BatchNorm's -- and the PReLU's in front of it -- backward applied in the launch's epilogue
     (`afd_conv3x3_backward_data_bnapply`): returns (dL/dz, its per-channel sums (double), dslope or None).  The two batch
@@ -304,6 +304,9 @@ def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, f
     sum(g) from the weights and the border sums of dy (`afd_conv3x3_input_grad_sums`)."""
     n, cin, h, wd, cout = geom[:5]
     aff, slope = fold
+    bn_codes = None
+    if pool is not None:  # the BatchNorm sits behind PReLU + max-pool: z is the pooled tensor, the slope the pool's
+        bn_codes, slope = pool
     mean, invstd, count, sync = bn_ctx
     dev = z.device
     buf = torch.empty(max(2 * cin, cin + 8 * cout), dtype=torch.float64, device=dev)
@@ -323,13 +326,13 @@ def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, f
         _native.ptr(sums), cin, -1.0 if on_dev else float(count), _native.ptr(count) if on_dev else None,
         _native.ptr(mdy), _native.ptr(mdyx), _native.stream_ptr()), "afd_bn_backward_means")
     tab = torch.stack((mean, invstd, mdy, mdyx), dim=1).contiguous()
-    dz = torch.empty_like(z)
+    dz = _empty_with_slack(z.shape, torch.float32, dev)  # (a pooled gradient is read in whole vectors past its end)
     out = torch.empty(2 * cin, dtype=torch.float64, device=dev)
     sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), dev, "bnstats")
     _native.check(lib.afd_conv3x3_backward_data_bnapply(
         _native.ptr(dy), _native.ptr(codes), _native.ptr(w), _native.ptr(z), _native.ptr(tab), _native.ptr(slope),
-        _native.ptr(dz), _native.ptr(out), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.ptr(sws), sws.numel(),
-        _native.stream_ptr()), "afd_conv3x3_backward_data_bnapply")
+        _native.ptr(bn_codes), _native.ptr(dz), _native.ptr(out), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(),
+        _native.ptr(sws), sws.numel(), _native.stream_ptr()), "afd_conv3x3_backward_data_bnapply")
     dslope = out[cin:].sum().float().reshape(1) if slope is not None else None
     return dz, out[:cin], dslope
 
@@ -358,9 +361,10 @@ def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_d
             _native.ptr(x), _native.ptr(fold[0]), _native.ptr(fold[1]), _native.ptr(dy), None, _native.ptr(dw),
             _native.ptr(db), _native.ptr(dy_sums), n, cin, h, wd, cout, crop[0], crop[1], _native.ptr(ws), ws.numel(),
             _native.stream_ptr()), "afd_conv3x3_backward_weight_fold")
+        pool = bn_link.pop("bn_pool", None)
         dz, dxs, dslope = _dgrad_with_bn_backward(lib, x, w, dw, dy, None, dy_sums, db, geom, crop, fold,
-                                                  bn_link.pop("bn_ctx"), ws)
-        bn_link["applied"] = (dslope, dxs)
+                                                  bn_link.pop("bn_ctx"), ws, pool)
+        bn_link["applied"] = (dslope, dxs, pool is not None)
         return dz, dw, db
     if (need_dx and bn is not None and k == 3 and pad == 1 and dil == 1
             and lib.afd_conv3x3_backward_data_bnstats_applicable(cin, h, wd, cout)):
@@ -562,6 +566,13 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
                 _native.ptr(idx), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
                 "afd_conv3x3_prelu_pool_forward")
         _tap("pool", idx)
+        import os
+        if (out_link is not None and x.is_cuda and bn_link is not None and bn_link.get("bn")
+                and not os.environ.get("AFD_NO_BWD_POOLAPPLY")
+                and lib.afd_conv3x3_pooled_backward_applicable(cin, h, wd, cout)):
+            # a BatchNorm right behind the pool may have its backward -- and this pool's / PReLU's -- applied by ITS
+            # consumer's backward-data launch, which then hands back the pooled gradient (`_dgrad_with_bn_backward`)
+            out_link["pool_ctx"] = (idx, slope)
         ctx.save_for_backward(x, w, u, idx, slope)
         ctx.geom = (n, cin, h, wd, cout, 3, 1, 1)
         ctx.crop = (2 * (h // 2), 2 * (wd // 2))
@@ -580,13 +591,20 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
             # the pooled gradient + the argmax codes stand for the dense one (three quarters zeros, 4x the bytes,
             # written once and read twice): both convolution kernels expand them while they load
             du = _f32c(du)
-            gg = _empty_with_slack(u.shape, torch.float32, u.device)
-            dslope = torch.zeros(1, dtype=torch.float32, device=u.device)
+            done = ctx.out_link.pop("compacted", None) if ctx.out_link is not None else None
+            if done is not None:
+                # du IS the pooled gradient of this convolution: the BatchNorm behind the pool and this PReLU / pool were
+                # differentiated by the next convolution's backward-data launch
+                gg, dslope = du, done
+            else:
+                gg = _empty_with_slack(u.shape, torch.float32, u.device)
+                dslope = torch.zeros(1, dtype=torch.float32, device=u.device)
             coef = ctx.out_link.pop("affine_coef", None) if ctx.out_link is not None else None
-            _native.check(lib.afd_prelu_pool_backward_compact(
-                _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(coef), cout,
-                _native.ptr(gg), _native.ptr(dslope), n * cout, h // 2, wd // 2, _native.stream_ptr()),
-                "afd_prelu_pool_backward_compact")
+            if done is None:
+                _native.check(lib.afd_prelu_pool_backward_compact(
+                    _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(coef), cout,
+                    _native.ptr(gg), _native.ptr(dslope), n * cout, h // 2, wd // 2, _native.stream_ptr()),
+                    "afd_prelu_pool_backward_compact")
             ws = _ws(lib.afd_conv2d_workspace_bytes(n, cin, h, wd, cout, 3, 1, 1), x.device)
             if ctx.has_bias and _bn_backward_in_dgrad_ok(lib, ctx.bn_link, ctx.fold, ctx.geom, True):
                 # as in `_conv2d_backward`: backward-weight first, then backward-data with the BatchNorm / PReLU
@@ -597,9 +615,10 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
                     _native.ptr(x), _native.ptr(ctx.fold[0]), _native.ptr(ctx.fold[1]), _native.ptr(gg), _native.ptr(idx),
                     _native.ptr(dw), _native.ptr(db), None, n, cin, h, wd, cout, h, wd, _native.ptr(ws), ws.numel(),
                     _native.stream_ptr()), "afd_conv3x3_backward_weight_fold")
+                pool = ctx.bn_link.pop("bn_pool", None)
                 dz, dxs, dsl_in = _dgrad_with_bn_backward(lib, x, w, dw, gg, idx, None, db, ctx.geom, ctx.crop, ctx.fold,
-                                                         ctx.bn_link.pop("bn_ctx"), ws)
-                ctx.bn_link["applied"] = (dsl_in, dxs)
+                                                         ctx.bn_link.pop("bn_ctx"), ws, pool)
+                ctx.bn_link["applied"] = (dsl_in, dxs, pool is not None)
                 return dz, dw, db, dslope, None, None
             dx = torch.empty_like(x)
             sums = torch.empty(2 * cin, dtype=torch.float64, device=x.device)
@@ -623,6 +642,8 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
                                                   sums.data_ptr() + 8 * cin, _native.stream_ptr()), "afd_conv_weight_dot")
             ctx.bn_link["bwd_sums"] = sums
             return dx, dw, db, dslope, None, None
+        if ctx.out_link is not None and "compacted" in ctx.out_link:
+            raise RuntimeError("conv3x3 + pool backward: a pooled gradient arrived on the dense-gradient path")
         dz, dslope = _pool_backward(u, slope, idx, du, (n, cout, h, wd), ctx.out_link)
         dx, dw, db = _conv2d_backward(x, w, ctx.bias_ref, ctx.has_bias, ctx.geom, ctx.crop, dz,
                                       ctx.needs_input_grad[0], ctx.needs_input_grad[1],
@@ -793,8 +814,13 @@ class _BatchNorm(torch.autograd.Function):
             link["bn"] = True
             if prod_link is None:
                 # the consumer's backward-data launch may apply this layer's (and the PReLU's) backward itself
-                # (`_dgrad_with_bn_backward`); a BatchNorm behind a pool hands its backward to the pool instead
+                # (`_dgrad_with_bn_backward`)
                 link["bn_ctx"] = (mean, invstd, ctx.count, sync)
+            elif slope is None and "pool_ctx" in prod_link:
+                # ... and behind a fused convolution + PReLU + pool, that pool's and PReLU's backward with it (the pool's
+                # codes decide the slope factor); otherwise the BatchNorm hands its backward to the pool (below)
+                link["bn_ctx"] = (mean, invstd, ctx.count, sync)
+                link["bn_pool"] = prod_link["pool_ctx"]
             empty = torch.empty(0)
             if slope is not None:
                 _tap("prelu", x)
@@ -846,8 +872,11 @@ class _BatchNorm(torch.autograd.Function):
         applied = ctx.link.pop("applied", None) if ctx.link is not None else None
         if applied is not None:
             # the consumer's backward-data launch has applied this layer's and the PReLU's backward: dy IS dL/dx
-            dslope, dxs = applied
-            if ctx.sum_link is not None:
+            dslope, dxs, pooled = applied
+            if pooled:
+                ctx.prod_link["compacted"] = dslope  # (the slope is the pool's: see `_Conv3x3PReLUPool.backward`)
+                dslope = None
+            elif ctx.sum_link is not None:
                 ctx.sum_link["dy_sums"] = dxs
             return dy, dslope, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         slope = slope if has_slope else None

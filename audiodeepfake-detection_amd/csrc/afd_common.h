@@ -105,7 +105,8 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
                float* u = nullptr, unsigned char* idx = nullptr, int fwd_stats = 0,
                const unsigned char* pooled_codes = nullptr,  // backward-data from the pooled gradient: see G4::pidx
                const float* in_aff = nullptr, const float* in_slope = nullptr,  // input fold: see G4::in_aff
-               const float* bn_tab = nullptr, const float* bn_slope = nullptr);  // BatchNorm backward epilogue: G4::bn_tab
+               const float* bn_tab = nullptr, const float* bn_slope = nullptr,  // BatchNorm backward epilogue: G4::bn_tab
+               const unsigned char* bn_codes = nullptr);
 long wino44_stat_rows(int N, int H, int W);
 bool wino44_pool_applicable(int Cin, int H, int W, int Cout);
 // wino44_wgrad.hip: 3x3 / pad 1 backward-weight in the Winograd F(4x4, 3x3) domain

@@ -899,11 +899,13 @@ extern "C" int afd_conv3x3_input_grad_sums(const float* dy, const uint8_t* codes
 // backward-data with the BatchNorm (+ PReLU) backward of its result in the epilogue: dz [N][Cin][H][W] instead of g; z the
 // BatchNorm's input, bn_tab [Cin][4] = (mean, invstd, mean of g, mean of g * xhat), bn_slope the PReLU slope or null;
 // sums[0 .. Cin) = sum(dz) per channel, sums[Cin .. 2 Cin) = the slope's partial gradients (their sum is dslope);
-// dy dense, or (codes != null) the pooled gradient of the convolution's PReLU + max-pool
+// dy dense, or (codes != null) the pooled gradient of the convolution's PReLU + max-pool.  bn_codes != null: the
+// BatchNorm sits right behind PReLU + MaxPool2d(2, 2) -- z is the pooled tensor, bn_codes the pool's codes, bn_slope that
+// PReLU's slope -- and dz is the pooled gradient afd_prelu_pool_backward_compact would leave
 extern "C" int afd_conv3x3_backward_data_bnapply(const float* dy, const uint8_t* codes, const float* w, const float* z,
-                                                 const float* bn_tab, const float* bn_slope, float* dz, double* sums, int N,
-                                                 int Cin, int H, int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
-                                                 size_t stat_ws_bytes, afd_stream_t stream) {
+                                                 const float* bn_tab, const float* bn_slope, const uint8_t* bn_codes,
+                                                 float* dz, double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
+                                                 size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream) {
     if (!dy || !w || !z || !bn_tab || !dz || !sums || !ws || !stat_ws)
         return afd::fail(AFD_ERR_ARG, "conv3x3 dgrad + bn backward: null pointer");
     if (N < 1 || !afd_conv3x3_backward_data_bnapply_applicable(Cin, H, W, Cout, codes != nullptr))
@@ -917,7 +919,7 @@ extern "C" int afd_conv3x3_backward_data_bnapply(const float* dy, const uint8_t*
     float* part = static_cast<float*>(stat_ws);
     double* part2 = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(part + (size_t)rows * slots) + 63) & ~(uintptr_t)63);
     int rc = afd::wino44_run(dy, w, nullptr, dz, N, Cout, H, W, Cin, 1, H, W, ws, ws_bytes, s, z, part, nullptr, nullptr, nullptr,
-                             0, codes, nullptr, nullptr, bn_tab, bn_slope);
+                             0, codes, nullptr, nullptr, bn_tab, bn_slope, bn_codes);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);

@@ -74,6 +74,10 @@ struct G4 {
     // sums per channel are sum(dz) (the bias gradient of the convolution in front) and the PReLU slope's partial gradient
     const float* bn_tab;
     const float* bn_slope;
+    // ... of a BatchNorm right behind PReLU + MaxPool2d(2, 2) (block 3 -> 4): bn_in is the pooled tensor u, bn_codes the
+    // pool's codes (bit 2: the window's winner was <= 0) -- the launch then writes the POOLED gradient of the convolution
+    // in front of the pool (what afd_prelu_pool_backward_compact leaves), the slope factor decided by the code
+    const unsigned char* bn_codes;
 };
 __device__ __forceinline__ bool getenv_noflip(const G4& g) { return g.noflip != 0; }
 
@@ -457,13 +461,16 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // BST: the BatchNorm outputs at channel j's output positions, requested one channel ahead from clamped (always
     // valid) addresses; products are masked where they are used
     f4u zn[BST ? 4 : 1];
+    unsigned cn[BST ? 4 : 1];
     auto load_xhat = [&](int j) {
         const int co = min(16 * wave + 4 * kq + j, g.Cout - 1);
         const int oxq = min(ox, g.W - 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oyr = min(oy + r, g.H - 1);
-            zn[r] = *reinterpret_cast<const f4u*>(g.bn_in + (((size_t)n * g.Cout + co) * g.H + oyr) * g.W + oxq);
+            const size_t o = (((size_t)n * g.Cout + co) * g.H + oyr) * g.W + oxq;
+            zn[r] = *reinterpret_cast<const f4u*>(g.bn_in + o);
+            if (g.bn_codes) cn[r] = *reinterpret_cast<const u32b*>(g.bn_codes + o);
         }
     };
     static_assert(!(BST && FST), "one statistics epilogue per launch");
@@ -474,6 +481,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const bool bnb = BST && have_x && g.bn_tab != nullptr;  // uniform: see G4::bn_tab
     const bool bn_act = bnb && g.bn_slope != nullptr;
     const float bn_a = bn_act ? g.bn_slope[0] : 1.f;
+    const bool bn_pool = bnb && g.bn_codes != nullptr;
+    const float bn_inva = (bn_act && bn_a != 0.f) ? 1.f / bn_a : 0.f;
     if constexpr (BST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) zn[r] = f4u{0.f, 0.f, 0.f, 0.f};
@@ -504,9 +513,13 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         const int j = 2 * jp + h;
         const int co = 16 * wave + 4 * kq + j;
         f4u zq[BST ? 4 : 1];
+        unsigned cq[BST ? 4 : 1];
         if constexpr (BST) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) zq[r] = zn[r];
+            for (int r = 0; r < 4; ++r) {
+                zq[r] = zn[r];
+                cq[r] = cn[r];
+            }
             if (j + 1 < 4 && have_x) load_xhat(j + 1);
             sg[j] = sgv[j] = 0.f;
         }
@@ -593,13 +606,16 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 const float zz = zv[q];
-                                const float v = bn_act ? (zz > 0.f ? zz : bn_a * zz) : zz;
+                                // (pooled: zz is the pool's output, already through its PReLU; the code says which side)
+                                const int e = BORDER ? ox + q - min(ox, g.W - 4) : q;
+                                const bool neg = bn_pool ? ((unsigned)e < 4u && ((cq[r] >> (8 * e)) & 4u) != 0u) : zz <= 0.f;
+                                const float v = (bn_act && !bn_pool) ? (zz > 0.f ? zz : bn_a * zz) : zz;
                                 const float xh = (v - bt[0]) * bt[1];
                                 float gg = bt[1] * (gq[q] - bt[2] - xh * bt[3]);
                                 const bool live = !BORDER || ox + q < g.cols;
                                 gg = live ? gg : 0.f;
-                                if (bn_act && zz <= 0.f) {
-                                    sgv[j] = fmaf(gg, zz, sgv[j]);
+                                if (bn_act && neg) {
+                                    sgv[j] = fmaf(gg, bn_pool ? zz * bn_inva : zz, sgv[j]);
                                     gg *= bn_a;
                                 }
                                 sg[j] += gg;
@@ -748,7 +764,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
                int Cout, int dgrad, int out_rows, int out_cols, void* ws, size_t ws_bytes, hipStream_t s,
                const float* bn_in, float* stat_part, const float* slope, float* u, unsigned char* idx, int fwd_stats,
                const unsigned char* pooled_codes, const float* in_aff, const float* in_slope, const float* bn_tab,
-               const float* bn_slope) {
+               const float* bn_slope, const unsigned char* bn_codes) {
     if (!ws || ws_bytes < wino44_workspace_bytes(Cin, Cout))
         return afd::fail(AFD_ERR_WORKSPACE, "winograd 4x4 conv: workspace too small");
     G4 g{};
@@ -765,7 +781,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
     g.in_aff = in_aff; g.in_slope = in_slope;
     g.noflip = getenv("AFD_WINO44_NO_FLIP") != nullptr;
-    g.bn_tab = bn_tab; g.bn_slope = bn_slope;
+    g.bn_tab = bn_tab; g.bn_slope = bn_slope; g.bn_codes = bn_tab ? bn_codes : nullptr;
     if (bn_tab && (!dgrad || !bn_in || !stat_part || fwd_stats))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the BatchNorm backward epilogue belongs to backward-data launches "
                                       "with the statistics epilogue and the BatchNorm's input");

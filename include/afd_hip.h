@@ -249,6 +249,9 @@ int afd_conv3x3_input_fold_applicable(int Cin, int H, int W, int Cout, int poole
  * z the BatchNorm's input, bn_tab [Cin][4] = (mean, invstd, mean(g), mean(g * xhat)), bn_slope the PReLU slope or NULL;
  * sums[0 .. Cin) = sum(dz) per channel (the bias gradient of the convolution that produced z), sums[Cin .. 2 Cin) =
  * per-channel partial gradients of the slope.  dy dense, or (codes != NULL) the pooled gradient with the pool's codes.
+ * bn_codes != NULL: the BatchNorm sits right behind nn.PReLU -> nn.MaxPool2d(2, 2) (models.py:264-266): z is the pooled
+ * tensor, bn_codes the pool's argmax codes, bn_slope that PReLU's slope, and dz is the pooled gradient of the convolution
+ * in front of the pool (what afd_prelu_pool_backward_compact leaves).
  * afd_conv3x3_input_grad_sums: sums must hold Cin + 8 Cout doubles (the tail is scratch); dy_sums (double) or dbias
  * (float) = the per-channel sums of dy, whichever the caller has. */
 int afd_conv3x3_backward_data_bnapply_applicable(int Cin, int H, int W, int Cout, int pooled);
@@ -258,8 +261,9 @@ int afd_conv3x3_input_grad_sums(const float* dy, const uint8_t* codes /* may be 
                                 afd_stream_t stream);
 int afd_conv3x3_backward_data_bnapply(const float* dy, const uint8_t* codes /* may be NULL */, const float* w,
                                       const float* z, const float* bn_tab, const float* bn_slope /* may be NULL */,
-                                      float* dz, double* sums, int N, int Cin, int H, int W, int Cout, void* ws,
-                                      size_t ws_bytes, void* stat_ws, size_t stat_ws_bytes, afd_stream_t stream);
+                                      const uint8_t* bn_codes /* may be NULL */, float* dz, double* sums, int N, int Cin,
+                                      int H, int W, int Cout, void* ws, size_t ws_bytes, void* stat_ws,
+                                      size_t stat_ws_bytes, afd_stream_t stream);
 int afd_conv3x3_forward_fold(const float* x, const float* in_aff, const float* in_slope /* may be NULL */,
                              const float* w, const float* bias, const float* slope, float* y, float* u, uint8_t* idx,
                              double* sums /* may be NULL */, int N, int Cin, int H, int W, int Cout, void* ws,

@@ -1181,3 +1181,56 @@ def test_batchnorm_applied_while_the_convolution_loads(shape, slope_in, cout, po
     if pooled:
         zr = F.max_pool2d(torch.where(zr > 0, zr, 0.25 * zr), 2, 2)
     _close(res[1][0], zr, 2e-5, "folded convolution against float64")
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 13, 1033), (3, 64, 51, 129), (1, 32, 12, 265)])
+def test_pool_and_batchnorm_backward_inside_the_next_backward_data_launch(shape, monkeypatch):
+    """DCNN blocks 2 -> 3 -> 4: BatchNorm -> [conv3x3 + PReLU + pool] -> BatchNorm -> conv3x3 -> BatchNorm.  By default the
+    second convolution's backward-data launch applies the middle BatchNorm's backward AND the pool's / PReLU's
+    (`afd_conv3x3_backward_data_bnapply` with the pool's codes) and hands the pooled gradient straight to the first
+    convolution's backward; with AFD_NO_BWD_BNAPPLY=1 the pool's backward pass does it.  Same gradients to rounding."""
+    torch.manual_seed(43)
+    n, cin, h, w = shape
+    c1, c2 = (96, 128) if cin == 64 else (64, 32)
+    x = torch.randn(shape, device="cuda") * 1.3 + 0.2
+    conv1 = torch.nn.Conv2d(cin, c1, 3, padding=1).cuda()
+    conv2 = torch.nn.Conv2d(c1, c2, 3, padding=1).cuda()
+    bn0 = torch.nn.BatchNorm2d(cin, affine=False).cuda().train()
+    bn1 = torch.nn.BatchNorm2d(c1, affine=False).cuda().train()
+    bn2 = torch.nn.BatchNorm2d(c2, affine=False).cuda().train()
+    a0 = torch.full((1,), 0.3, device="cuda", requires_grad=True)
+    a1 = torch.full((1,), 0.25, device="cuda", requires_grad=True)
+    a2 = torch.full((1,), 0.2, device="cuda")
+    lib = _native.load()
+    if not (lib.afd_conv3x3_pooled_backward_applicable(cin, h, w, c1)
+            and ops.conv3x3_input_fold_applicable(bn1, conv2, (n, c1, h // 2, w // 2), False, True)):
+        pytest.skip("geometry off the kernels this chain needs")
+    res = []
+    for off in (True, False):
+        if off:
+            monkeypatch.setenv("AFD_NO_BWD_BNAPPLY", "1")
+        else:
+            monkeypatch.delenv("AFD_NO_BWD_BNAPPLY", raising=False)
+        for m in (conv1, conv2):
+            m.zero_grad()
+        a0.grad = a1.grad = None
+        xg = x.clone().requires_grad_(True)
+        l0, pool_link, l1 = {}, {"want_stats": True}, {}
+        h0 = ops.batch_norm(xg, bn0, a0, False, l0, defer=True)
+        u = ops.conv3x3_prelu_maxpool(h0, conv1.weight, conv1.bias, a1, l0, pool_link)
+        h1 = ops.batch_norm(u, bn1, None, False, l1, pool_link, defer=True)
+        out_link = {"want_stats": True, "stats_slope": a2}
+        z = ops.conv2d(h1, conv2.weight, conv2.bias, 1, 1, bn_link=l1, out_link=out_link)
+        y = ops.batch_norm(z, bn2, a2, False, None, sum_link=out_link)
+        gen = torch.Generator(device="cuda").manual_seed(7)
+        y.backward(torch.randn(y.shape, device="cuda", generator=gen))
+        assert ("compacted" not in pool_link) and ("applied" not in l1)  # consumed
+        res.append((xg.grad.clone(), conv1.weight.grad.clone(), conv1.bias.grad.clone(), conv2.weight.grad.clone(),
+                    conv2.bias.grad.clone(), a0.grad.clone(), a1.grad.clone()))
+    names = ("input gradient", "first weight gradient", "first bias gradient", "second weight gradient",
+             "second bias gradient", "slope in front", "pool's slope")
+    # (the first convolution's bias gradient sums the pooled gradient, whose terms the BatchNorm backward centred: the
+    # two forms of that arithmetic -- the pool pass's A g + B u + K, the launch's invstd (g - mean g - xhat mean g xhat) --
+    # differ in the last bits of every element and the sum keeps little else)
+    for got, want, what in zip(res[1], res[0], names):
+        _close(got, want.cpu(), 3e-4 if "slope" in what else (5e-5 if what == "first bias gradient" else 2e-5), what)
