@@ -787,13 +787,11 @@ conv_border_sums_kernel(const float* __restrict__ dy, const unsigned char* __res
                 if (x == 0) s[4] += v;
                 if (x == W - 1) s[5] += v;
             }
-            if (Hp > 1 || true) {
-                v = at(Hp - 1, pc, y, x);
-                if (y == H - 1) {
-                    s[1] += v;
-                    if (x == 0) s[6] += v;
-                    if (x == W - 1) s[7] += v;
-                }
+            v = at(Hp - 1, pc, y, x);  // (Hp == 1: the same windows again -- each lands in row 0 or row 1 = H - 1, not both)
+            if (y == H - 1) {
+                s[1] += v;
+                if (x == 0) s[6] += v;
+                if (x == W - 1) s[7] += v;
             }
         }
         for (int pr = tid; pr < Hp; pr += 256) {
