@@ -549,14 +549,24 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                         for (int pc = 0; pc < 2; ++pc) {
                             const float y00 = o0[2 * pc] + bv, y01 = o0[2 * pc + 1] + bv;
                             const float y10 = o1[2 * pc] + bv, y11 = o1[2 * pc + 1] + bv;
-                            float best = act(y00), zb = y00;
-                            unsigned bi = 0;
-                            float v = act(y01);
-                            if (v > best) { best = v; bi = 1; zb = y01; }
-                            v = act(y10);
-                            if (v > best) { best = v; bi = 2; zb = y10; }
-                            v = act(y11);
-                            if (v > best) { best = v; bi = 3; zb = y11; }
+                            float best, zb;
+                            unsigned bi;
+                            if (a > 0.f) {
+                                // (uniform) a positive slope makes PReLU strictly increasing: the window's first maximum
+                                // of PReLU(y) is the first maximum of y -- two max instructions and an equality chain, one
+                                // PReLU, instead of four PReLUs and three compare / select rounds (conv1.hip does the same)
+                                zb = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+                                bi = y00 == zb ? 0u : (y01 == zb ? 1u : (y10 == zb ? 2u : 3u));
+                                best = act(zb);
+                            } else {
+                                best = act(y00); zb = y00; bi = 0;
+                                float v = act(y01);
+                                if (v > best) { best = v; bi = 1; zb = y01; }
+                                v = act(y10);
+                                if (v > best) { best = v; bi = 2; zb = y10; }
+                                v = act(y11);
+                                if (v > best) { best = v; bi = 3; zb = y11; }
+                            }
                             ub[pc] = best;
                             cb[pc] = bi | (zb <= 0.f ? 4u : 0u);
                         }
