@@ -460,8 +460,9 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const int ox = 4 * txe;
     // BST: the BatchNorm outputs at channel j's output positions, requested one channel ahead from clamped (always
     // valid) addresses; products are masked where they are used
-    f4u zn[BST ? 4 : 1];
-    unsigned cn[BST ? 4 : 1];
+    // (two channels ahead: behind one channel's 100 vector instructions a 2 us load does not hide)
+    f4u zn[BST ? 2 : 1][BST ? 4 : 1];
+    unsigned cn[BST ? 2 : 1][BST ? 4 : 1];
     auto load_xhat = [&](int j) {
         const int co = min(16 * wave + 4 * kq + j, g.Cout - 1);
         const int oxq = min(ox, g.W - 4);
@@ -469,8 +470,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         for (int r = 0; r < 4; ++r) {
             const int oyr = min(oy + r, g.H - 1);
             const size_t o = (((size_t)n * g.Cout + co) * g.H + oyr) * g.W + oxq;
-            zn[r] = *reinterpret_cast<const f4u*>(g.bn_in + o);
-            if (g.bn_codes) cn[r] = *reinterpret_cast<const u32b*>(g.bn_codes + o);
+            zn[j & 1][r] = *reinterpret_cast<const f4u*>(g.bn_in + o);
+            if (g.bn_codes) cn[j & 1][r] = *reinterpret_cast<const u32b*>(g.bn_codes + o);
         }
     };
     static_assert(!(BST && FST), "one statistics epilogue per launch");
@@ -485,8 +486,11 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const float bn_inva = (bn_act && bn_a != 0.f) ? 1.f / bn_a : 0.f;
     if constexpr (BST) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) zn[r] = f4u{0.f, 0.f, 0.f, 0.f};
-        if (have_x) load_xhat(0);
+        for (int r = 0; r < 4; ++r) zn[0][r] = zn[1][r] = f4u{0.f, 0.f, 0.f, 0.f};
+        if (have_x) {
+            load_xhat(0);
+            load_xhat(1);
+        }
     }
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
@@ -517,10 +521,10 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         if constexpr (BST) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                zq[r] = zn[r];
-                cq[r] = cn[r];
+                zq[r] = zn[j & 1][r];
+                cq[r] = cn[j & 1][r];
             }
-            if (j + 1 < 4 && have_x) load_xhat(j + 1);
+            if (j + 2 < 4 && have_x) load_xhat(j + 2);
             sg[j] = sgv[j] = 0.f;
         }
         if constexpr (FST) sg[j] = sgv[j] = 0.f;
