@@ -184,7 +184,8 @@ def float_array(vals):
 
 
 KERNEL_CLASSES = {"wpt": 0, "conv_igemm": 1, "conv_wgrad": 2, "stft": 3, "conv_direct": 4,
-                  "conv_winograd": 5, "conv_wgrad_1x1": 6, "lcnn_bf16": 7}
+                  "conv_winograd": 5, "conv_wgrad_1x1": 6, "lcnn_bf16": 7, "conv_first": 8, "batchnorm": 9,
+                  "elementwise": 10, "conv1x1": 11}
 
 
 def timing_enable(on: bool) -> None:

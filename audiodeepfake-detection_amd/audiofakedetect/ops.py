@@ -339,8 +339,10 @@ def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, f
 
 def _conv2d_backward(x, w, b, has_bias, geom, crop, dy, need_dx, need_dw, need_db, bn_link=None, dy_sums=None,
                      fold=None):
-    """Backward-data on the current stream; backward-weight on the second stream, added straight into
-    the FusedAdam gradient arena, when the parameters live there (see `_Conv2d`).  `bn_link`: when x was the
+    """Backward-data and backward-weight, both issued on the CURRENT stream in program order (the second stream of
+    rounds 1-2 is gone, profiles/r03_stream_modes.json): the launches share the workspace `ws` and the statistics
+    buffers, and the fold / bnapply branches rely on backward-weight having finished before backward-data reads its
+    sums -- which same-stream ordering gives.  `bn_link`: when x was the
     output of a training-mode BatchNorm (which set "bn" there), the backward-data launch also produces that
     BatchNorm's backward sums -- of dx and of dx * x -- and leaves them in the dict."""
     lib = _lib()
@@ -683,6 +685,22 @@ def _dist_on(sync: bool) -> bool:
 
 
 _direct_rccl = False
+# collectives issued by the training step since the last `collective_counters(reset=True)`: the first run with more
+# than one GPU records what it exchanged (bench.py prints them per step on its line)
+_collectives = {"count": 0, "bytes": 0}
+
+
+def note_collective(t: torch.Tensor) -> None:
+    _collectives["count"] += 1
+    _collectives["bytes"] += t.numel() * t.element_size()
+
+
+def collective_counters(reset: bool = False) -> dict:
+    out = dict(_collectives)
+    if reset:
+        _collectives["count"] = 0
+        _collectives["bytes"] = 0
+    return out
 
 
 def enable_direct_rccl() -> bool:
@@ -700,13 +718,29 @@ def enable_direct_rccl() -> bool:
     import ctypes
     buf = ctypes.create_string_buffer(128)
     dev = torch.device("cuda", torch.cuda.current_device())
-    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    # byte 128 = rank 0's status: a failure to draw the id must not leave the other ranks waiting in the broadcast
+    uid = torch.zeros(129, dtype=torch.uint8, device=dev)
+    err = None
     if dist.get_rank() == 0:
-        _native.check(lib.afd_rccl_unique_id(buf), "afd_rccl_unique_id")
-        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+        rc = lib.afd_rccl_unique_id(buf)
+        if rc != 0:
+            err = lib.afd_last_error().decode(errors="replace")
+            uid[128] = 1
+        else:
+            uid[:128].copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
     dist.broadcast(uid, src=0)
-    raw = bytes(uid.cpu().tolist())
-    _native.check(lib.afd_rccl_init(ctypes.c_char_p(raw), dist.get_rank(), dist.get_world_size()), "afd_rccl_init")
+    host = uid.cpu().tolist()
+    if host[128]:
+        raise RuntimeError(f"direct RCCL: rank 0 could not draw a unique id ({err or 'see rank 0'})")
+    rc = lib.afd_rccl_init(ctypes.c_char_p(bytes(host[:128])), dist.get_rank(), dist.get_world_size())
+    # every rank learns whether every rank's communicator came up, so that all raise (or all proceed) together
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if rc == 0:
+            lib.afd_rccl_destroy()
+        raise RuntimeError("direct RCCL: ncclCommInitRank failed on at least one rank"
+                           + (f" (this rank: {lib.afd_last_error().decode(errors='replace')})" if rc != 0 else ""))
     _direct_rccl = True
     return True
 
@@ -719,9 +753,15 @@ def disable_direct_rccl() -> None:
 
 
 def all_reduce_sum(t: torch.Tensor) -> None:
-    """In-place sum of `t` over the ranks: ncclAllReduce on the current stream when the direct communicator is up and
-    the tensor qualifies (contiguous float32 / float64 on the GPU), `dist.all_reduce` otherwise."""
-    if _direct_rccl and t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64):
+    """In-place sum of `t` over the ranks: ncclAllReduce on the current stream when the direct communicator is up
+    (contiguous float32 / float64 GPU tensors only -- anything else raises), `dist.all_reduce` otherwise."""
+    note_collective(t)
+    if _direct_rccl:
+        # exactly one communicator carries the in-step collectives: RCCL orders launches within a communicator, not
+        # across two of them on one device, so a tensor the direct path cannot take is an error, not a detour via c10d
+        if not (t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)):
+            raise RuntimeError(f"direct RCCL: all_reduce_sum takes contiguous float32 / float64 GPU tensors, got "
+                               f"{t.dtype} on {t.device} (contiguous: {t.is_contiguous()})")
         _native.check(_native.load().afd_rccl_all_reduce_sum(_native.ptr(t), t.numel(), 1 if t.dtype == torch.float64 else 0,
                                                              _native.stream_ptr()), "afd_rccl_all_reduce_sum")
     else:

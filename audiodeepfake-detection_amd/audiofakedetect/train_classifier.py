@@ -139,6 +139,7 @@ def start_gradient_allreduce(optimizer) -> None:
             ops.all_reduce_sum(optimizer.flat_grad)
             optimizer._pending_allreduce = _Done()
         else:
+            ops.note_collective(optimizer.flat_grad)
             optimizer._pending_allreduce = dist.all_reduce(optimizer.flat_grad, async_op=True)
 
     ops.at_end_of_backward(fire)
@@ -619,20 +620,27 @@ def main() -> None:
         model_name = model.get_name() if args.model == "modules" and hasattr(model, "get_name") else "customModel"
         trainer = Trainer(snap, args, normalize, transforms, test_loader, model, train_loader,
                           val_loader, cross_val, cross_test, optimizer, loss_fun, make_writer(args, model_name))
-        if args.only_testing:
-            # evaluate an existing snapshot on the cross-source test set (reference :1313-1316)
-            trainer._check_model_init()
-            trainer.load_snapshot(trainer.snapshot_path)
-            trainer.testing(only_unknown=cross_test is not None)
-        elif args.only_ig:
-            # attribution of an existing snapshot (reference :1317-1323)
-            trainer._check_model_init()
-            trainer.load_snapshot(trainer.snapshot_path)
-            tag = (f"{args.transform}_{args.sample_rate}_{args.seconds}_{args.seed}_"
-                   f"{(args.only_use or ['all'])[-1]}_{args.wavelet}_{args.power}_{loss_less_flag(args)}")
-            trainer.integrated_gradients(tag)
-        else:
-            trainer.train(args.epochs)
+        try:
+            if args.only_testing:
+                # evaluate an existing snapshot on the cross-source test set (reference :1313-1316)
+                trainer._check_model_init()
+                trainer.load_snapshot(trainer.snapshot_path)
+                trainer.testing(only_unknown=cross_test is not None)
+            elif args.only_ig:
+                # attribution of an existing snapshot (reference :1317-1323)
+                trainer._check_model_init()
+                trainer.load_snapshot(trainer.snapshot_path)
+                tag = (f"{args.transform}_{args.sample_rate}_{args.seconds}_{args.seed}_"
+                       f"{(args.only_use or ['all'])[-1]}_{args.wavelet}_{args.power}_{loss_less_flag(args)}")
+                trainer.integrated_gradients(tag)
+            else:
+                trainer.train(args.epochs)
+        finally:
+            # the reference closes its writer at the end of main (:1364); here one writer per experiment, closed with
+            # it: the last scalars (test / cross-test accuracy and EER) sit in the writer's queue until then
+            if trainer.writer is not None:
+                trainer.writer.close()
+                trainer.writer = None
         exp_results.setdefault(args.seed, []).append(trainer.test_results)
         if is_lead(args):
             last = trainer.loss_list[-1][2] if trainer.loss_list else float("nan")
@@ -647,6 +655,7 @@ def main() -> None:
                 print(f"results seed {seed}: mean {np.round(arr.mean(0), 4).tolist()} std {np.round(arr.std(0), 4).tolist()} "
                       f"over {arr.shape[0]} run(s) [acc, eer, cross acc, cross eer]")
     if args.ddp:
+        ops.disable_direct_rccl()  # the library's own communicator (AFD_RCCL_DIRECT) goes before the process group
         dist.destroy_process_group()
 
 

@@ -45,6 +45,11 @@ struct ScopedTiming {
     }
 };
 
+// launches bound by HBM or by the vector ALU (no matrix work): work = bytes = every tensor of the launch once
+struct ScopedBytes : ScopedTiming {
+    ScopedBytes(int id, double b, hipStream_t st) : ScopedTiming(id, b, st) { bytes(b); }
+};
+
 // wpt4.hip: levels 9..14 of the level-14 packet transform in lattice form (1 = not its case);
 // wpt4_available: the taps are an orthogonal bank with a usable lattice (cached per tap table)
 bool wpt4_available(const float* dec_lo, const float* dec_hi, int L);

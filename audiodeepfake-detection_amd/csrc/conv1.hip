@@ -291,6 +291,10 @@ extern "C" int afd_conv1_pool_forward(const float* x, const float* w, const floa
     const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
     if (N < 1 || Cout < 1 || Hp < 1 || Wp < 1 || pad < 0) return afd::fail(AFD_ERR_ARG, "conv1 fwd: bad geometry");
     if (Hp > 65535 || N > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 fwd: grid too large");
+    // bytes: the one-channel image in, pooled values + argmax codes out
+    const double fwd_bytes = (double)N * (4.0 * H * W + 5.0 * Cout * Hp * Wp);
+    afd::ScopedTiming timing(AFD_K_CONV_FIRST, fwd_bytes, AFD_STREAM);
+    timing.bytes(fwd_bytes);
     hipLaunchKernelGGL(conv1_pool_fwd_kernel, dim3((Wp + kT * kFP - 1) / (kT * kFP), Hp, N), dim3(kT), 0, AFD_STREAM,
                        x, w, bias, slope, u, idx, H, W, Cout, pad, Hp, Wp);
     return afd::check_launch("conv1_pool_fwd_kernel");
@@ -321,6 +325,11 @@ extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, c
     if (!ws || ws_bytes < (size_t)S * CG * kCG * 11 * sizeof(float))
         return afd::fail(AFD_ERR_WORKSPACE, "conv1 bwd: workspace too small");
     float* partial = static_cast<float*>(ws);
+    // bytes: the image, the pooled gradient, the pooled values and the codes in (the affine form's residual IS the
+    // pooled value tensor it reads anyway); nothing but the small gradient tensors out
+    const double bwd_bytes = (double)N * (4.0 * H * W + 9.0 * Cout * Hp * Wp);
+    afd::ScopedTiming timing(AFD_K_CONV_FIRST, bwd_bytes, AFD_STREAM);
+    timing.bytes(bwd_bytes);
     hipLaunchKernelGGL(conv1_pool_bwd_kernel, dim3(CG, S), dim3(kT), 0, AFD_STREAM, x, du, idx, u, slope,
                        partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles, alpha, beta);
     const int total = CG * kCG * 11;

@@ -531,7 +531,7 @@ int conv1x1_forward(const float* x, const float* w, const float* bias, float* y,
                     int Cout, long HW, hipStream_t s) {
     G1 g{};
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.HW = (int)HW; g.trans = 0;
-    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    afd::ScopedTiming timing(AFD_K_CONV1X1, 2.0 * N * Cout * (double)HW * Cin, s);
     timing.issued(2.0 * N * pad32(Cout) * (double)HW * Cin);
     timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
     return run_gemm(g, x, w, bias, y, s);
@@ -548,7 +548,7 @@ int conv1x1_forward_stats(const float* x, const float* w, const float* bias, con
                           hipStream_t s) {
     G1 g{};
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.HW = (int)HW; g.trans = 0;
-    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    afd::ScopedTiming timing(AFD_K_CONV1X1, 2.0 * N * Cout * (double)HW * Cin, s);
     timing.issued(2.0 * N * pad32(Cout) * (double)HW * Cin);
     timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
     float* part = static_cast<float*>(ws);
@@ -565,7 +565,7 @@ int conv1x1_backward_data(const float* dy, const float* w, float* dx, int N, int
                           long HW, hipStream_t s) {
     G1 g{};
     g.N = N; g.Cin = Cout; g.Cout = Cin; g.HW = (int)HW; g.trans = 1;
-    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    afd::ScopedTiming timing(AFD_K_CONV1X1, 2.0 * N * Cout * (double)HW * Cin, s);
     timing.issued(2.0 * N * pad32(Cin) * (double)HW * Cout);
     timing.bytes(4.0 * N * (double)HW * (Cin + Cout));
     return run_gemm(g, dy, w, nullptr, dx, s);
@@ -577,7 +577,7 @@ int conv1x1_backward_data_affine(const float* dy, const float* w, const float* r
                                  hipStream_t s) {
     G1 g{};
     g.N = N; g.Cin = Cout; g.Cout = Cin; g.HW = (int)HW; g.trans = 1;
-    afd::ScopedTiming timing(AFD_K_CONV_IGEMM, 2.0 * N * Cout * (double)HW * Cin, s);
+    afd::ScopedTiming timing(AFD_K_CONV1X1, 2.0 * N * Cout * (double)HW * Cin, s);
     timing.issued(2.0 * N * pad32(Cin) * (double)HW * Cout);
     timing.bytes(4.0 * N * (double)HW * (2.0 * Cin + Cout));
     return run_gemm(g, dy, w, beta, dx, s, res, alpha);

@@ -810,6 +810,7 @@ extern "C" int afd_moments_accumulate(const float* x, size_t n, double* acc, afd
     size_t blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 4.0 * (double)n, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(moments_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, acc);
     return afd::check_launch("moments_kernel");
 }
@@ -817,6 +818,7 @@ extern "C" int afd_moments_accumulate(const float* x, size_t n, double* acc, afd
 extern "C" int afd_normalize_forward(const float* x, float* y, size_t n, float mean, float std,
                                      afd_stream_t stream) {
     if (!x || !y || std == 0.f) return afd::fail(AFD_ERR_ARG, "normalize: bad argument");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)n, AFD_STREAM);
     hipLaunchKernelGGL(normalize_kernel, dim3(grid1d(n)), dim3(kT), 0, AFD_STREAM, x, y, n, mean, std);
     return afd::check_launch("normalize_kernel");
 }
@@ -833,6 +835,7 @@ extern "C" int afd_normalize_channels_forward(const float* x, float* y, int B, i
     }
     size_t gx = (plane + kT - 1) / kT;
     if (gx > 1024) gx = 1024;
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)B * C * (double)plane, AFD_STREAM);
     hipLaunchKernelGGL(normalize_channels_kernel, dim3((unsigned)gx, (unsigned)(B * C)), dim3(kT), 0, AFD_STREAM, x, y,
                        plane, C, st);
     return afd::check_launch("normalize_channels_kernel");
@@ -842,6 +845,7 @@ extern "C" int afd_transpose_last2(const float* x, float* y, int planes, int R, 
                                    afd_stream_t stream) {
     if (!x || !y || planes < 1 || R < 1 || C < 1) return afd::fail(AFD_ERR_ARG, "transpose: bad argument");
     if (planes > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "transpose: too many planes");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)planes * R * C, AFD_STREAM);
     hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, planes), dim3(kT), 0,
                        AFD_STREAM, x, y, R, C);
     return afd::check_launch("transpose_kernel");
@@ -850,6 +854,7 @@ extern "C" int afd_transpose_last2(const float* x, float* y, int planes, int R, 
 extern "C" int afd_prelu_dropout_forward(const float* z, const float* slope, float* y, size_t n,
                                          float p, uint64_t seed, afd_stream_t stream) {
     if (!z || !slope || !y || p < 0.f || p >= 1.f) return afd::fail(AFD_ERR_ARG, "prelu fwd: bad argument");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)n, AFD_STREAM);
     hipLaunchKernelGGL(prelu_dropout_fwd_kernel, dim3(grid1d(n)), dim3(kT), 0, AFD_STREAM, z, slope,
                        y, n, p, (unsigned long long)seed);
     return afd::check_launch("prelu_dropout_fwd_kernel");
@@ -859,6 +864,7 @@ extern "C" int afd_prelu_dropout_backward(const float* z, const float* slope, co
                                           float* dz, float* dslope, size_t n, float p,
                                           uint64_t seed, afd_stream_t stream) {
     if (!z || !slope || !dy || !dz || !dslope) return afd::fail(AFD_ERR_ARG, "prelu bwd: null pointer");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 12.0 * (double)n, AFD_STREAM);
     hipLaunchKernelGGL(prelu_dropout_bwd_kernel, dim3(grid1d(n, 1024)), dim3(kT), 0, AFD_STREAM, z,
                        slope, dy, dz, dslope, n, p, (unsigned long long)seed);
     return afd::check_launch("prelu_dropout_bwd_kernel");
@@ -869,6 +875,7 @@ extern "C" int afd_prelu_pool_forward(const float* z, const float* slope, float*
     if (!z || !u || !idx || NC < 1 || H < 2 || W < 2) return afd::fail(AFD_ERR_ARG, "pool fwd: bad argument");
     const int Hp = H / 2, Wp = W / 2;
     if ((long)Hp * Wp >= (1L << 23)) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: plane too large");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, (double)NC * (4.0 * H * W + 5.0 * Hp * Wp), AFD_STREAM);
     const unsigned gx = grid1d((size_t)Hp * Wp, 64);
     // float2 rows need 8-byte alignment: even W, even plane size, 8-byte aligned base
     const bool vec = true;  // dwordx2 loads need 4-byte alignment only
@@ -897,6 +904,7 @@ extern "C" int afd_prelu_pool_backward_compact(const float* u, const float* slop
     if (!u || !idx || !du || !gg || (slope && !dslope)) return afd::fail(AFD_ERR_ARG, "pool bwd (compact): null pointer");
     if (coef && (C < 1 || NC % C != 0)) return afd::fail(AFD_ERR_ARG, "pool bwd (compact): planes are not a multiple of the channels");
     if (NC < 1 || Hp < 1 || Wp < 1 || (long)Hp * Wp >= (1L << 30)) return afd::fail(AFD_ERR_ARG, "pool bwd (compact): bad geometry");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 13.0 * (double)NC * Hp * Wp, AFD_STREAM);
     const int HWp = Hp * Wp;
     const int chunks = (HWp + kT * 4 - 1) / (kT * 4);
     const long items = (long)NC * chunks;
@@ -924,6 +932,7 @@ extern "C" int afd_prelu_pool_backward_affine(const float* u, const float* slope
     if (coef && (C < 1 || NC % C != 0)) return afd::fail(AFD_ERR_ARG, "pool bwd: planes are not a multiple of the channels");
     const int Hp = H / 2, Wp = W / 2;
     if ((long)Hp * Wp >= (1L << 23)) return afd::fail(AFD_ERR_UNSUPPORTED, "pool: plane too large");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, (double)NC * (9.0 * Hp * Wp + 4.0 * H * W), AFD_STREAM);
     const unsigned gx = grid1d(((size_t)Hp * Wp + 3) / 4, 16);
     const bool vec = true;  // dwordx2 stores need 4-byte alignment only
     {
@@ -977,6 +986,7 @@ extern "C" int afd_bn_finalize(const double* sums, int C, double count, float ep
                                long long* nbt, double* count_out, afd_stream_t stream) {
     if (!sums || !mean || !invstd || C < 1) return afd::fail(AFD_ERR_ARG, "bn finalize: bad argument");
     if ((running_mean == nullptr) != (running_var == nullptr)) return afd::fail(AFD_ERR_ARG, "bn finalize: running stats");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 40.0 * C, AFD_STREAM);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, AFD_STREAM, sums, C, count, eps,
                        momentum, mean, invstd, running_mean, running_var, nbt, count_out);
     return afd::check_launch("bn_finalize_kernel");
@@ -986,6 +996,7 @@ extern "C" int afd_bn_backward_means(const double* sums, int C, double count, co
                                      float* mdy, float* mdyx, afd_stream_t stream) {
     if (!sums || !mdy || !mdyx || C < 1 || (count < 0.0 && !count_dev))
         return afd::fail(AFD_ERR_ARG, "bn backward means: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 24.0 * C, AFD_STREAM);
     hipLaunchKernelGGL(bn_bwd_means_kernel, dim3((C + 255) / 256), dim3(256), 0, AFD_STREAM, sums, C, count,
                        count_dev, mdy, mdyx);
     return afd::check_launch("bn_bwd_means_kernel");
@@ -1068,6 +1079,7 @@ bn_backward_coef_kernel(const float* __restrict__ mean, const float* __restrict_
 extern "C" int afd_bn_fold_forward(const float* w, const float* b, const float* mean, const float* invstd,
                                    float* wf, float* bf, int C, int Cin, afd_stream_t stream) {
     if (!w || !mean || !invstd || !wf || !bf || C < 1 || Cin < 1) return afd::fail(AFD_ERR_ARG, "bn fold: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 8.0 * C * Cin, AFD_STREAM);
     hipLaunchKernelGGL(bn_fold_forward_kernel, dim3(C), dim3(64), 0, AFD_STREAM, w, b, mean, invstd, wf, bf, Cin);
     return afd::check_launch("bn_fold_forward_kernel");
 }
@@ -1077,6 +1089,7 @@ extern "C" int afd_bn_fold_backward_weights(const float* G, const float* db, con
                                             afd_stream_t stream) {
     if (!G || !db || !w || !mean || !invstd || !dw || !sums || C < 1 || Cin < 1)
         return afd::fail(AFD_ERR_ARG, "bn fold backward: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 12.0 * C * Cin, AFD_STREAM);
     hipLaunchKernelGGL(bn_fold_backward_weights_kernel, dim3((Cin + 127) / 128), dim3(128), 0, AFD_STREAM, G, db, w,
                        mean, invstd, dw, sums, C, Cin);
     return afd::check_launch("bn_fold_backward_weights_kernel");
@@ -1087,6 +1100,7 @@ extern "C" int afd_bn_fold_backward_affine(const double* sums, double count, con
                                            int Cin, afd_stream_t stream) {
     if (!sums || !mean || !invstd || !alpha || !beta || Cin < 1 || (count < 0.0 && !count_dev))
         return afd::fail(AFD_ERR_ARG, "bn fold backward affine: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 32.0 * Cin, AFD_STREAM);
     hipLaunchKernelGGL(bn_fold_backward_affine_kernel, dim3((Cin + 127) / 128), dim3(128), 0, AFD_STREAM, sums, count,
                        count_dev, mean, invstd, alpha, beta, Cin);
     return afd::check_launch("bn_fold_backward_affine_kernel");
@@ -1095,6 +1109,7 @@ extern "C" int afd_bn_fold_backward_affine(const double* sums, double count, con
 extern "C" int afd_bn_backward_coef(const float* mean, const float* invstd, const float* mdy, const float* mdyx,
                                     float* coef, int C, afd_stream_t stream) {
     if (!mean || !invstd || !mdy || !mdyx || !coef || C < 1) return afd::fail(AFD_ERR_ARG, "bn backward coef: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 32.0 * C, AFD_STREAM);
     hipLaunchKernelGGL(bn_backward_coef_kernel, dim3((C + 127) / 128), dim3(128), 0, AFD_STREAM, mean, invstd, mdy,
                        mdyx, coef, C);
     return afd::check_launch("bn_backward_coef_kernel");
@@ -1112,6 +1127,7 @@ static int plane_splits(int C, int gy, int HW) {
 extern "C" int afd_bn_stats(const float* x, const float* slope, double* sums, int N, int C, int HW,
                             afd_stream_t stream) {
     if (!x || !sums || N < 1 || C < 1 || HW < 1) return afd::fail(AFD_ERR_ARG, "bn stats: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 4.0 * (double)N * C * HW, AFD_STREAM);
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, AFD_STREAM);
     if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "bn stats: memset: %s", hipGetErrorString(e));
     int gy = N;
@@ -1126,6 +1142,7 @@ extern "C" int afd_bn_apply_forward(const float* x, const float* slope, const fl
                                     float* y, int N, int C, int HW, afd_stream_t stream) {
     if (!x || !mean || !invstd || !y) return afd::fail(AFD_ERR_ARG, "bn apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn apply: N*C > 65535");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 8.0 * (double)N * C * HW, AFD_STREAM);
     unsigned bx = (unsigned)(HW / 16384);  // at least 16k elements per workgroup
     if (bx < 1) bx = 1;
     if (bx > 16) bx = 16;
@@ -1138,6 +1155,7 @@ extern "C" int afd_bn_backward_stats(const float* x, const float* slope, const f
                                      const float* mean, const float* invstd, double* sums, int N,
                                      int C, int HW, afd_stream_t stream) {
     if (!x || !dy || !mean || !invstd || !sums) return afd::fail(AFD_ERR_ARG, "bn bwd stats: null pointer");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 8.0 * (double)N * C * HW, AFD_STREAM);
     hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, AFD_STREAM);
     if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "bn bwd stats: memset: %s", hipGetErrorString(e));
     int gy = N;
@@ -1163,6 +1181,7 @@ extern "C" int afd_bn_backward_apply_sums(const float* x, const float* slope, co
     if (!x || !dy || !mean || !invstd || !mean_dy || !mean_dy_xhat || !dx || (slope && !dslope))
         return afd::fail(AFD_ERR_ARG, "bn bwd apply: null pointer");
     if ((long)N * C > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "bn bwd apply: N*C > 65535");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 12.0 * (double)N * C * HW, AFD_STREAM);
     // at least 16k elements per workgroup (each ends in one float atomic on dslope; short
     // workgroups also pay the block reduction per few hundred elements)
     unsigned bx = (unsigned)(HW / 16384);
@@ -1177,6 +1196,7 @@ extern "C" int afd_dropout_permute(const float* x, float* y, int B, int C, int H
                                    uint64_t seed, int inverse, afd_stream_t stream) {
     if (!x || !y || B < 1 || p < 0.f || p >= 1.f) return afd::fail(AFD_ERR_ARG, "dropout_permute: bad argument");
     if (B > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "dropout_permute: batch > 65535");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)B * C * H * W, AFD_STREAM);
     if ((W & 3) == 0 && (size_t)C * H * W < 0x7fffffffULL && ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0) {
         hipLaunchKernelGGL(dropout_permute4_kernel, dim3(grid1d((size_t)C * H * (W / 4), 64), B), dim3(kT), 0, AFD_STREAM, x, y,
                            C, H, W / 4, p, (unsigned long long)seed, inverse);
@@ -1191,6 +1211,7 @@ extern "C" int afd_linear_mean_forward(const float* x, const float* w, const flo
                                        int B, int TD, int F, int O, afd_stream_t stream) {
     if (!x || !w || !bias || !y) return afd::fail(AFD_ERR_ARG, "linear fwd: null pointer");
     if (O != 2) return afd::fail(AFD_ERR_UNSUPPORTED, "linear: only 2 classes (reference models.py:297)");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 4.0 * ((double)B * TD * F + (double)F * O), AFD_STREAM);
     hipLaunchKernelGGL(linear_mean_fwd_kernel<2>, dim3(B), dim3(kLinT), 0, AFD_STREAM, x, w, bias, y, TD, F);
     return afd::check_launch("linear_mean_fwd_kernel");
 }
@@ -1201,6 +1222,7 @@ extern "C" int afd_linear_mean_backward(const float* x, const float* w, const fl
     if (!x || !w || !dy || !dx || !dw || !db) return afd::fail(AFD_ERR_ARG, "linear bwd: null pointer");
     if (O != 2) return afd::fail(AFD_ERR_UNSUPPORTED, "linear: only 2 classes");
     if (B > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "linear: batch > 65535");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)B * TD * F, AFD_STREAM);
     hipLaunchKernelGGL(linear_mean_bwd_x_kernel<2>, dim3(grid1d(F, 64), B), dim3(kT), 0, AFD_STREAM,
                        dy, w, dx, TD, F);
     hipLaunchKernelGGL(linear_mean_bwd_w_kernel<2>, dim3((F + 63) / 64), dim3(kT), 0, AFD_STREAM, x,
@@ -1211,6 +1233,7 @@ extern "C" int afd_linear_mean_backward(const float* x, const float* w, const fl
 extern "C" int afd_cross_entropy(const float* logits, const int64_t* labels, float* loss,
                                  float* dlogits, float* correct, int B, int O, afd_stream_t stream) {
     if (!logits || !labels || !loss || B < 1 || O < 2) return afd::fail(AFD_ERR_ARG, "cross entropy: bad argument");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 16.0 * B * O, AFD_STREAM);
     hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(kT), 0, AFD_STREAM, logits,
                        reinterpret_cast<const long long*>(labels), loss, dlogits, correct, B, O);
     return afd::check_launch("ce_kernel");
@@ -1238,6 +1261,9 @@ multi_gather_kernel(const GatherTable t, float* __restrict__ dst) {
 extern "C" int afd_multi_gather(const float* const* srcs, const long* offsets, const long* counts, int n, float* dst,
                                 afd_stream_t stream) {
     if (n < 0 || (n > 0 && (!srcs || !offsets || !counts || !dst))) return afd::fail(AFD_ERR_ARG, "multi gather: bad argument");
+    double total = 0.0;
+    for (int k = 0; k < n; ++k) total += counts[k] > 0 ? (double)counts[k] : 0.0;
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * total, AFD_STREAM);
     for (int base = 0; base < n; base += kGatherMax) {
         GatherTable t{};
         const int m = n - base < kGatherMax ? n - base : kGatherMax;
@@ -1261,6 +1287,7 @@ extern "C" int afd_adam_step(float* params, const float* grads, float* m, float*
                              float beta1, float beta2, float eps, float weight_decay, int step,
                              float grad_scale, afd_stream_t stream) {
     if (!params || !grads || !m || !v || step < 1) return afd::fail(AFD_ERR_ARG, "adam: bad argument");
+    afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 28.0 * (double)n, AFD_STREAM);
     const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bc2 = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(kT), 0, AFD_STREAM, params, grads, m, v, n,

@@ -543,11 +543,11 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     const int MT = (Cout + 31) / 32;
     float* U = static_cast<float*>(ws);
     const int total = g.nchunks * 16 * MT * 4 * 64;
+    afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     hipLaunchKernelGGL(wino_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, MT,
                        g.nchunks, dgrad);
     int rc = afd::check_launch("wino_weights_kernel");
     if (rc) return rc;
-    afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols / (u ? 4.0 : 1.0)));
     const bool wide = !getenv("AFD_WINO_NT1");
     switch (MT) {
@@ -606,6 +606,7 @@ conv_weight_dot_kernel(const float* __restrict__ w, const float* __restrict__ dw
 extern "C" int afd_conv_weight_dot(const float* w, const float* dw, int Cout, int Cin, int KK, double* out,
                                    afd_stream_t stream) {
     if (!w || !dw || !out || Cout < 1 || Cin < 1 || KK < 1) return afd::fail(AFD_ERR_ARG, "conv weight dot: bad argument");
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, 8.0 * Cout * Cin * KK, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(conv_weight_dot_kernel, dim3(Cin), dim3(256), 0, static_cast<hipStream_t>(stream), w, dw, Cout, Cin,
                        KK, out);
     return afd::check_launch("conv_weight_dot_kernel");
@@ -642,6 +643,7 @@ extern "C" int afd_conv3x3_backward_data_bnstats(const float* dy, const float* w
                                  nullptr, xhat, part);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    afd::ScopedBytes red_timing(AFD_K_BATCHNORM, 4.0 * (double)rows * slots, s);
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
     hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cin,
                        sums);
@@ -681,6 +683,7 @@ extern "C" int afd_conv3x3_backward_data_bnstats_pooled(const float* gg, const u
                              nullptr, 0, codes);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    afd::ScopedBytes red_timing(AFD_K_BATCHNORM, 4.0 * (double)rows * slots, s);
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
     hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cin,
                        sums);
@@ -736,6 +739,7 @@ static int forward_stats_impl(const float* x, const float* w, const float* bias,
                              u, idx, 1, nullptr, in_aff, in_slope);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    afd::ScopedBytes red_timing(AFD_K_BATCHNORM, 4.0 * (double)rows * slots, s);
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
     hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cout,
                        sums);
@@ -889,6 +893,8 @@ extern "C" int afd_conv3x3_input_grad_sums(const float* dy, const uint8_t* codes
         dy_cols = 2 * (W / 2);
     }
     const int rows = dy_rows < H ? dy_rows : H, cols = dy_cols < W ? dy_cols : W;
+    // two rows and two columns of every dy plane (the pooled form: of the pooled plane and its codes)
+    afd::ScopedBytes timing(AFD_K_BATCHNORM, (codes ? 5.0 : 4.0) * (double)N * Cout * (double)(codes ? (W / 2 + H / 2) : 2 * (W + H)), s);
     hipLaunchKernelGGL(conv_border_sums_kernel, dim3(Cout, N), dim3(256), 0, s, dy, codes, Cout, H, W, rows, cols, bs);
     hipLaunchKernelGGL(conv_input_grad_sums_kernel, dim3(Cin), dim3(256), 0, s, w, dy_sums, dbias, bs, Cout, Cin, sums);
     return afd::check_launch("conv3x3 input-gradient sums kernels");
@@ -920,6 +926,7 @@ extern "C" int afd_conv3x3_backward_data_bnapply(const float* dy, const uint8_t*
                              0, codes, nullptr, nullptr, bn_tab, bn_slope, bn_codes);
     if (rc) return rc;
     const int blocks = rows < kStatBlocks ? (int)rows : kStatBlocks;
+    afd::ScopedBytes red_timing(AFD_K_BATCHNORM, 4.0 * (double)rows * slots, s);
     hipLaunchKernelGGL(wino_bnstats_reduce1_kernel, dim3(blocks), dim3(256), 0, s, part, (int)rows, slots, part2);
     hipLaunchKernelGGL(wino_bnstats_reduce2_kernel, dim3((2 * co_pad + 7) / 8), dim3(256), 0, s, part2, blocks, co_pad, Cin,
                        sums);

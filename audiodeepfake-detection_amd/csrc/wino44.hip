@@ -703,9 +703,14 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     const long rows = (long)g.N * g.tilesY;
     // 36 GEMMs [16 CG x Cin] x [Cin x 16 tiles] per workgroup, every tile computed in full
-    // (30 of them in a tile row with at most three live output rows)
-    const int last_live = g.rows - 4 * (g.tilesY - 1);
-    const double pos_rows = (double)kPos * (g.tilesY - 1) + (last_live <= 3 ? 30.0 : (double)kPos);
+    // (30 of them in a tile row with at most three live output rows,
+    // and 6 in the tile row whose patches have one non-zero row: the kernel's own conditions, row by row)
+    double pos_rows = 0.0;
+    for (int ty = 0; ty < g.tilesY; ++ty) {
+        const bool row0_only = PIN && 4 * ty - 1 == 2 * g.Hp - 1;
+        const bool skip5 = g.rows - 4 * ty <= 3;
+        pos_rows += row0_only ? 6.0 : (skip5 ? 30.0 : (double)kPos);
+    }
     afd::timing_annotate(2.0 * pos_rows * (16.0 * CG) * ((double)kTiles * g.wgX) * (double)g.N * g.Cin, -1.0);
     // interior workgroup columns: every patch column inside the image (6 columns from 4 tx - 1)
     const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
@@ -814,12 +819,19 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     if (!x || !w || (!y && !u)) return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: null pointer");
     float* U = static_cast<float*>(ws);
     const int total = g.nchunks * kPos * CG * KS * 64;
+    afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     hipLaunchKernelGGL(wino44_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, CG,
                        g.nchunks, dgrad, KS);
     int rc = afd::check_launch("wino44_weights_kernel");
     if (rc) return rc;
-    afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
-    timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols));
+    {   // every tensor the launch touches, once: the pooled forms move 4 + 1 bytes per 2x2 window, the epilogues that
+        // read the BatchNorm's input (statistics with xhat, BatchNorm backward) add that tensor (and its pool codes)
+        const double px_in = (double)H * W, px_out = (double)g.rows * g.cols;
+        double b = pooled_codes ? 5.0 * Cin * (double)(H / 2) * (W / 2) : 4.0 * Cin * px_in;
+        b += u ? 5.0 * Cout * (double)(g.rows / 2) * (g.cols / 2) : 4.0 * Cout * px_out;
+        if (bn_in) b += (bn_tab && bn_codes ? 5.0 : 4.0) * Cout * px_out;
+        timing.bytes(b * N);
+    }
     if (u) {  // pooled forward: u / idx are written, y is not used
         if (CG == 6 && fwd_stats) return launch44<6, false, true, 2, true>(g, x, U, bias, y, s);
         if (fwd_stats) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv + pool: statistics for Cout %d", Cout);

@@ -463,7 +463,10 @@ bool wpt_lattice_coefficients(const float* dec_lo, const float* dec_hi, int L, d
     double worst = 0.0;
     for (int i = 0; i < R; ++i) worst = std::fabs(res[i]) > worst ? std::fabs(res[i]) : worst;
     if (fit_residual) *fit_residual = worst;
-    if (!(worst <= 1e-5)) return false;
+    // a few ulp of the float32 taps: real orthogonal tables fit to <= 2e-7 (tests/test_wpt_lattice.py); a bank that is
+    // only approximately orthogonal (learned / hand-edited taps) must run through the direct-form kernels with ITS taps,
+    // not through the nearest lattice -- six cascaded levels would turn a 1e-5 tap error into visible feature error
+    if (!(worst <= 1e-6)) return false;
     // scaled one-FMA-per-stage form: A = G a, B = G k b (tools/wpt_lattice.py::scaled_form)
     double G = 1.0, k = 1.0;
     for (int s = 0; s < K; ++s) {
@@ -473,7 +476,10 @@ bool wpt_lattice_coefficients(const float* dec_lo, const float* dec_hi, int L, d
         beta[s] = r.a[1][1] / (r.a[1][0] * k);
         G = G / r.a[0][0];
         k = r.a[0][0] / r.a[1][0];
-        if (!(std::fabs(alpha[s]) < 1e6) || !(std::fabs(beta[s]) < 1e6)) return false;
+        // conditioning of the float32 recursion: a stage computes A + alpha B, so |alpha| is the factor by which B's
+        // rounding error enters A (coif4's largest is 45, every other shipped table's below 10; the fuzz of
+        // tools/wpt_fuzz.py holds the 5e-6 bar with them); near-degenerate rotations go to the direct form
+        if (!(std::fabs(alpha[s]) < 1e3) || !(std::fabs(beta[s]) < 1e3)) return false;
     }
     scales[0] = 1.0 / G;
     scales[1] = 1.0 / (G * k);

@@ -51,6 +51,13 @@ int afd_version(void);
                                   work = direct-form flops, of which the kernel issues 16/36 as MFMAs */
 #define AFD_K_LCNN_BF16 7 /* bf16 matrix-core launches of the LCNN evaluation forward (convolutions, LSTM / Linear
                              projections): work = the layer's flops, issued = with row / k padding; peak = bf16 MFMA */
+#define AFD_K_CONV_FIRST 8  /* block 1 (Cin = 1): convolution + PReLU + 2x2 max-pool, forward and backward, on the
+                               vector ALU; work = bytes = every tensor of the launch once (HBM-bound class) */
+#define AFD_K_BATCHNORM 9   /* BatchNorm statistics / apply / backward passes and the small sum / fold kernels */
+#define AFD_K_ELEMENTWISE 10 /* pool, dropout, permute, Linear + mean, cross entropy, gather, Adam, normalise */
+#define AFD_K_CONV1X1 11    /* 1x1 convolutions forward / backward-data: GEMMs at 16 flop per byte, HBM-leaning;
+                               work = direct-form flops, issued = the same with tile padding, bytes = tensors once */
+#define AFD_K_COUNT 12
 int afd_timing_enable(int on);
 int afd_timing_collect(int id, double* total_ms, long long* count, double* total_work,
                        double* total_issued_flops, double* total_algorithmic_bytes);

@@ -58,6 +58,13 @@ def test_bench_line_has_the_contract_fields(workload):
         assert r["traffic"] and r["traffic"] > 0
         for name, c in d["classes"].items():
             assert c["hbm_bytes_per_step_pmc"] and c["hbm_bytes_per_step_pmc"] > 0, (name, c)
+            # tensors that do not fit the 256 MiB Infinity Cache cannot be moved with fewer HBM bytes than they hold:
+            # a class whose counter bytes fall below its algorithmic bytes is a calibration error (tools/pmc_json.py)
+            if c["algorithmic_bytes_per_step"] > 2 * 256 * 2 ** 20:
+                assert c["hbm_bytes_per_step_pmc"] >= 0.9 * c["algorithmic_bytes_per_step"], (name, c)
+    if workload == "coif4-l14":
+        # every launch of the library belongs to a timing class: the classes add up to the step
+        assert 0.97 <= d["classes_share_of_step"] <= 1.05, (d["classes_sum_ms_per_step"], d["ms_per_step"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert c["front_end_batch"] == 2 and c["step_batch"] == 1
@@ -76,7 +83,13 @@ def test_bench_line_has_the_contract_fields(workload):
         assert len(sec) == 5 and not any("error" in f for f in d["secondary"]), d["secondary"]
         for f in d["secondary"]:
             assert f["ms_per_step"] > 0 and 0.0 < f["frac"] <= 1.0 and f["dominant_class"], f
-        assert sec["STFT(n_fft 511, hop 220) + LCNN eval forward (bf16 matrix products)"]["dtype"] == "bf16"
+        lcnn = sec["STFT(n_fft 511, hop 220) + LCNN eval forward (bf16 matrix products)"]
+        assert lcnn["dtype"] == "bf16"
+        # configs[4]: accuracy / EER of the evaluation loop on the synthetic cross-generator labels, and the batch a
+        # GPU wants beside the protocol's 128
+        assert 0.0 <= lcnn["accuracy"] <= 1.0 and 0.0 <= lcnn["eer"] <= 1.0 and lcnn["eval_frames"] == 1024
+        assert set(lcnn["per_label_accuracy"]) == {"A_real", "B_melgan", "C_hifigan"}
+        assert lcnn["large_batch"]["batch"] == 1024 and lcnn["large_batch"]["ms_per_step"] > 0
     else:
         assert d["frontend_only"] is None and d["secondary"] is None
 
@@ -101,3 +114,5 @@ def test_bench_spawns_its_own_ranks():
     assert d["n_gpus"] == 1 and d["world"]["size"] == 1
     assert d["world"]["backend"] and d["world"]["rccl_version"]
     assert len(d["world"]["devices"]) == 1 and "cuda:0" in d["world"]["devices"][0]
+    # the line carries what the step exchanged (nothing with one rank; the first multi-GPU run records its own)
+    assert d["world"]["collectives"]["per_step"] == 0 and d["world"]["collectives"]["bytes_per_step"] == 0

@@ -216,3 +216,39 @@ def test_trainer_epoch_on_the_native_loader(tmp_path):
     trainer.train(1)
     assert trainer.step_total == len(train) and all(np.isfinite(l[2]) for l in trainer.loss_list)
     assert 0.0 <= trainer.test_results[0] <= 1.0
+
+
+def test_tensorboard_writer_is_closed_after_the_last_scalars(tmp_path, monkeypatch):
+    """`--tensorboard`: the writer of an experiment is closed when the experiment ends (reference
+    train_classifier.py:1364 closes it at the end of main), AFTER the test scalars were handed to it -- an open
+    SummaryWriter keeps its last events in a queue that the interpreter's exit does not flush."""
+    sys.path.insert(0, ROOT)
+    from audiofakedetect import train_classifier as tc
+
+    made = []
+
+    class Recorder:
+        def __init__(self):
+            self.rows, self.closed_after = [], None
+
+        def add_scalar(self, tag, v, step):
+            assert self.closed_after is None, f"scalar {tag} after close()"
+            self.rows.append(tag)
+
+        def close(self):
+            self.closed_after = len(self.rows)
+
+    def fake_writer(args, model_name):
+        made.append(Recorder())
+        return made[-1]
+
+    monkeypatch.setattr(tc, "make_writer", fake_writer)
+    monkeypatch.setattr(sys, "argv", ["train_classifier", "--log-dir", str(tmp_path), "--transform", "packets",
+                                      "--wavelet", "sym5", "--num-of-scales", "256", "--log-scale", "--model", "modules",
+                                      "--init-seeds", "0", "1", "--synthetic", "--tensorboard",
+                                      "--config", os.path.join(ROOT, "tests", "synthetic_config.py")])
+    tc.main()
+    assert len(made) == 2  # one writer per experiment (two seeds), none left open
+    for w in made:
+        assert w.closed_after is not None and w.closed_after == len(w.rows)
+        assert "loss/train" in w.rows and "accuracy/test" in w.rows and "eer/test" in w.rows

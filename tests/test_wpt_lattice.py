@@ -63,3 +63,16 @@ def test_a_bank_that_is_not_orthogonal_has_no_lattice():
     lo[3] += 0.05
     rc, *_ = _lattice(lo, hi)
     assert rc != 0
+
+
+def test_a_nearly_orthogonal_bank_is_not_run_through_the_nearest_lattice():
+    """A bank whose taps are off an orthogonal table by more than a few float32 ulp (a learned or hand-edited filter)
+    must keep ITS taps: the lattice is refused and `afd_wpt_forward` falls back to the direct-form kernels."""
+    lo = list(wavelets.Wavelet("sym5").dec_lo)
+    lo[3] += 1e-5  # fits a lattice to 3e-6 -- good enough to look right, wrong by 1e-5 per level
+    rc, *_, res = _lattice(lo, wpt_oracle.dec_hi_from_lo(lo))
+    assert rc != 0 and 1e-6 < res < 1e-5, (rc, res)
+    lo = list(wavelets.Wavelet("sym5").dec_lo)
+    lo[3] += 1e-7  # within the float32 rounding of the table itself
+    rc, *_, res = _lattice(lo, wpt_oracle.dec_hi_from_lo(lo))
+    assert rc == 0 and res <= 2e-7
