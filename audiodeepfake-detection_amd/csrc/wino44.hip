@@ -66,6 +66,7 @@ struct G4 {
     const float* in_aff;
     const float* in_slope;
     int noflip;  // development switch AFD_WINO44_NO_FLIP: see the kernel's wave roles
+    int xcd_map;  // XCD-aware workgroup order (AFD_WINO44_XCDM; 16 by default, 0 / 1 = plain row-major): see the kernel
     // BatchNorm backward in the epilogue (backward-data launches with the statistics epilogue; round 4): the result g is the
     // gradient of a training-mode BatchNorm(affine=False) output whose backward sums are known BEFORE the launch
     // (afd_conv3x3_input_grad_sums, afd_conv_weight_dot): bn_tab [C][4] = (mean, invstd, mean of g, mean of g * xhat),
@@ -198,12 +199,50 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         // two of them.  Workgroups 256 apart are the ones that meet on a CU (8 XCDs x 32 CUs, dispatched in order).
         if ((blockIdx.x >> 8) & 1) wave = (wave + 6) & 7;
     }
+    // Workgroup -> (image, tile row, workgroup column).  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each
+    // XCD has its own L2: in plain row-major order a workgroup's column neighbours -- which share the 128-byte lines its
+    // 264-byte row segments start and end in -- sit on other XCDs, and every shared line is fetched once per XCD (round 5:
+    // the read requests by size, profiles/r05_pmc_traffic_*, show the class moving 2.0 x its algorithmic bytes).
+    // xcd_map = m > 1: in every group of 8 m consecutive ids XCD x takes the m consecutive logical ids x m .. x m + m - 1,
+    // i.e. m neighbouring workgroup columns of one tile row.  Measured on the level-14 step (same box, alternating runs,
+    // tools/ab_env.py): row-major 20.26-20.41 ms for the class, m = 2 / 4 / 16 / 32 / 64: 20.21 / 20.18 / 20.08-20.15 /
+    // 20.12 / 20.29 -- the default is 16.  The order that also keeps the tile rows of a column block on one XCD (negative
+    // values: tile row fastest inside the group, or over a whole eighth of the grid) costs 1.5 ms at every group size:
+    // 21.7-22.0 ms -- the launch then reads four times as many image rows at once in windows a quarter as wide; what the
+    // memory side rewards is few, wide streams, not fewer bytes (the class draws 2.4 TB/s, far from the HBM's limit).
     int id = blockIdx.x;
-    const int wi = id % g.wxCount;
-    id /= g.wxCount;
+    int wi, ty, n;
+    if (g.xcd_map < 0) {
+        // as below, with the logical order running tile row fastest: an XCD's m ids are m / tilesY columns x every tile row
+        const int m = -g.xcd_map, grp = 8 * m;
+        const int base = id / grp * grp;
+        if (base + grp <= (int)gridDim.x) {
+            const int p = id - base;
+            id = base + (p & 7) * m + (p >> 3);
+        }
+        ty = id % g.tilesY;
+        id /= g.tilesY;
+        wi = id % g.wxCount;
+        n = id / g.wxCount;
+    } else if (g.xcd_map > 1) {
+        // groups of 8 m consecutive ids: XCD x takes the m consecutive logical ids x m .. x m + m - 1 of the group
+        const int m = g.xcd_map, grp = 8 * m;
+        const int base = id / grp * grp;
+        if (base + grp <= (int)gridDim.x) {
+            const int p = id - base;
+            id = base + (p & 7) * m + (p >> 3);
+        }
+        wi = id % g.wxCount;
+        id /= g.wxCount;
+        ty = id % g.tilesY;
+        n = id / g.tilesY;
+    } else {
+        wi = id % g.wxCount;
+        id /= g.wxCount;
+        ty = id % g.tilesY;
+        n = id / g.tilesY;
+    }
     const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
-    const int ty = id % g.tilesY;
-    const int n = id / g.tilesY;
     const int tx0 = wx * kTiles;
     const bool skip5 = g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
     // PIN: the dense gradient has 2 Hp live rows; a tile row whose patches start on the last of them (4 ty - 1 =
@@ -800,6 +839,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
     g.in_aff = in_aff; g.in_slope = in_slope;
     g.noflip = getenv("AFD_WINO44_NO_FLIP") != nullptr;
+    g.xcd_map = getenv("AFD_WINO44_XCDM") ? atoi(getenv("AFD_WINO44_XCDM")) : 16;
     g.bn_tab = bn_tab; g.bn_slope = bn_slope; g.bn_codes = bn_tab ? bn_codes : nullptr;
     if (bn_tab && (!dgrad || !bn_in || !stat_part || fwd_stats))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the BatchNorm backward epilogue belongs to backward-data launches "

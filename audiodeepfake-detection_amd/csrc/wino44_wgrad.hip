@@ -69,7 +69,8 @@ struct GW {
     int N, Cin, Cout, H, W;
     int rows, cols;             // valid region of dy (a crop of H x W)
     int tilesX, tilesY, groupsX;  // groupsX = k-step groups (4 tiles) per tile row
-    long units;                 // N * groupsX * tilesY k-steps, ordered (n, column group, tile row)
+    long units;                 // N * groupsX * tilesY k-steps, ordered (n, column super-group, tile row, member)
+    int gsh;                    // log2 of the column groups per super-group (see decode_unit)
     int S;                      // splits of the unit sequence
     long units_per_split;       // even
     int cig;                    // channel groups along Cin
@@ -153,11 +154,19 @@ struct Unit {
 __device__ __forceinline__ Unit decode_unit(long u, long end, const GW& g) {
     Unit r;
     r.live = u < end;
+    // Order of the k-steps: (image, column SUPER-group of 2^gsh neighbouring column groups, tile row, member).  The two
+    // k-steps of a round are neighbouring column groups of one tile row -- together they read 128 + 8 bytes of every
+    // patch row, whole cache lines, where a lone group reads 72 bytes out of a 128-byte line whose rest was fetched again
+    // tilesY k-steps later, after the L2 had dropped it (round 5: the read requests by size, profiles/r05_pmc_traffic_*,
+    // put the launch at 1.6-1.8 x its algorithmic bytes); the next round is the tile row below (two shared halo rows).
     const unsigned uu = r.live ? (unsigned)u : 0u;
-    const unsigned q = uu / (unsigned)g.tilesY;
-    r.ty = (int)(uu - q * (unsigned)g.tilesY);
-    const unsigned n = q / (unsigned)g.groupsX;
-    r.xg = (int)(q - n * (unsigned)g.groupsX);
+    const unsigned m = uu & ((1u << g.gsh) - 1u);
+    const unsigned v = uu >> g.gsh;
+    const unsigned q = v / (unsigned)g.tilesY;
+    r.ty = (int)(v - q * (unsigned)g.tilesY);
+    const unsigned sgx = (unsigned)g.groupsX >> g.gsh;
+    const unsigned n = q / sgx;
+    r.xg = (int)(((q - n * sgx) << g.gsh) + m);
     r.n = (int)n;
     return r;
 }
@@ -436,14 +445,12 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     const bool want_bias = g.partb != nullptr && (cg % g.cig) == 0;
     // A dy tile with at most three live rows (the last tile row of an image whose rows are not a multiple of 4: 6-row
     // images at level 14) has A dy A^T = 0 at the positions 30..35 (row 5 of A picks dy row 3): those six products of
-    // its k-step are skipped.  ty_first = tile row of the round's first k-step (uniform)
+    // its k-step are skipped (uniform: the tile rows of the round's two k-steps)
     const int ty_short = (g.rows & 3) ? g.tilesY - 1 : -1;
-    int ty_first = (int)((unsigned)u_begin % (unsigned)g.tilesY);
+    auto ty_of = [&](long u) { return (int)(((unsigned)u >> g.gsh) % (unsigned)g.tilesY); };  // scalar, as decode_unit
     load_x(u_begin);
     for (long u0 = u_begin; u0 < u_end; u0 += 2) {
-        const int ty_second = ty_first + 1 < g.tilesY ? ty_first + 1 : 0;
-        const bool short0 = ty_first == ty_short, short1 = ty_second == ty_short;
-        ty_first = ty_second + 1 < g.tilesY ? ty_second + 1 : 0;
+        const bool short0 = ty_of(u0) == ty_short, short1 = ty_of(u0 + 1) == ty_short;
         // the dy tile (four 16-byte loads) is requested here and arrives during the x transform; only the x patch
         // (36 registers) is held across the matrix phase -- with the dy tile too the kernel spilled
         load_d(u0);
@@ -577,6 +584,13 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     g.tilesY = (g.rows + 3) / 4;
     g.groupsX = (g.tilesX + 3) / 4;
     g.units = (long)N * g.groupsX * g.tilesY;
+    {   // column groups per super-group: the largest power of two up to the aim that divides the groups of a tile row
+        const char* e = getenv("AFD_WW_GSH");
+        int aim = e ? atoi(e) : 0;  // measured level at 0 / 1 / 2 / 3 (12.48-12.55 ms for the class): off by default
+        aim = aim < 0 ? 0 : (aim > 4 ? 4 : aim);
+        g.gsh = 0;
+        while (g.gsh < aim && g.groupsX % (2 << g.gsh) == 0) ++g.gsh;
+    }
     g.cig = Cin / (16 * CIB);
     const int cgroups = g.cig * (Cout / (16 * COB));
     // three, two or one rounds of workgroups over the CUs (see target_wgs), each workgroup with at least 8 rounds
