@@ -86,28 +86,42 @@ def gpu_dcnn(rank, world):
     from audiofakedetect.utils import DotDict
 
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # geometry: the shipped sym5 level-8 model by default; AFD_TEST_GEOMETRY picks the others -- every fused unit of the
+    # step (input folds, BatchNorm-backward epilogues, the block-2 pass) has its own packed-sum exchange, and which of
+    # them run depends on the feature shape
+    packets, frames_t, add, per_rank = {"sym5l8": (256, 95, 1, 4), "coif4l8": (256, 109, 0, 4), "stft": (256, 101, 0, 4),
+                                        "coif4l14": (16384, 24, 0, 2)}[os.environ.get("AFD_TEST_GEOMETRY", "sym5l8")]
+    flat = 40 * (packets // 8 - 24)
+    total = per_rank * world
 
     def make(ddp):
         torch.manual_seed(3)
-        a = DotDict(input_dim=[4, 1, 256, 95], ochannels1=64, ochannels2=64, ochannels3=96,
+        a = DotDict(input_dim=[per_rank, 1, packets, frames_t], ochannels1=64, ochannels2=64, ochannels3=96,
                     ochannels4=128, ochannels5=32, kernel1=3, dropout_cnn=0.0, dropout_lstm=0.0,
-                    time_dim_add=1, flattend_size=320, ddp=ddp)
+                    time_dim_add=add, flattend_size=flat, ddp=ddp)
         return DCNN(a).cuda().train()
 
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(8, 1, 256, 95, generator=g).cuda()
-    y = torch.randint(0, 2, (8,), generator=g).cuda()
+    x = torch.randn(total, 1, packets, frames_t, generator=g).cuda()
+    y = torch.randint(0, 2, (total,), generator=g).cuda()
     net = make(True)
     wrapped = DataParallelRCCL(net)
     opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=1e-3)
     opt.zero_grad()
-    out = wrapped(x[rank * 4:(rank + 1) * 4])
-    loss = ops.CrossEntropyLoss()(out, y[rank * 4:(rank + 1) * 4])
+    ops.collective_counters(reset=True)
+    out = wrapped(x[rank * per_rank:(rank + 1) * per_rank])
+    loss = ops.CrossEntropyLoss()(out, y[rank * per_rank:(rank + 1) * per_rank])
     start_gradient_allreduce(opt)  # as left behind by a step whose backward raised before its callbacks ran
     start_gradient_allreduce(opt)  # the all-reduce is issued (once) by the end-of-backward hook
     loss.backward()
     assert getattr(opt, "_pending_allreduce", None) is not None
     scale = sync_gradients(wrapped, opt)
+    # the step's exchanges: one packed-sum all-reduce per BatchNorm forward and backward (8 + 8: reference
+    # models.py:260-289, SyncBatchNorm) and ONE all-reduce over the gradient arena -- every packed-sum site of the fused
+    # units has therefore been through a two-rank reduction
+    coll = ops.collective_counters(reset=True)
+    assert coll["count"] == 17, coll
+    assert coll["bytes"] >= opt.flat_grad.numel() * 4, coll
     grads = (opt.flat_grad * scale).clone()
     bn_rm = net.cnn[3].running_mean.clone()
 
@@ -116,7 +130,7 @@ def gpu_dcnn(rank, world):
     ropt.zero_grad()
     rout = ref(x)
     ops.CrossEntropyLoss()(rout, y).backward()
-    err = (out - rout[rank * 4:(rank + 1) * 4]).abs().max().item()
+    err = (out - rout[rank * per_rank:(rank + 1) * per_rank]).abs().max().item()
     assert err <= 1e-4, f"sharded logits differ from full-batch logits: {err}"
     rel = ((grads - ropt.flat_grad).norm() / ropt.flat_grad.norm()).item()
     assert rel <= 3e-3, f"all-reduced gradients differ from full-batch gradients: {rel}"

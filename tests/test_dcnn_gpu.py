@@ -431,7 +431,7 @@ def test_level14_batch128_train_step_properties(wavelet, t_len):
         feats, _ = tr(x.cuda())
     opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=0.0)
     losses = []
-    for it in range(4):
+    for it in range(24):
         opt.zero_grad()
         out = net(feats)
         loss = ops.CrossEntropyLoss()(out, labels)
@@ -447,9 +447,10 @@ def test_level14_batch128_train_step_properties(wavelet, t_len):
             assert abs(slope - 1.0) <= 0.01, slope  # measured 0.99994 / 0.99998 (level 14), 0.9975 (STFT)
         losses.append(loss.item())
         opt.step()
-    # (at lr 4e-4 the first Adam steps on the 80 960-wide Linear overshoot on some batches: the property is that
-    # the optimiser reaches a lower loss within the four steps, not monotone descent)
-    assert all(map(lambda v: v == v and v < 10, losses)) and min(losses[1:]) < losses[0], losses
+    # the fixed batch is learned: at lr 4e-4 the first Adam steps on the 80 960-wide Linear overshoot (the loss is above
+    # its start for about ten steps, profiles/r04_overfit.txt), after 24 steps it is well below it
+    print("losses", [round(v, 4) for v in losses])
+    assert all(map(lambda v: v == v and v < 10, losses)) and losses[-1] < 0.8 * losses[0], losses
 
 
 def test_stft_dcnn_batch128_eval_and_train_step_properties():
@@ -477,7 +478,7 @@ def test_stft_dcnn_batch128_eval_and_train_step_properties():
     net.train()
     opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=0.0)
     losses = []
-    for it in range(4):
+    for it in range(24):
         opt.zero_grad()
         out = net(feats)
         loss = ops.CrossEntropyLoss()(out, labels)
@@ -492,4 +493,5 @@ def test_stft_dcnn_batch128_eval_and_train_step_properties():
             assert abs(slope - 1.0) <= 0.01, slope  # measured 0.99994 / 0.99998 (level 14), 0.9975 (STFT)
         losses.append(loss.item())
         opt.step()
-    assert all(v == v and v < 10 for v in losses) and min(losses[1:]) < losses[0], losses
+    print("losses", [round(v, 4) for v in losses])
+    assert all(v == v and v < 10 for v in losses) and losses[-1] < 0.8 * losses[0], losses

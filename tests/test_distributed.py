@@ -20,13 +20,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_world2(mode, timeout=300, one_gpu_per_rank=False, world=2):
+def _run_world2(mode, timeout=300, one_gpu_per_rank=False, world=2, extra_env=None):
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                    WORLD_SIZE=str(world), LOCAL_RANK=str(rank if one_gpu_per_rank else 0), OMP_NUM_THREADS="2",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), mode],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -48,8 +48,14 @@ def test_world2_gloo_cpu_gradient_allreduce_bn_stats_sampler():
 
 
 @pytest.mark.gpu
-def test_world2_sharded_dcnn_step_equals_full_batch_step():
-    _run_world2("gpu_dcnn")
+@pytest.mark.parametrize("geometry", ["sym5l8", "coif4l8", "stft", "coif4l14"])
+def test_world2_sharded_dcnn_step_equals_full_batch_step(geometry):
+    """Two ranks (both on cuda:0, gloo) against the single-process full-batch step at every model geometry: the shipped
+    level-8 / STFT shapes (4 frames per rank) and the level-14 benchmark shape (2 frames per rank).  Each geometry
+    activates a different set of fused units -- the four input folds, both BatchNorm-backward epilogues, the one-pass
+    block 2 -- and each unit's packed BatchNorm sums must come out of a real two-rank reduction: 8 + 8 + 1 collectives,
+    sharded logits / gradients / running statistics / Adam update equal to the full batch's."""
+    _run_world2("gpu_dcnn", extra_env={"AFD_TEST_GEOMETRY": geometry}, timeout=600)
 
 
 def _gpu_count():
