@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #define AFD_OK 0
 #define AFD_ERR_ARG (-1)
@@ -130,6 +131,23 @@ void wgrad3x3_geometry(int N, int Cin, int H, int W, int Cout, int dz_rows, int 
                        int* nchunks, int* CI_T, int* CO_PAD, int* NCOL);
 int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, int N, int Cin, int H,
                     int W, int Cout, int dz_rows, int dz_cols, hipStream_t s);
+
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8) and every XCD has its own L2.  Kernels whose neighbouring
+// work items share cache lines (row segments that do not start on 128-byte boundaries) want neighbours on ONE XCD, in
+// flight together: in every group of 8 m consecutive ids XCD x takes the m consecutive logical ids x m .. x m + m - 1
+// (the tail of the grid that does not fill a group keeps its ids).  m <= 1: identity.
+__device__ __forceinline__ int xcd_grouped_id(int id, int total, int m) {
+    if (m <= 1) return id;
+    const int grp = 8 * m;
+    const int base = id / grp * grp;
+    if (base + grp > total) return id;
+    const int p = id - base;
+    return base + (p & 7) * m + (p >> 3);
+}
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
 
 constexpr int kWave = 64;
 constexpr int kLdsBytes = 160 * 1024;  // per-CU LDS on gfx950

@@ -140,11 +140,22 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
                       const unsigned char* __restrict__ idx, const float* __restrict__ u,
                       const float* __restrict__ slope, float* __restrict__ partial, int N, int H,
                       int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalTiles,
-                      const float* __restrict__ aff_alpha, const float* __restrict__ aff_beta) {
+                      const float* __restrict__ aff_alpha, const float* __restrict__ aff_beta, int xcd_split) {
     __shared__ float red[kT / 64][kCG * 11];
-    const int cg = blockIdx.x;
-    const int split = blockIdx.y;
+    // The channel groups of one split read the same input patches (the one-channel image, 4 rows x 2 KB per tile).  As
+    // grid (cg, split) the eight groups of a split had consecutive block ids -- one per XCD, the image fetched once per
+    // XCD (3.2 GB of the launch's 13.6 GB, profiles/r05_pmc_traffic_*).  Linear ids in groups of 64: XCD x = id & 7 takes
+    // split 8 g + x with its eight channel groups in consecutive dispatch slots, so seven of the eight patch reads hit L2.
+    int cg, split;
     const int S = gridDim.y;
+    if (xcd_split) {
+        const int id = blockIdx.y * gridDim.x + blockIdx.x;  // gridDim.x == 8 (checked by the host)
+        split = (id >> 6) * 8 + (id & 7);
+        cg = (id >> 3) & 7;
+    } else {
+        cg = blockIdx.x;
+        split = blockIdx.y;
+    }
     const float a = slope[0];
     const float inva = a != 0.f ? 1.f / a : 0.f;
     float acc[kCG][9];
@@ -331,7 +342,8 @@ extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, c
     afd::ScopedTiming timing(AFD_K_CONV_FIRST, bwd_bytes, AFD_STREAM);
     timing.bytes(bwd_bytes);
     hipLaunchKernelGGL(conv1_pool_bwd_kernel, dim3(CG, S), dim3(kT), 0, AFD_STREAM, x, du, idx, u, slope,
-                       partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles, alpha, beta);
+                       partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles, alpha, beta,
+                       (CG == 8 && S % 8 == 0 && !getenv("AFD_CONV1_BWD_ROWMAJOR")) ? 1 : 0);
     const int total = CG * kCG * 11;
     hipLaunchKernelGGL(conv1_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, AFD_STREAM, partial,
                        dw, dbias, dslope, Cout, CG, S);

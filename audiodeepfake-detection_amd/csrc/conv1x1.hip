@@ -24,6 +24,7 @@ struct G1 {
     int HW;
     int tiles_per_img, ntiles;
     int trans;  // 0: W[m][k] = w[m * Cin + k] (forward); 1: W[m][k] = w[k * Cout + m] (dgrad)
+    int xcd_m;  // workgroups per XCD group (afd::xcd_grouped_id): neighbouring tiles share the lines their rows end in
 };
 
 // NW consecutive floats with 4-byte alignment (image rows of 13 x 8193 floats start anywhere):
@@ -97,7 +98,7 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
         }
     };
 
-    int t = blockIdx.x * 4 + wave;
+    int t = afd::xcd_grouped_id((int)blockIdx.x, (int)gridDim.x, g.xcd_m) * 4 + wave;
     float s1[STATS ? MW : 1][16], s2[STATS ? MW : 1][16];
     float slope_a = 0.f;
     if constexpr (STATS) {
@@ -428,6 +429,7 @@ int launch_gemm_stats(G1 g, const float* x, const float* w, const float* bias, c
     const long nt = (long)g.N * g.tiles_per_img;
     if (nt > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1: too many tiles");
     g.ntiles = (int)nt;
+    g.xcd_m = afd::env_int("AFD_CONV1X1_XCDM", 16);
     const int Kpad = (g.Cin + 31) / 32 * 32;
     const size_t lds = (size_t)Kpad * MW * 32 * sizeof(float);
     long blocks = (nt + 3) / 4;
@@ -451,6 +453,7 @@ int launch_gemm(G1 g, const float* x, const float* w, const float* bias, float* 
     const long nt = (long)g.N * g.tiles_per_img;
     if (nt > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1: too many tiles");
     g.ntiles = (int)nt;
+    g.xcd_m = afd::env_int("AFD_CONV1X1_XCDM", 16);
     const int Kpad = (g.Cin + 31) / 32 * 32;
     const size_t lds = (size_t)Kpad * MW * 32 * sizeof(float);
     long blocks = (nt + 3) / 4;

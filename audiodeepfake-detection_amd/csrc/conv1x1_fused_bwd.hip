@@ -56,6 +56,7 @@ struct FB {
     float* t;
     float* partial;
     int N, Cin, C, HW, tiles_per_img, ntiles;
+    int xcd_m;
 };
 
 struct Chunk {
@@ -87,7 +88,9 @@ conv1x1_fused_bwd_kernel(const FB p) {
     const float a = p.slope[0];
     const size_t HW = (size_t)p.HW;
     const int tstride = (int)gridDim.x * kWaves;
-    int t = (int)blockIdx.x * kWaves + wave;
+    // neighbouring tiles share the cache lines their 256-byte row segments start and end in: m consecutive workgroups
+    // (4 m tiles) per XCD at a time (afd::xcd_grouped_id)
+    int t = afd::xcd_grouped_id((int)blockIdx.x, (int)gridDim.x, p.xcd_m) * kWaves + wave;
 
     f32x16 acc2[2][2];
 #pragma unroll
@@ -368,6 +371,7 @@ extern "C" int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, con
     const long nt = (long)N * p.tiles_per_img;
     if (nt > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1 fused backward: too many tiles");
     p.ntiles = (int)nt;
+    p.xcd_m = afd::env_int("AFD_FUSED_BWD_XCDM", 16);
     long blocks = (nt + kWaves - 1) / kWaves;
     const int cap = fused_blocks();
     if (blocks > cap) blocks = cap;
