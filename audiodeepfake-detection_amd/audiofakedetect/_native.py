@@ -121,12 +121,13 @@ _SIGNATURES = {
     "afd_conv2d_forward_bf16": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_sz, c_p]),
     "afd_lcnn_prep_bytes": (c_sz, [c_i, c_i, c_i]),
     "afd_lcnn_prep_conv_bf16": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p]),
-    "afd_lcnn_conv1_nhwc_bf16": (c_i, [c_p, c_p, c_p] + [c_i] * 6 + [c_p]),
-    "afd_lcnn_conv_nhwc_bf16": (c_i, [c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
+    "afd_lcnn_conv1_nhwc_bf16": (c_i, [c_p, c_p, c_p] + [c_i] * 7 + [c_p]),
+    "afd_lcnn_conv_nhwc_bf16": (c_i, [c_p, c_p, c_p] + [c_i] * 8 + [c_p]),
     "afd_lcnn_pool_nhwc_bf16": (c_i, [c_p, c_p] + [c_i] * 5 + [c_p]),
     "afd_f32_to_bf16": (c_i, [c_p, c_p, c_sz, c_p]),
     "afd_lstm_step_bf16": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
     "afd_lstm_step_bf16_pair": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_p]),
+    "afd_blstm_layer_bf16": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_lstm_cell": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "afd_lstm_cell_backward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "afd_cross_entropy": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -95,6 +97,12 @@ def conv2d_bf16(x: torch.Tensor, w: torch.Tensor, b, padding: int, mfm: bool = F
     return y
 
 
+def lstm_fragment_order(wh: torch.Tensor) -> torch.Tensor:
+    """weight_hh [4H][H] -> the matrix-fragment order `afd_blstm_layer_bf16` reads ([H/8][H/16][64 lanes][8])."""
+    h = wh.shape[1]
+    return wh.view(4, h // 8, 8, h // 16, 2, 8).permute(1, 3, 4, 0, 2, 5).contiguous()
+
+
 def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, whh: Optional[dict] = None,
                        bias2: Optional[dict] = None) -> torch.Tensor:
     """Inference forward of a bidirectional LSTM layer with bf16 projections (cell update in fp32).  `wih`:
@@ -106,6 +114,20 @@ def blstm_forward_bf16(x: torch.Tensor, m: nn.LSTM, wih: Optional[dict] = None, 
     h = m.weight_hh_l0.shape[1]
     xt = x.permute(1, 0, 2).contiguous().view(steps * bsz, d)
     out = torch.empty((steps, bsz, 2 * h), dtype=torch.float32, device=x.device)
+    if whh is not None and h % 16 == 0 and h <= 256 and not os.environ.get("AFD_LSTM_STEPWISE"):
+        # the whole layer -- every step of both directions -- in one launch (`afd_blstm_layer_bf16`)
+        pres = []
+        for sfx in ("", "_reverse"):
+            wi = wih[sfx] if wih is not None else getattr(m, "weight_ih_l0" + sfx)
+            bias = bias2[sfx] if bias2 is not None else getattr(m, "bias_ih_l0" + sfx) + getattr(m, "bias_hh_l0" + sfx)
+            pres.append(gemm_nt(xt, ops._f32c(wi), bias, bf16=True))
+        frag = [whh.get("frag" + sfx) for sfx in ("", "_reverse")]
+        if frag[0] is None:  # callers without a prepared plan: pack on the fly
+            frag = [lstm_fragment_order(whh[sfx]) for sfx in ("", "_reverse")]
+        _native.check(lib.afd_blstm_layer_bf16(_native.ptr(pres[0]), _native.ptr(pres[1]), _native.ptr(frag[0]),
+                                               _native.ptr(frag[1]), _native.ptr(out), steps, bsz, h,
+                                               _native.stream_ptr()), "afd_blstm_layer_bf16")
+        return out.permute(1, 0, 2).contiguous()
     if whh is not None and h % 16 == 0:
         # both directions advance together: one launch per time step (`afd_lstm_step_bf16_pair`)
         pres, hs2, cs2 = [], [], []
@@ -290,6 +312,8 @@ class _Bf16Plan:
                 _native.check(lib.afd_f32_to_bf16(_native.ptr(w), _native.ptr(wb), w.numel(), _native.stream_ptr()),
                               "afd_f32_to_bf16")
                 d[sfx] = wb
+                if w.shape[1] % 16 == 0 and w.shape[1] <= 256:
+                    d["frag" + sfx] = lstm_fragment_order(wb)  # what the one-launch layer kernel reads
             self.whh.append(d)
         # b_ih + b_hh per layer and direction, once (two launches per layer and step otherwise)
         self.bias = [{sfx: (getattr(layer.l_blstm, "bias_ih_l0" + sfx) + getattr(layer.l_blstm, "bias_hh_l0" + sfx)).detach()
@@ -383,21 +407,22 @@ class LCNN(nn.Module):
         last = len(plan.convs) - 1
         for i, (buf, cin, cout, k, pad, pooled) in enumerate(plan.convs):
             ho, wo = h + 2 * pad - (k - 1), w + 2 * pad - (k - 1)
-            y = torch.empty((n, ho, wo, cout // 2), dtype=torch.bfloat16, device=x.device)
+            # the MaxPool2d(2, 2) behind a layer runs in that layer's epilogue (pool = 1; 2 = fp32 out for the tensor that
+            # feeds the BLSTM layers): the pre-pool tensor is never written
+            f32 = pooled and i == last
+            pool = (2 if f32 else 1) if pooled else 0
+            if pooled:
+                ho, wo = ho // 2, wo // 2
+            y = torch.empty((n, ho, wo, cout // 2), dtype=torch.float32 if f32 else torch.bfloat16, device=x.device)
             if i == 0:
+                if pool == 2:
+                    raise RuntimeError("LCNN(precision='bf16'): the first layer cannot be the last")
                 _native.check(lib.afd_lcnn_conv1_nhwc_bf16(_native.ptr(cur), _native.ptr(buf), _native.ptr(y), n, h, w, cout,
-                                                           k, pad, _native.stream_ptr()), "afd_lcnn_conv1_nhwc_bf16")
+                                                           k, pad, pool, _native.stream_ptr()), "afd_lcnn_conv1_nhwc_bf16")
             else:
                 _native.check(lib.afd_lcnn_conv_nhwc_bf16(_native.ptr(cur), _native.ptr(buf), _native.ptr(y), n, h, w, cin,
-                                                          cout, k, pad, _native.stream_ptr()), "afd_lcnn_conv_nhwc_bf16")
+                                                          cout, k, pad, pool, _native.stream_ptr()), "afd_lcnn_conv_nhwc_bf16")
             cur, h, w = y, ho, wo
-            if pooled:
-                f32 = i == last
-                z = torch.empty((n, h // 2, w // 2, cout // 2), dtype=torch.float32 if f32 else torch.bfloat16,
-                                device=x.device)
-                _native.check(lib.afd_lcnn_pool_nhwc_bf16(_native.ptr(cur), _native.ptr(z), n, h, w, cout // 2,
-                                                          1 if f32 else 0, _native.stream_ptr()), "afd_lcnn_pool_nhwc_bf16")
-                cur, h, w = z, h // 2, w // 2
         seq = cur.reshape(n, h, -1)  # [B, T', W' C] fp32 (dropout is the identity in evaluation mode)
         for li, layer in enumerate(self.lstm):
             seq = blstm_forward_bf16(seq, layer.l_blstm, plan.wih0 if li == 0 else None, plan.whh[li], plan.bias[li])

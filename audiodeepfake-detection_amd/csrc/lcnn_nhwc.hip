@@ -67,7 +67,74 @@ __global__ void lcnn_prep_conv_kernel(const float* __restrict__ w, const float* 
 
 struct LG {
     int N, H, W, Cin, Cout, pad, Ho, Wo, tiles, half, HP, Kpad;
+    int PH, PW;  // POOL forms: the pooled image (floor(Ho / 2) x floor(Wo / 2)); tiles then counts 32-window tiles
 };
+
+// POOL forms (round 5): MaxPool2d(2, 2) in the convolution's epilogue.  A lane's pixel is position (r & 3) of window
+// (r >> 2) of its wave -- the four pixels of a 2 x 2 window sit in the four lanes of a quad, so the pool is two DPP
+// quad permutes + maxima per value in the D fragment, and the pooled pixel's channels leave from all four lanes (lane
+// `pos` stores channel group `pos`): the pre-pool tensor (1.7 GB behind the first layer at B = 1024) is never written.
+// max(round(a), round(b)) = round(max(a, b)): bit-identical to the separate pool on the rounded tensor.
+__device__ __forceinline__ float quad_max(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    const float m = a > v ? a : v;
+    const int j = __builtin_bit_cast(int, m);
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(j, j, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    return b > m ? b : m;
+}
+
+// y: bf16 (or, OUT_F32, bf16-rounded fp32) [window][half] of this pooled pixel
+template <int MT, bool OUT_F32>
+__device__ __forceinline__ void mfm_pool_store(const f32x16 (&acc)[MT], const float* __restrict__ bb, void* __restrict__ yv,
+                                               int half, int HP, int h, int pos) {
+#pragma unroll
+    for (int i = 0; i < MT / 2; ++i) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = 32 * i + 8 * (q >> 2) + 4 * h + (q & 3);
+            const float a = acc[i][q] + bb[c];
+            const float b = acc[i + MT / 2][q] + bb[HP + c];
+            v[q] = quad_max(b > a ? b : a);
+        }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = pos == 0 ? v[j] : (pos == 1 ? v[4 + j] : (pos == 2 ? v[8 + j] : v[12 + j]));
+        const int c0 = 32 * i + 8 * pos + 4 * h;
+        if (c0 < half) {
+            bf16x4 ob;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ob[j] = (__bf16)o[j];
+            if (OUT_F32) {
+                float* y = static_cast<float*>(yv) + c0;
+                *reinterpret_cast<float4*>(y) = make_float4((float)ob[0], (float)ob[1], (float)ob[2], (float)ob[3]);
+            } else {
+                *reinterpret_cast<bf16x4*>(static_cast<__bf16*>(yv) + c0) = ob;
+            }
+        }
+    }
+}
+
+// pixel of a lane: plain forms p = tile * 128 + 32 wave + r; POOL forms window = tile * 32 + 8 wave + (r >> 2)
+template <bool POOL>
+__device__ __forceinline__ bool lane_pixel(const LG& g, int tile, int wave, int r, int& oy, int& ox, size_t& out_px) {
+    if (POOL) {
+        const int wdw = tile * 32 + 8 * wave + (r >> 2);
+        const bool pv = wdw < g.PH * g.PW;
+        const int py = pv ? wdw / g.PW : 0, px = pv ? wdw - py * g.PW : 0;
+        oy = 2 * py + ((r >> 1) & 1);
+        ox = 2 * px + (r & 1);
+        out_px = (size_t)wdw;
+        return pv;
+    }
+    const int p = tile * kPixT + 32 * wave + r;
+    const bool pv = p < g.Ho * g.Wo;
+    oy = pv ? p / g.Wo : 0;
+    ox = pv ? p - oy * g.Wo : 0;
+    out_px = (size_t)p;
+    return pv;
+}
 
 // D fragment of a 32x32 tile: column (pixel) = lane & 31, row (channel) = (q & 3) + 8 (q >> 2) + 4 (lane >> 5).
 // Pair maximum of tile i (first halves) and tile i + MT/2 (second halves), bias included; four consecutive channels
@@ -94,17 +161,17 @@ __device__ __forceinline__ void mfm_store(const f32x16 (&acc)[MT], const float* 
 }
 
 // first layer: Cin = 1, K x K taps (25 -> Kpad 32); x fp32 [N][H][W]
-template <int MT>
+template <int MT, bool POOL>
 __global__ void __launch_bounds__(kThr) lcnn_conv1_kernel(const LG g, const float* __restrict__ x,
                                                           const __bf16* __restrict__ wb, const float* __restrict__ bb,
                                                           __bf16* __restrict__ y, int K) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n = blockIdx.x / g.tiles;
-    const int p = (blockIdx.x - n * g.tiles) * kPixT + 32 * wave + r;
-    const int HW = g.Ho * g.Wo;
-    const bool pv = p < HW;
-    const int oy = pv ? p / g.Wo : 0, ox = pv ? p - oy * g.Wo : 0;
+    int oy, ox;
+    size_t opx;
+    const bool pv = lane_pixel<POOL>(g, blockIdx.x - n * g.tiles, wave, r, oy, ox, opx);
+    const size_t out_plane = POOL ? (size_t)g.PH * g.PW : (size_t)g.Ho * g.Wo;
     const float* xn = x + (size_t)n * g.H * g.W;
     f32x16 acc[MT];
 #pragma unroll
@@ -128,14 +195,74 @@ __global__ void __launch_bounds__(kThr) lcnn_conv1_kernel(const LG g, const floa
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mt], 0, 0, 0);
         }
     }
-    if (pv) mfm_store<MT>(acc, bb, y + ((size_t)n * HW + p) * g.half, g.half, g.HP, h);
+    if (pv) {
+        __bf16* yp = y + ((size_t)n * out_plane + opx) * g.half;
+        if (POOL) mfm_pool_store<MT, false>(acc, bb, yp, g.half, g.HP, h, r & 3);
+        else mfm_store<MT>(acc, bb, yp, g.half, g.HP, h);
+    }
+}
+
+// First layer with the pool in its epilogue, patch staged in LDS (round 5).  The gathering kernel above pays ~15 vector
+// instructions per tap and pixel (k -> (ky, kx) by integer division, four bounds checks, a scattered 4-byte load): 0.94 ms
+// for the 26.5 M pixels of B = 1024, all of it index arithmetic.  Here a workgroup owns 4 pooled rows x 8 pooled columns
+// (8 x 16 convolution pixels; wave = pooled row, quad = window), its 12 x 20 input patch sits in LDS with the zero padding
+// materialised, and a tap is one select between two compile-time offsets (the lane's k half) + one ds_read_b32.
+template <int MT, int K>
+__global__ void __launch_bounds__(kThr) lcnn_conv1_pool_kernel(const LG g, const float* __restrict__ x,
+                                                               const __bf16* __restrict__ wb, const float* __restrict__ bb,
+                                                               __bf16* __restrict__ y) {
+    constexpr int PR = 8 + K - 1, PC = 16 + K - 1;  // patch rows / columns
+    constexpr int KP = (K * K + 15) / 16 * 16;
+    __shared__ float patch[PR * PC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int pxb = blockIdx.x, pyb = blockIdx.y, n = blockIdx.z;
+    const float* xn = x + (size_t)n * g.H * g.W;
+    const int iy0 = 8 * pyb - g.pad, ix0 = 16 * pxb - g.pad;
+    for (int e = tid; e < PR * PC; e += kThr) {
+        const int pr = e / PC, pc = e - pr * PC;
+        const int iy = iy0 + pr, ix = ix0 + pc;
+        patch[e] = (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) ? xn[(size_t)iy * g.W + ix] : 0.f;
+    }
+    __syncthreads();
+    const int py = 4 * pyb + wave, px = 8 * pxb + (r >> 2);
+    const bool pv = py < g.PH && px < g.PW;
+    // top-left tap of this lane's convolution pixel inside the patch
+    const float* base = patch + (2 * wave + ((r >> 1) & 1)) * PC + 2 * (r >> 2) + (r & 1);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+#pragma unroll
+    for (int k0 = 0; k0 < KP; k0 += 16) {
+        bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // k = k0 + 8 h + e: both halves' offsets are compile-time constants; taps past K * K meet zero weights and
+            // read the pixel's first tap (a finite value of the same patch)
+            const int ka = k0 + e, kb = k0 + 8 + e;
+            const int oa = ka < K * K ? (ka / K) * PC + ka % K : 0;
+            const int ob = kb < K * K ? (kb / K) * PC + kb % K : 0;
+            b[e] = (__bf16)base[h ? ob : oa];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(wb + (size_t)(32 * mt + r) * g.Kpad + k0 + 8 * h);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[mt], 0, 0, 0);
+        }
+    }
+    if (pv) {
+        __bf16* yp = y + (((size_t)n * g.PH + py) * g.PW + px) * g.half;
+        mfm_pool_store<MT, false>(acc, bb, yp, g.half, g.HP, h, r & 3);
+    }
 }
 
 // 1x1 / 3x3 layers on channels-last bf16
-template <int K, int MT, int CIN>
+template <int K, int MT, int CIN, int POOL = 0>  // POOL: 0 none, 1 pooled bf16, 2 pooled fp32 (bf16-rounded values)
 __global__ void __launch_bounds__(kThr) lcnn_conv_nhwc_kernel(const LG g, const __bf16* __restrict__ x,
                                                               const __bf16* __restrict__ wb,
-                                                              const float* __restrict__ bb, __bf16* __restrict__ y) {
+                                                              const float* __restrict__ bb, void* __restrict__ yv) {
     constexpr int PITCH = CIN + 8;            // bf16 per LDS row: 16-byte aligned rows, banks spread
     constexpr int ROWS = 32 * MT;
     constexpr int PIECES = ROWS * (CIN / 8);  // 16-byte pieces of one tap's weight slice
@@ -145,10 +272,10 @@ __global__ void __launch_bounds__(kThr) lcnn_conv_nhwc_kernel(const LG g, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n = blockIdx.x / g.tiles;
-    const int p = (blockIdx.x - n * g.tiles) * kPixT + 32 * wave + r;
-    const int HW = g.Ho * g.Wo;
-    const bool pv = p < HW;
-    const int oy = pv ? p / g.Wo : 0, ox = pv ? p - oy * g.Wo : 0;
+    int oy, ox;
+    size_t opx;
+    const bool pv = lane_pixel<POOL != 0>(g, blockIdx.x - n * g.tiles, wave, r, oy, ox, opx);
+    const size_t out_plane = POOL ? (size_t)g.PH * g.PW : (size_t)g.Ho * g.Wo;
     const __bf16* xn = x + (size_t)n * g.H * g.W * CIN + 8 * h;
 
     f32x16 acc[MT];
@@ -209,7 +336,12 @@ __global__ void __launch_bounds__(kThr) lcnn_conv_nhwc_kernel(const LG g, const 
         if (t + 1 < K * K) stash(buf ^ 1);
         __syncthreads();
     }
-    if (pv) mfm_store<MT>(acc, bb, y + ((size_t)n * HW + p) * g.half, g.half, g.HP, h);
+    if (pv) {
+        const size_t o = ((size_t)n * out_plane + opx) * g.half;
+        if (POOL == 2) mfm_pool_store<MT, true>(acc, bb, static_cast<float*>(yv) + o, g.half, g.HP, h, r & 3);
+        else if (POOL == 1) mfm_pool_store<MT, false>(acc, bb, static_cast<__bf16*>(yv) + o, g.half, g.HP, h, r & 3);
+        else mfm_store<MT>(acc, bb, static_cast<__bf16*>(yv) + o, g.half, g.HP, h);
+    }
 }
 
 // MaxPool2d(2, 2), floor mode, 8 channels per thread
@@ -326,23 +458,119 @@ __global__ void __launch_bounds__(64) lstm_step_bf16_pair_kernel(const LstmDir d
     lstm_step_body(d.pre, d.wh, d.hprev, d.c, d.hout, ldh, d.hnext, B, H);
 }
 
+// A whole bidirectional LSTM layer in ONE launch (round 5; the step kernels above take 2 x T launches of 9-17 us, bound by
+// launch and one round of loads each).  The recurrence only couples the hidden units of ONE batch row, so a workgroup that
+// owns 32 batch rows and ALL hidden units of one direction needs no other workgroup: it walks the T steps by itself with a
+// workgroup barrier per step.  8 waves; wave w owns the row tiles w, w + 8, ... (a tile = 4 gates x 8 units, as in
+// lstm_step_body, so that a lane holds the four gates of its units); h lives in LDS as bf16 [32][H] (double-buffered: the
+// B operand of the next step), c in registers for the whole sequence; Wh -- handed over in matrix-fragment order, see
+// afd_blstm_layer_bf16 -- streams from L2 every step (512 KB per direction at H = 256, resident in every XCD's L2), the
+// step's `pre` rows are requested before its matrix instructions.
+constexpr int kLstmWaves = 8, kLstmTilesMax = 4;
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.f + __expf(-x)); }
+__global__ void __launch_bounds__(kLstmWaves * 64)
+blstm_layer_bf16_kernel(const float* __restrict__ pre_f, const float* __restrict__ pre_r, const __bf16* __restrict__ wh_f,
+                        const __bf16* __restrict__ wh_r, float* __restrict__ out, int T, int B, int H) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 hbuf[];  // [2][32][H + 8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int dir = blockIdx.y;
+    const int b = blockIdx.x * 32 + r;
+    const bool bv = b < B;
+    const float* pre = dir ? pre_r : pre_f;
+    const __bf16* wh = dir ? wh_r : wh_f;
+    const int pitch = H + 8;
+    const int tiles = H / 8;
+    for (int e = tid; e < 2 * 32 * pitch; e += kLstmWaves * 64) hbuf[e] = (__bf16)0.f;
+    float c[kLstmTilesMax][4];
+#pragma unroll
+    for (int i = 0; i < kLstmTilesMax; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[i][j] = 0.f;
+    __syncthreads();
+    for (int s = 0; s < T; ++s) {
+        const int t = dir ? T - 1 - s : s;
+        const __bf16* hp = hbuf + (size_t)(s & 1) * 32 * pitch + (size_t)r * pitch + 8 * hh;
+        __bf16* hn = hbuf + (size_t)((s + 1) & 1) * 32 * pitch + (size_t)r * pitch;
+        const float* pb = pre + ((size_t)t * B + (bv ? b : 0)) * 4 * H;
+        float* ob = out + ((size_t)t * B + (bv ? b : 0)) * 2 * H + (size_t)dir * H;
+#pragma unroll
+        for (int i = 0; i < kLstmTilesMax; ++i) {
+            const int tile = wave + kLstmWaves * i;
+            if (tile >= tiles) break;  // uniform
+            const int u0 = 8 * tile + 4 * hh;
+            // the four gates of this lane's four units (order i | f | g | o): in flight during the matrix instructions
+            const float4 pi = *reinterpret_cast<const float4*>(pb + u0), pf = *reinterpret_cast<const float4*>(pb + H + u0);
+            const float4 pg = *reinterpret_cast<const float4*>(pb + 2 * H + u0), po = *reinterpret_cast<const float4*>(pb + 3 * H + u0);
+            // weights in FRAGMENT order [tile][k-step][lane][8]: a wave's load is 1 KB of consecutive bytes (row-major
+            // weights made every load touch 32 lines for 32 bytes each -- 22 us per step on the CU's L1 at H = 256)
+            const __bf16* arow = wh + ((size_t)tile * (H / 16) * 64 + lane) * 8;
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            if (s > 0) {  // h_0 = 0: the first step has no recurrent term
+                // eight k-steps of weight rows requested together (one L2 round trip per 128 k, not per 16)
+                for (int k0 = 0; k0 < H; k0 += 128) {
+                    bf16x8 a[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k0 + 16 * j < H) a[j] = *reinterpret_cast<const bf16x8*>(arow + (size_t)(k0 / 16 + j) * 512);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k0 + 16 * j < H) {
+                            const bf16x8 bb = *reinterpret_cast<const bf16x8*>(hp + k0 + 16 * j);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bb, acc, 0, 0, 0);
+                        }
+                }
+            }
+            const float pia[4] = {pi.x, pi.y, pi.z, pi.w}, pfa[4] = {pf.x, pf.y, pf.z, pf.w};
+            const float pga[4] = {pg.x, pg.y, pg.z, pg.w}, poa[4] = {po.x, po.y, po.z, po.w};
+            float hv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // hardware exp / reciprocal (a 32-row workgroup walks the whole sequence alone: its gate arithmetic is on
+                // the critical path of every step); tanh x = 2 sigmoid(2 x) - 1.  ~1e-6 relative, inside the bf16 bar
+                const float ig = fast_sigmoid(acc[j] + pia[j]);
+                const float fg = fast_sigmoid(acc[4 + j] + pfa[j]);
+                const float gg = 2.f * fast_sigmoid(2.f * (acc[8 + j] + pga[j])) - 1.f;
+                const float og = fast_sigmoid(acc[12 + j] + poa[j]);
+                c[i][j] = fg * c[i][j] + ig * gg;
+                hv[j] = og * (2.f * fast_sigmoid(2.f * c[i][j]) - 1.f);
+            }
+            bf16x4 hb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hb[j] = (__bf16)hv[j];
+            *reinterpret_cast<bf16x4*>(hn + u0) = hb;
+            if (bv) *reinterpret_cast<float4*>(ob + u0) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void f32_to_bf16_kernel(const float* __restrict__ x, __bf16* __restrict__ y, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (__bf16)x[i];
 }
 
-template <int K, int MT>
-int launch_nhwc(const LG& g, const __bf16* x, const __bf16* wb, const float* bb, __bf16* y, hipStream_t s) {
+template <int K, int MT, int POOL>
+int launch_nhwc_p(const LG& g, const __bf16* x, const __bf16* wb, const float* bb, void* y, hipStream_t s) {
     const unsigned grid = (unsigned)(g.N * g.tiles);
     switch (g.Cin) {
-        case 32: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 32>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
-        case 48: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 48>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
-        case 64: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 64>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
+        case 32: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 32, POOL>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
+        case 48: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 48, POOL>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
+        case 64: hipLaunchKernelGGL((lcnn_conv_nhwc_kernel<K, MT, 64, POOL>), dim3(grid), dim3(kThr), 0, s, g, x, wb, bb, y); break;
         default: return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: %d input channels", g.Cin);
     }
     return afd::check_launch("lcnn_conv_nhwc_kernel");
 }
 
-int fill_geom(LG& g, int N, int H, int W, int Cin, int Cout, int K, int pad) {
+template <int K, int MT>
+int launch_nhwc(const LG& g, const __bf16* x, const __bf16* wb, const float* bb, void* y, int pool, hipStream_t s) {
+    if (pool == 2) return launch_nhwc_p<K, MT, 2>(g, x, wb, bb, y, s);
+    if (pool == 1) return launch_nhwc_p<K, MT, 1>(g, x, wb, bb, y, s);
+    return launch_nhwc_p<K, MT, 0>(g, x, wb, bb, y, s);
+}
+
+int fill_geom(LG& g, int N, int H, int W, int Cin, int Cout, int K, int pad, int pool = 0) {
     if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 2 || (Cout & 1)) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: bad shape");
     if (pad < 0 || pad >= K) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: padding %d", pad);
     g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.pad = pad;
@@ -350,6 +578,12 @@ int fill_geom(LG& g, int N, int H, int W, int Cin, int Cout, int K, int pad) {
     g.Wo = W + 2 * pad - (K - 1);
     if (g.Ho < 1 || g.Wo < 1) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: empty output");
     g.tiles = (g.Ho * g.Wo + kPixT - 1) / kPixT;
+    g.PH = g.Ho / 2;
+    g.PW = g.Wo / 2;
+    if (pool) {
+        if (pool < 0 || pool > 2 || g.PH < 1 || g.PW < 1) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: pooled form on a %d x %d output", g.Ho, g.Wo);
+        g.tiles = (g.PH * g.PW + 31) / 32;
+    }
     g.half = Cout / 2;
     if (g.half % 4) return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: %d feature-map pairs", g.half);
     g.HP = round_up_i(g.half, 32);
@@ -385,39 +619,53 @@ extern "C" int afd_lcnn_prep_conv_bf16(const float* w, const float* bias, const 
 }
 
 extern "C" int afd_lcnn_conv1_nhwc_bf16(const float* x, const void* wb_bb, void* y, int N, int H, int W, int Cout, int K,
-                                        int pad, afd_stream_t stream) {
+                                        int pad, int pool, afd_stream_t stream) {
     if (!x || !wb_bb || !y) return afd::fail(AFD_ERR_ARG, "lcnn conv1 bf16: null pointer");
+    if (pool != 0 && pool != 1) return afd::fail(AFD_ERR_ARG, "lcnn conv1 bf16: pool is 0 or 1");
     LG g{};
-    int rc = fill_geom(g, N, H, W, 1, Cout, K, pad);
+    int rc = fill_geom(g, N, H, W, 1, Cout, K, pad, pool);
     if (rc) return rc;
     const __bf16* wb = static_cast<const __bf16*>(wb_bb);
     const float* bb = reinterpret_cast<const float*>(wb + (size_t)2 * g.HP * g.Kpad);
     afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * N * (double)g.Ho * g.Wo * Cout * K * K, AFD_STREAM);
     timing.issued(2.0 * N * (double)g.tiles * kPixT * 2 * g.HP * g.Kpad);
-    timing.bytes((double)N * (4.0 * H * W + 2.0 * g.Ho * g.Wo * g.half));
+    timing.bytes((double)N * (4.0 * H * W + 2.0 * (pool ? (double)g.PH * g.PW : (double)g.Ho * g.Wo) * g.half));
     const unsigned grid = (unsigned)(g.N * g.tiles);
-    if (2 * g.HP == 64) hipLaunchKernelGGL((lcnn_conv1_kernel<2>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, static_cast<__bf16*>(y), K);
-    else hipLaunchKernelGGL((lcnn_conv1_kernel<4>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, static_cast<__bf16*>(y), K);
+    __bf16* yb = static_cast<__bf16*>(y);
+    if (pool && K == 5 && g.Kpad == 32 && 2 * g.HP == 64 && N <= 65535 && !getenv("AFD_LCNN_CONV1_GATHER")) {
+        // the model's first layer (5 x 5, 64 channels): patch in LDS; its grid is 4 x 8-window blocks of the pooled image
+        timing.issued(2.0 * N * (double)((g.PW + 7) / 8) * ((g.PH + 3) / 4) * kPixT * 2 * g.HP * g.Kpad);
+        hipLaunchKernelGGL((lcnn_conv1_pool_kernel<2, 5>), dim3((g.PW + 7) / 8, (g.PH + 3) / 4, N), dim3(kThr), 0, AFD_STREAM, g, x,
+                           wb, bb, yb);
+        return afd::check_launch("lcnn_conv1_pool_kernel");
+    }
+    if (2 * g.HP == 64) {
+        if (pool) hipLaunchKernelGGL((lcnn_conv1_kernel<2, true>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, yb, K);
+        else hipLaunchKernelGGL((lcnn_conv1_kernel<2, false>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, yb, K);
+    } else {
+        if (pool) hipLaunchKernelGGL((lcnn_conv1_kernel<4, true>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, yb, K);
+        else hipLaunchKernelGGL((lcnn_conv1_kernel<4, false>), dim3(grid), dim3(kThr), 0, AFD_STREAM, g, x, wb, bb, yb, K);
+    }
     return afd::check_launch("lcnn_conv1_kernel");
 }
 
 extern "C" int afd_lcnn_conv_nhwc_bf16(const void* x, const void* wb_bb, void* y, int N, int H, int W, int Cin, int Cout,
-                                       int K, int pad, afd_stream_t stream) {
+                                       int K, int pad, int pool, afd_stream_t stream) {
     if (!x || !wb_bb || !y) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: null pointer");
     if (K != 1 && K != 3) return afd::fail(AFD_ERR_UNSUPPORTED, "lcnn conv bf16: kernel size %d", K);
+    if (pool < 0 || pool > 2) return afd::fail(AFD_ERR_ARG, "lcnn conv bf16: pool is 0, 1 (bf16) or 2 (fp32)");
     LG g{};
-    int rc = fill_geom(g, N, H, W, Cin, Cout, K, pad);
+    int rc = fill_geom(g, N, H, W, Cin, Cout, K, pad, pool);
     if (rc) return rc;
     const __bf16* wb = static_cast<const __bf16*>(wb_bb);
     const float* bb = reinterpret_cast<const float*>(wb + (size_t)2 * g.HP * g.Kpad);
     const __bf16* xb = static_cast<const __bf16*>(x);
-    __bf16* yb = static_cast<__bf16*>(y);
     afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * N * (double)g.Ho * g.Wo * Cout * Cin * K * K, AFD_STREAM);
     timing.issued(2.0 * N * (double)g.tiles * kPixT * 2 * g.HP * g.Kpad);
-    timing.bytes(2.0 * N * ((double)H * W * Cin + (double)g.Ho * g.Wo * g.half));
+    timing.bytes(2.0 * N * ((double)H * W * Cin + (pool ? (pool == 2 ? 2.0 : 1.0) * g.PH * g.PW : (double)g.Ho * g.Wo) * g.half));
     const bool two = 2 * g.HP == 64;
-    if (K == 1) return two ? launch_nhwc<1, 2>(g, xb, wb, bb, yb, AFD_STREAM) : launch_nhwc<1, 4>(g, xb, wb, bb, yb, AFD_STREAM);
-    return two ? launch_nhwc<3, 2>(g, xb, wb, bb, yb, AFD_STREAM) : launch_nhwc<3, 4>(g, xb, wb, bb, yb, AFD_STREAM);
+    if (K == 1) return two ? launch_nhwc<1, 2>(g, xb, wb, bb, y, pool, AFD_STREAM) : launch_nhwc<1, 4>(g, xb, wb, bb, y, pool, AFD_STREAM);
+    return two ? launch_nhwc<3, 2>(g, xb, wb, bb, y, pool, AFD_STREAM) : launch_nhwc<3, 4>(g, xb, wb, bb, y, pool, AFD_STREAM);
 }
 
 extern "C" int afd_lcnn_pool_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, int out_f32,
@@ -455,6 +703,24 @@ extern "C" int afd_lstm_step_bf16_pair(const float* const* pre, const void* cons
     hipLaunchKernelGGL(lstm_step_bf16_pair_kernel, dim3((unsigned)(H / 8), (unsigned)((B + 31) / 32), 2), dim3(64), 0, AFD_STREAM,
                        d[0], d[1], ldh, B, H);
     return afd::check_launch("lstm_step_bf16_pair_kernel");
+}
+
+extern "C" int afd_blstm_layer_bf16(const float* pre_fwd, const float* pre_rev, const void* wh_fwd_bf16,
+                                    const void* wh_rev_bf16, float* out, int T, int B, int H, afd_stream_t stream) {
+    if (!pre_fwd || !pre_rev || !wh_fwd_bf16 || !wh_rev_bf16 || !out || T < 1 || B < 1)
+        return afd::fail(AFD_ERR_ARG, "blstm layer bf16: bad argument");
+    if (H < 16 || (H & 15) || H / 8 > kLstmWaves * kLstmTilesMax)
+        return afd::fail(AFD_ERR_UNSUPPORTED, "blstm layer bf16: hidden size %d (multiples of 16 up to %d)", H,
+                         8 * kLstmWaves * kLstmTilesMax);
+    const size_t lds = (size_t)2 * 32 * (H + 8) * sizeof(__bf16);
+    afd::ScopedTiming timing(AFD_K_LCNN_BF16, 2.0 * 2.0 * T * (double)B * 4.0 * H * H, AFD_STREAM);
+    // the first step has no recurrent product (h_0 = 0)
+    timing.issued(2.0 * 2.0 * (T - 1) * (double)((B + 31) / 32 * 32) * 4.0 * H * H);
+    timing.bytes(2.0 * (2.0 * 4 * H * H) + (double)T * B * 4.0 * (2.0 * 4.0 * H + 2.0 * H));
+    hipLaunchKernelGGL(blstm_layer_bf16_kernel, dim3((unsigned)((B + 31) / 32), 2), dim3(kLstmWaves * 64), lds, AFD_STREAM,
+                       pre_fwd, pre_rev, static_cast<const __bf16*>(wh_fwd_bf16), static_cast<const __bf16*>(wh_rev_bf16), out,
+                       T, B, H);
+    return afd::check_launch("blstm_layer_bf16_kernel");
 }
 
 extern "C" int afd_lstm_step_bf16(const float* pre, const void* wh_bf16, const float* hprev, float* c, float* hout, int ldh,

@@ -103,8 +103,9 @@ CLASS_KERNELS = {
                     "adam_kernel", "normalize_kernel", "normalize_channels_kernel", "transpose_kernel", "moments_kernel"),
     "wpt": ("wpt_fused_kernel", "wpt_haar14_kernel", "wpt3_top_kernel", "wpt4_deep_kernel"),
     "stft": ("stft_mfma_kernel",),
-    "lcnn_bf16": ("lcnn_conv_nhwc_kernel", "lcnn_conv1_kernel", "gemm_nt_bf16_kernel", "conv_bf16_kernel",
-                  "lstm_step_bf16_kernel"),
+    "lcnn_bf16": ("lcnn_conv_nhwc_kernel", "lcnn_conv1_kernel", "lcnn_conv1_pool_kernel", "gemm_nt_bf16_kernel",
+                  "gemm_nt_bf16_128_kernel", "conv_bf16_kernel", "lstm_step_bf16_kernel", "lstm_step_bf16_pair_kernel",
+                  "blstm_layer_bf16_kernel"),
 }
 
 

@@ -510,15 +510,19 @@ int afd_gemm_nt_bf16(const float* A, const float* B, const float* bias, float* C
  *                           k = (ky K + kx) Cin + ci, followed by the folded fp32 bias.
  * afd_lcnn_conv1_nhwc_bf16: first layer, x fp32 [N][H][W] (one channel) -> y bf16 [N][Ho][Wo][Cout/2].
  * afd_lcnn_conv_nhwc_bf16 : K in {1, 3}, Cin in {32, 48, 64}: x bf16 [N][H][W][Cin] -> y bf16 [N][Ho][Wo][Cout/2].
+ *                           pool (both convolutions; round 5): 0 = as above; 1 = the MaxPool2d(2, 2) that follows the
+ *                           layer (models.py:87-107) runs in the epilogue and y is bf16 [N][Ho/2][Wo/2][Cout/2]; 2
+ *                           (afd_lcnn_conv_nhwc_bf16 only) = the same with y in fp32 (bf16-rounded values) -- the
+ *                           pre-pool tensor is never written, results bit-identical to conv + afd_lcnn_pool_nhwc_bf16.
  * afd_lcnn_pool_nhwc_bf16 : MaxPool2d(2, 2) (floor mode) on bf16 [N][H][W][C], C % 8 == 0; out_f32 != 0 writes
  *                           fp32 (the tensor that feeds the BLSTM layers as [N][H/2][(W/2) C]). */
 size_t afd_lcnn_prep_bytes(int Cin, int Cout, int K);
 int afd_lcnn_prep_conv_bf16(const float* w, const float* bias, const float* bn_mean, const float* bn_var, float eps,
                             void* wb_bb, int Cin, int Cout, int K, afd_stream_t stream);
 int afd_lcnn_conv1_nhwc_bf16(const float* x, const void* wb_bb, void* y, int N, int H, int W, int Cout, int K, int pad,
-                             afd_stream_t stream);
+                             int pool, afd_stream_t stream);
 int afd_lcnn_conv_nhwc_bf16(const void* x, const void* wb_bb, void* y, int N, int H, int W, int Cin, int Cout, int K,
-                            int pad, afd_stream_t stream);
+                            int pad, int pool, afd_stream_t stream);
 int afd_lcnn_pool_nhwc_bf16(const void* x, void* y, int N, int H, int W, int C, int out_f32, afd_stream_t stream);
 /* One step of an LSTM direction in evaluation (nn.LSTM inside BLSTMLayer, models.py:212-237), recurrent projection and
  * cell in one launch: gates = pre [B][4H] (input projection + biases of the step, order i | f | g | o) + hprev [B][H] .
@@ -532,6 +536,15 @@ int afd_lstm_step_bf16(const float* pre, const void* wh_bf16, const float* hprev
 int afd_lstm_step_bf16_pair(const float* const* pre, const void* const* wh_bf16, const float* const* hprev,
                             float* const* c, float* const* hout, int ldh, float* const* hnext, int B, int H,
                             afd_stream_t stream);
+/* A whole bidirectional layer in ONE launch (round 5): pre_fwd / pre_rev [T][B][4H] fp32 (input projections + biases of
+ * every step, time-major); out [T][B][2H] fp32 (forward half | reverse half of every step); h_0 = c_0 = 0.
+ * wh_*_bf16: weight_hh [4H][H] as bf16 in MATRIX-FRAGMENT order [H/8 tiles][H/16 k-steps][64 lanes][8]: element e of lane
+ * (hh = lane / 32, r = lane % 32) of (tile, k-step) is weight_hh[(r / 8) H + 8 tile + r % 8][16 k-step + 8 hh + e], i.e.
+ * weight_hh.view(4, H/8, 8, H/16, 2, 8).permute(1, 3, 4, 0, 2, 5) -- a wave's operand load is 1 KB of consecutive bytes.
+ * A workgroup owns 32 batch rows of one direction and walks the T steps alone (the recurrence couples only the units of
+ * one batch row): h in LDS, c in registers.  H a multiple of 16 up to 256.  Same arithmetic as afd_lstm_step_bf16. */
+int afd_blstm_layer_bf16(const float* pre_fwd, const float* pre_rev, const void* wh_fwd_bf16, const void* wh_rev_bf16,
+                         float* out, int T, int B, int H, afd_stream_t stream);
 /* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):
  * gates = saved pre-activation sums [B][4H] of the step, c / cprev = cell state after / before it
  * (cprev NULL = zero), dh = gradient reaching h_t (row stride lddh), dc = running cell-state

@@ -91,6 +91,28 @@ def test_gemm_nt_bf16():
     assert (got2.cpu().double() - (2 * ref_r - bias.double())).abs().max().item() <= 2e-5 * ref_r.abs().max().item()
 
 
+def test_gemm_nt_bf16_on_128_tiles():
+    """The 128 x 128-tile kernel (K % 32 == 0, 16-byte aligned rows) on ragged M and N, with and without accumulation,
+    against float64 on the bf16-rounded operands -- and equal to the 64 x 64 kernel's result (same rounding, same
+    accumulation order along K)."""
+    import os
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(333, 320, generator=g)
+    b = torch.randn(200, 320, generator=g)
+    bias = torch.randn(200, generator=g)
+    ref_r = _bf16_round(a) @ _bf16_round(b).t() + bias.double()
+    got = gemm_nt(a.cuda(), b.cuda(), bias.cuda(), bf16=True)
+    assert (got.cpu().double() - ref_r).abs().max().item() <= 1e-5 * ref_r.abs().max().item()
+    got2 = gemm_nt(a.cuda(), b.cuda(), None, out=got.clone(), accumulate=True, bf16=True)
+    assert (got2.cpu().double() - (2 * ref_r - bias.double())).abs().max().item() <= 2e-5 * ref_r.abs().max().item()
+    os.environ["AFD_GEMM_BF16_SMALL"] = "1"
+    try:
+        small = gemm_nt(a.cuda(), b.cuda(), bias.cuda(), bf16=True)
+    finally:
+        del os.environ["AFD_GEMM_BF16_SMALL"]
+    assert (got - small).abs().max().item() <= 1e-5 * ref_r.abs().max().item()
+
+
 def test_lcnn_bf16_eval_labels_and_logits():
     """BASELINE configs[4] precision: LCNN(precision="bf16") evaluation forward.  Bars (stated up front):
     class labels bit-exact on the reference fixture; logits within 3e-2 of the largest fp32 logit magnitude
@@ -239,11 +261,11 @@ def test_lcnn_nhwc_bf16_layers(cin, cout, k, pad, h, w, bn):
     if cin == 1:
         xc = x[:, 0].contiguous().cuda()
         _native.check(lib.afd_lcnn_conv1_nhwc_bf16(_native.ptr(xc), _native.ptr(buf), _native.ptr(y), n, h, w, cout, k, pad,
-                                                   _native.stream_ptr()), "conv1")
+                                                   0, _native.stream_ptr()), "conv1")
     else:
         xc = xq.permute(0, 2, 3, 1).contiguous().cuda()
         _native.check(lib.afd_lcnn_conv_nhwc_bf16(_native.ptr(xc), _native.ptr(buf), _native.ptr(y), n, h, w, cin, cout, k,
-                                                  pad, _native.stream_ptr()), "conv")
+                                                  pad, 0, _native.stream_ptr()), "conv")
     got = y.float().cpu().permute(0, 3, 1, 2).double()
     scale_ref = yr.abs().max().item()
     assert (got - yr).abs().max().item() <= 4.5e-3 * scale_ref
@@ -254,6 +276,18 @@ def test_lcnn_nhwc_bf16_layers(cin, cout, k, pad, h, w, bn):
                                                   _native.stream_ptr()), "pool")
         zr = torch.nn.functional.max_pool2d(y.float().cpu().permute(0, 3, 1, 2), 2, 2)
         assert torch.equal(z.float().cpu().permute(0, 3, 1, 2), zr)
+        # the pool in the convolution's epilogue (the four pixels of a window in the four lanes of a quad): the same
+        # values bit for bit -- rounding to bf16 is monotone, so it commutes with the maximum
+        if f32 and cin == 1:
+            continue  # the first layer has no fp32 form
+        zf = torch.full_like(z, float("nan"))
+        if cin == 1:
+            _native.check(lib.afd_lcnn_conv1_nhwc_bf16(_native.ptr(xc), _native.ptr(buf), _native.ptr(zf), n, h, w, cout, k,
+                                                       pad, 1, _native.stream_ptr()), "conv1 + pool")
+        else:
+            _native.check(lib.afd_lcnn_conv_nhwc_bf16(_native.ptr(xc), _native.ptr(buf), _native.ptr(zf), n, h, w, cin, cout,
+                                                      k, pad, 2 if f32 else 1, _native.stream_ptr()), "conv + pool")
+        assert torch.equal(zf, z), (f32, (zf.float() - z.float()).abs().max().item())
 
 
 def test_lstm_step_bf16_matches_the_two_launch_form():
@@ -277,5 +311,42 @@ def test_lstm_step_bf16_matches_the_two_launch_form():
         two = blstm_forward_bf16(x, m)
         one = blstm_forward_bf16(x, m, None, whh)
         ref, _ = m.double()(x.double())
-    assert (one - two).abs().max().item() <= 1e-5 * two.abs().max().item()
+    # `one` now runs the whole layer in one launch with hardware exp / reciprocal in the gates; h is rounded to bf16 for
+    # the next step's product, so a 1e-7 difference in a gate can flip a rounding (2^-9 relative of one h): the bar
+    # between two bf16 recurrences is a few bf16 ulp of the largest output, the mean difference stays tiny
+    assert (one - two).abs().max().item() <= 2e-3 * two.abs().max().item()
+    assert (one - two).abs().mean().item() <= 2e-5 * two.abs().max().item()
     assert (one.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("hidden,batch", [(256, 70), (64, 33), (32, 5)])
+def test_blstm_layer_in_one_launch_equals_the_stepwise_form(hidden, batch):
+    """afd_blstm_layer_bf16 (every step of both directions of a layer in one launch: h in LDS, c in registers) against
+    the per-step launches it replaces: the same bf16 operands and an fp32 cell (hardware exp / reciprocal in the layer
+    kernel) -- at the model's hidden size (256), with ragged batch blocks, and at small sizes."""
+    import os
+    from audiofakedetect import _native
+    from audiofakedetect.lcnn import blstm_forward_bf16
+    lib = _native.load()
+    torch.manual_seed(hidden + batch)
+    m = torch.nn.LSTM(2 * hidden, hidden, batch_first=True, bidirectional=True).cuda()
+    x = torch.randn(batch, 6, 2 * hidden, device="cuda")
+    whh = {}
+    for sfx in ("", "_reverse"):
+        w = getattr(m, "weight_hh_l0" + sfx).detach().contiguous()
+        wb = torch.empty(w.shape, dtype=torch.bfloat16, device="cuda")
+        _native.check(lib.afd_f32_to_bf16(_native.ptr(w), _native.ptr(wb), w.numel(), _native.stream_ptr()), "cvt")
+        whh[sfx] = wb
+    with torch.no_grad():
+        layer = blstm_forward_bf16(x, m, None, whh)
+        os.environ["AFD_LSTM_STEPWISE"] = "1"
+        try:
+            steps = blstm_forward_bf16(x, m, None, whh)
+        finally:
+            del os.environ["AFD_LSTM_STEPWISE"]
+        ref, _ = m.double()(x.double())
+    assert layer.shape == steps.shape == (batch, 6, 2 * hidden)
+    # two bf16 recurrences: a few bf16 ulp at the worst element (a flipped rounding of one h), tiny on average
+    assert (layer - steps).abs().max().item() <= 2e-3 * steps.abs().max().item()
+    assert (layer - steps).abs().mean().item() <= 2e-5 * steps.abs().max().item()
+    assert (layer.double() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
