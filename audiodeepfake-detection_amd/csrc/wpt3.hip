@@ -15,10 +15,20 @@
 #include "wpt_shared.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
 using namespace afd::wptc;
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a template argument
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // top levels
@@ -47,6 +57,23 @@ template <int L> struct Std3 {
         return n;
     }
     static constexpr int pitch_at(int k) { return padded_pitch(n_at(k), L); }
+    // Outputs per work item at level k (2^(k-2) parents in a half frame, both children of each): the smallest even run
+    // with which the level is ONE round of the 1024 threads.  Every level of a half frame holds about 5 500 positions
+    // whatever k, so pairs (W = 2) are 2.7 rounds -- three, the last one a quarter full -- and W = 4 is 1.36 rounds, two
+    // with the second a third full (which is why four outputs per item measured 1-2 % in round 4); W = 6 is 0.90-0.97 of
+    // a round for coif4 / sym5 / db8 (W = 10 at coif4's level 7, 14 at level 1).  The item's window is L + 2 (W - 1) samples: 1.5 LDS
+    // reads of 16 bytes per position instead of 3.5, and the index / address / bounds arithmetic of an item is paid once
+    // per W positions -- the kernel is bound by the SUM of its LDS and vector-instruction time (profiles/r05_frontend_floor.md).
+    // Levels 1 .. Ks-1 run lanes along the positions of a node: neighbouring lanes' windows start 2 W floats apart, and
+    // 16-byte LDS reads are conflict-free when W / 2 is odd (W = 6: 48-byte lane stride, the 16 lanes of a phase cover the
+    // 64 banks once; W = 8 would put lanes 0, 4, 8, 12 on the same banks).  The last level runs lanes along the NODES
+    // (pitch / 4 odd: conflict-free at any W).
+    static constexpr int run_at(int k) {
+        const int parents = k < 2 ? 1 : 1 << (k - 2);
+        for (int w = 6; w <= 14; w += (k == Ks ? 2 : 4))
+            if (parents * ((n_at(k) + w - 1) / w) <= kTopThreads) return w;
+        return 14;
+    }
     static constexpr long size_at(int k) { return (k == 0 ? 1L : (1L << (k - 1))) * pitch_at(k); }
     static constexpr int off_at(int k) { return (k & 1) && k < Ks ? (int)((kTopLdsFloats - size_at(k)) & ~3L) : 0; }
 };
@@ -108,6 +135,9 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         if (j >= 1 && j <= PAD + (pN & 1)) X0[pN - 1 + j] = xg[pN - 1 - j];
     }
     __syncthreads();
+#if defined(AFD_TOP_STOP)
+    if (AFD_TOP_STOP == 0) { if (tid == 0) p.dst[blockIdx.x] = lds[off_of(0) + PAD + 5]; return; }
+#endif
 
     // ---- level 1: this workgroup's child of the frame (h = 0 low-pass, 1 high-pass) ----
     if (pKs == 1) return;  // not built: the caller keeps one-level transforms on the first-generation kernel
@@ -116,21 +146,39 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         float* node = lds + off_of(1) + PAD;
         const int n1 = n_of(1);
         const float* taps = h ? p.rhi : p.rlo;
-        for (int j = tid; 2 * j < n1; j += kTopThreads) {
-            Window<L> win;
-            win.load(src + 4 * j);
-            put<L>(node, 2 * j, n1, win.template dot<0>(taps));
-            if (2 * j + 1 < n1) put<L>(node, 2 * j + 1, n1, win.template dot<1>(taps));
+        if constexpr (STD) {
+            // one round: every thread a run of W1 outputs of the one child (14 for the standard frame: a 50-sample window)
+            constexpr int W1 = SG::run_at(1);
+            constexpr int items = (SG::n_at(1) + W1 - 1) / W1;
+            static_assert(items <= kTopThreads, "level 1 is one round of the workgroup");
+            if (tid < items) {
+                const int i = W1 * tid;
+                Window<L, W1> win;
+                win.load(src + 2 * i);
+                float c1[W1];
+                static_for<W1>([&](auto u) { c1[u.value] = win.template dot<u.value>(taps); });
+#pragma unroll
+                for (int u = 0; u < W1; ++u)
+                    if (i + u < n1) put<L>(node, i + u, n1, c1[u]);
+            }
+        } else {
+            for (int j = tid; 2 * j < n1; j += kTopThreads) {
+                Window<L> win;
+                win.load(src + 4 * j);
+                put<L>(node, 2 * j, n1, win.template dot<0>(taps));
+                if (2 * j + 1 < n1) put<L>(node, 2 * j + 1, n1, win.template dot<1>(taps));
+            }
         }
     }
     __syncthreads();
+#if defined(AFD_TOP_STOP)
+    if (AFD_TOP_STOP == 1) { if (tid == 0) p.dst[blockIdx.x] = lds[off_of(1) + PAD + 5]; return; }
+#endif
 
     // ---- levels 2 .. Ks-1: both children of every node, lanes along the output index ----
-    // W outputs of both children per work item.  W = 4 (index arithmetic, loads and border checks paid once per four
-    // outputs) measured 1-2 % ahead in the STD instance and level with run-time geometry -- not worth reading 8 more
-    // floats past a node's last item
-    constexpr int W = 2;
-    auto level = [&](const int k) {
+    // W outputs of both children per work item (Std3::run_at for the compile-time geometry, pairs otherwise)
+    auto level = [&](const int k, auto wtag) {
+        constexpr int W = decltype(wtag)::value;
         const int Mp = 1 << (k - 2);  // parents (nodes of level k-1 in this half)
         const int nk = n_of(k);
         const int mk = (nk + W - 1) / W;  // items per node
@@ -146,12 +194,10 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
             Window<L, W> win;
             win.load(src0 + q * pin + 2 * i);
             float ca[W], cd[W];
-            ca[0] = win.template dot<0>(p.rlo); cd[0] = win.template dot<0>(p.rhi);
-            ca[1] = win.template dot<1>(p.rlo); cd[1] = win.template dot<1>(p.rhi);
-            if constexpr (W == 4) {
-                ca[2] = win.template dot<2>(p.rlo); cd[2] = win.template dot<2>(p.rhi);
-                ca[3] = win.template dot<3>(p.rlo); cd[3] = win.template dot<3>(p.rhi);
-            }
+            static_for<W>([&](auto u) {
+                ca[u.value] = win.template dot<u.value>(p.rlo);
+                cd[u.value] = win.template dot<u.value>(p.rhi);
+            });
             // odd-frequency parents list their children (d, a)
             const int par = (k == 2) ? h : (q & 1);
             float* na = dst0 + (2 * q + par) * pout;
@@ -185,9 +231,20 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         __syncthreads();
     };
     if constexpr (STD) {  // six inlined copies with a constant level: every length, pitch and offset folds
-        level(2); level(3); level(4); level(5); level(6); level(7);
+        level(2, std::integral_constant<int, SG::run_at(2)>{}); level(3, std::integral_constant<int, SG::run_at(3)>{});
+#if defined(AFD_TOP_STOP)
+        if (AFD_TOP_STOP == 3) { if (tid == 0) p.dst[blockIdx.x] = lds[off_of(3) + PAD + 5]; return; }
+#endif
+        level(4, std::integral_constant<int, SG::run_at(4)>{}); level(5, std::integral_constant<int, SG::run_at(5)>{});
+#if defined(AFD_TOP_STOP)
+        if (AFD_TOP_STOP == 5) { if (tid == 0) p.dst[blockIdx.x] = lds[off_of(5) + PAD + 5]; return; }
+#endif
+        level(6, std::integral_constant<int, SG::run_at(6)>{}); level(7, std::integral_constant<int, SG::run_at(7)>{});
+#if defined(AFD_TOP_STOP)
+        if (AFD_TOP_STOP == 7) { if (tid == 0) p.dst[blockIdx.x] = lds[off_of(7) + PAD + 5]; return; }
+#endif
     } else {
-        for (int k = 2; k < pKs; ++k) level(k);
+        for (int k = 2; k < pKs; ++k) level(k, std::integral_constant<int, 2>{});
     }
 
     // ---- level Ks: lanes along the nodes, results leave the chip packet-contiguous ----
@@ -196,7 +253,8 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         const int logM = k - 2;  // parents in this half: 2^(k-2)
         const int Mp = 1 << logM;
         const int nk = n_of(k);
-        const int total = ((nk + 1) >> 1) << logM;
+        constexpr int WL = STD ? SG::run_at(SG::Ks) : 2;  // outputs per item (one round of the workgroup in the STD instance)
+        const int total = ((nk + WL - 1) / WL) << logM;
         const float* src0 = lds + off_of(k - 1);
         const int pin = pitch_of(k - 1);
         const size_t P = (size_t)1 << k;
@@ -205,16 +263,16 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
         float* outb = p.dst + (size_t)b * nch * chan;
         for (int idx = tid; idx < total; idx += kTopThreads) {
             const int q = idx & (Mp - 1);
-            const int i = 2 * (idx >> logM);
-            Window<L> win;
+            const int i = WL * (idx >> logM);
+            Window<L, WL> win;
             win.load(src0 + q * pin + 2 * i);
             const int par = (k == 2) ? h : (q & 1);  // odd-frequency parents list their children (d, a)
             float* o = outb + (size_t)i * P + 2 * ((size_t)(h << logM) + q);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            static_for<WL>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
                 if (i + u < nk) {
-                    const float ca = u ? win.template dot<1>(p.rlo) : win.template dot<0>(p.rlo);
-                    const float cd = u ? win.template dot<1>(p.rhi) : win.template dot<0>(p.rhi);
+                    const float ca = win.template dot<u>(p.rlo);
+                    const float cd = win.template dot<u>(p.rhi);
                     f2 v;
                     v.x = par ? cd : ca;
                     v.y = par ? ca : cd;
@@ -233,7 +291,7 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
                         }
                     }
                 }
-            }
+            });
         }
     }
 }

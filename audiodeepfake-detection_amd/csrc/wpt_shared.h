@@ -57,10 +57,9 @@ __device__ __forceinline__ void put(float* node, int i, int n, float v) {
     if ((unsigned)(n - 2 - i) < (unsigned)(PAD + (n & 1))) node[2 * (n - 1) - i] = v;
 }
 
-// A work item is a PAIR of neighbouring outputs (i, i + 1), i even: their windows share L - 2 of L samples,
-// so the item reads L + 2 samples as 16-byte vectors (7 ds_read_b128 for 24 taps, lanes 16 bytes apart:
-// conflict-free) and both filters run over registers.
-// (W outputs per item: W = 2 above; the compile-time-geometry levels of the top kernel take W = 4 -- L + 6 samples)
+// A work item is a run of W neighbouring outputs i .. i + W - 1, i even: their windows overlap, so the item reads
+// L + 2 (W - 1) samples as 16-byte vectors and both filters run over registers.  W = 2: 7 ds_read_b128 for 24 taps, 3.5
+// per output position; W = 6: 9 reads, 1.5 per position (the compile-time-geometry levels of the top kernel, round 5).
 template <int L, int W = 2>
 struct Window {
     static constexpr int NV = (L + 2 * (W - 1) + 3) / 4;
@@ -127,8 +126,10 @@ template <> struct HasShape3<16> { static constexpr bool value = true; };
 // node pitch (floats) of an LDS image whose nodes carry their reflect pads:
 // [L-2 left pad | n samples | L-2 (+1) right pad | up to 3 floats an odd node's last item reads], 16-byte aligned
 // nodes, pitch / 4 odd (node-strided 16-byte reads hit distinct banks)
+// (round 5: a work item of the top kernel covers up to 14 output positions, its window reaches 2 (14 - 1) + 3 floats past
+// the last sample an item of a node's last positions needs: 31 floats of slack instead of 5)
 constexpr int padded_pitch(int n, int L) {
-    int pitch = n + 2 * (L - 2) + 5;
+    int pitch = n + 2 * (L - 2) + 31;
     while (pitch % 8 != 4) ++pitch;
     return pitch;
 }

@@ -106,6 +106,15 @@ print("""
   as the arithmetic.  Four outputs per work item (L + 6 samples per four positions, half the index arithmetic) measured
   1-2 % in round 4: neither stream alone is the limiter, their sum is (LDS reads and vector instructions of a wave do
   not overlap with each other when every wave runs the same read -> multiply -> store sequence between two barriers).
+* **Where the top kernel's time goes, stage by stage** (round 5, `tools/top_stages.py`: builds that return after level k,
+  B = 4096, us per launch): coif4 -- frame -> LDS 95, level 1 +93, levels 2-3 +138, 4-5 +142, 6-7 +164, level 8 + store
+  +125 = 757; sym5 -- 96, +51, +72, +79, +97, +71 = 466.  A level costs 70-80 us (coif4) / 36-49 us (sym5) against 35 / 14 us
+  of packed FMAs: every level is one pass read window -> multiply -> store -> barrier over the whole workgroup, so the
+  LDS phase (16 waves x 9 reads x 8 cycles) and the arithmetic phase do not overlap, and one 1024-thread workgroup per CU
+  (it needs the whole LDS) has no second workgroup to fill the gaps; the frame load alone (one round of memory latency
+  with nothing to hide it) is 12-20 % of the kernel.  Runs of 6-14 outputs per work item (Std3::run_at: every level one
+  round of the threads, 1.5 instead of 3.5 LDS reads per position) bought 1 % (coif4) / 7 % (sym5): neither stream is the
+  limiter, the serialisation is.
 * **The deep kernel's LDS bank conflicts** (`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` = 0.44 coif4, 0.32 sym5) sit in the
   lane-strided 8-byte reads of the multi-lane levels 8 -> 12 (lane stride 2 R floats); those levels are 0.56 of the
   kernel's 1.7 ms and LDS-active cycles are 25 % of its SIMD cycles -- removing every conflict is worth at most 0.1 ms.
