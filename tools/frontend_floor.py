@@ -115,6 +115,13 @@ print("""
   with nothing to hide it) is 12-20 % of the kernel.  Runs of 6-14 outputs per work item (Std3::run_at: every level one
   round of the threads, 1.5 instead of 3.5 LDS reads per position) bought 1 % (coif4) / 7 % (sym5): neither stream is the
   limiter, the serialisation is.
+* **Hiding the frame load behind the previous item was built and rejected**: a persistent grid (one workgroup per CU walking
+  32 (frame, half) items at B = 4096) with the next item's frame requested into 11 + 1 registers per thread right after
+  level 1 and stored to LDS at the top of the next iteration -- parity green, 2.40 -> 2.64 ms (coif4) / 1.05 -> 1.19 ms
+  (sym5) at B = 4096.  The same binary launched one workgroup per item is also slower than the kernel without the loop
+  (2.56 / 1.14 ms: the prefetch registers push the kernel to 111 of the 128 registers a 1024-thread workgroup may use, and
+  the item loop invites the compiler to hoist every level's lane addresses out of it -- 128 registers and 2.4 x slower
+  until the thread index was made opaque per item), and the static item assignment loses to the dispatcher's dynamic one.
 * **The deep kernel's LDS bank conflicts** (`SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE` = 0.44 coif4, 0.32 sym5) sit in the
   lane-strided 8-byte reads of the multi-lane levels 8 -> 12 (lane stride 2 R floats); those levels are 0.56 of the
   kernel's 1.7 ms and LDS-active cycles are 25 % of its SIMD cycles -- removing every conflict is worth at most 0.1 ms.
