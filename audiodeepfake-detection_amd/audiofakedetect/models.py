@@ -89,6 +89,9 @@ class DCNN(nn.Module):
             # STFT features are dense [B, C, F, T]: one tiled transpose on the GPU
             h = ops.transpose_contiguous(x.contiguous())
         cnn = self.cnn
+        # the fused units this forward pass runs, in order: one entry per launch group (read by tests / tools through
+        # `last_plan`; the decisions themselves are the branches below -- shape and mode decide, nothing is cached)
+        plan_log = self.last_plan = []
         pending_bn = None  # a BatchNorm waiting to be folded into the 1x1 convolution after it
         link = None        # hand-over of a gradient term from block 2's backward to block 1's
         bn_link = None     # from a BatchNorm to the 3x3 convolution after it: that layer's backward-data launch
@@ -103,6 +106,7 @@ class DCNN(nn.Module):
                     and conv.dilation == (1, 1) and not h.requires_grad):
                 # single-channel first block: conv + PReLU + pool in one kernel
                 link = {} if fold_next else None
+                plan_log.append(f"block{step + 1}: conv1+prelu+pool" + (" | bn folded into the next 1x1" if fold_next else ""))
                 h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0], link)
                 if fold_next:
                     pending_bn = cnn[bn_i]
@@ -116,6 +120,8 @@ class DCNN(nn.Module):
                 bn_link = {}
                 # (the second BatchNorm's result is not stored when block 3's convolution can build it while it loads)
                 zshape = (h.shape[0], conv.out_channels, h.shape[2], h.shape[3])
+                plan_log.append(f"block{step + 1}: bn+conv1x1+prelu+bn one-pass backward"
+                                + (" | bn applied by the next conv" if self._next_normalises(step, zshape) else ""))
                 h = ops.bn_conv1x1_prelu_bn(h, pending_bn, conv.weight, conv.bias, slope, cnn[bn_i],
                                             self.sync_bn, link, bn_link, self._next_normalises(step, zshape))
                 pending_bn = link = None
@@ -127,12 +133,16 @@ class DCNN(nn.Module):
             pool_link = {} if (pooled and bn_i is not None and not fold_next) else None
             if pending_bn is not None:
                 # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
+                plan_log.append(f"block{step + 1}: bn folded into conv1x1")
                 z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)
                 pending_bn = None
             elif pooled and ops.conv3x3_prelu_maxpool_applicable(h, conv):
                 # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue: the conv output is never written
                 if pool_link is not None and self.training:
                     pool_link["want_stats"] = True  # the BatchNorm behind it takes its batch sums from that launch
+                plan_log.append(f"block{step + 1}: conv3x3+prelu+pool (winograd epilogue)"
+                                + (" | input bn applied on load" if in_link and in_link.get("fold") is not None else "")
+                                + (" | bn sums from the epilogue" if pool_link and pool_link.get("want_stats") else ""))
                 h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link, pool_link)
                 fused_pool = True
             else:
@@ -142,10 +152,14 @@ class DCNN(nn.Module):
                 if sum_link is not None and self.training:
                     sum_link["want_stats"] = True  # the BatchNorm of PReLU(z) takes its batch sums from this launch
                     sum_link["stats_slope"] = slope
+                plan_log.append(f"block{step + 1}: conv{conv.kernel_size[0]}x{conv.kernel_size[1]}"
+                                + (" | input bn applied on load" if in_link and in_link.get("fold") is not None else "")
+                                + (" | bn sums from the epilogue" if sum_link and sum_link.get("want_stats") else ""))
                 z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled,
                                bn_link=in_link, out_link=sum_link)
             if pooled:
                 if not fused_pool:
+                    plan_log.append(f"block{step + 1}: prelu+pool pass")
                     h = ops.prelu_maxpool2x2(z, slope, pool_link)
                 if fold_next:
                     pending_bn = cnn[bn_i]

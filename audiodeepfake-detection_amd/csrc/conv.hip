@@ -425,11 +425,6 @@ IgemmCfg pick_cfg(int co_pad) {
         case 3: c = {3, 1, 4, 1}; break;   // 96 ch  x 128 px, 4 waves
         default: c = {2, 2, 2, 1}; break;  // 128 ch x 128 px, 2 x 2 waves
     }
-    // development override: AFD_IGEMM_CFG="MW,NW,WNB,two"
-    if (const char* e = getenv("AFD_IGEMM_CFG")) {
-        int a, b, d, t;
-        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &d, &t) == 4 && (co_pad / 32) % a == 0) c = {a, b, d, t};
-    }
     return c;
 }
 
@@ -814,8 +809,8 @@ bool wgrad_swap_applicable(int Cin, int H, int W, int Cout, int K, int pad, int 
     if (K != 3 || pad != 1 || dil != 1 || dy_rows < H || dy_cols < W) return false;
     if (Cin % 32 != 0 || Cin > 128 || Cout % 32 != 0 || ((size_t)H * W) % 4 != 0) return false;
     // measured: one channel tile of Cout, and 96 -> 128 channels, whose swapped form runs on the 64-channel workgroups
-    const bool pays = (Cout == 32 && Cin >= 64) || (Cin == 96 && Cout == 128 && !getenv("AFD_NO_WGRAD_SWAP4"));
-    if (!pays && !getenv("AFD_WGRAD_SWAP_ALL")) return false;
+    const bool pays = (Cout == 32 && Cin >= 64) || (Cin == 96 && Cout == 128);
+    if (!pays) return false;
     return afd::wgrad3x3_applicable(Cout, H, W, Cin, K, pad, dil);
 }
 
@@ -883,8 +878,8 @@ int plan_wgrad(WgradGeom& wg, int N, int Cin, int H, int W, int Cout, int K, int
     wg.NG = NG;
     {
         const int nthreads = wg.MT * wg.NG * 64;
-        wg.fast_stage = getenv("AFD_WGRAD_FAST") != nullptr && (g.CO_PAD <= kZV * (nthreads / 64)) &&
-                        ((long)ct * g.PR * g.PC <= (long)kPW * nthreads) && pix == 64;
+        (void)nthreads;
+        wg.fast_stage = false;  // the register-staged variant measured slower (round 1) and is never selected
     }
     wg.totalTiles = (long)N * g.tilesX * g.tilesY;
     long S = 1024 / g.nchunks;
@@ -1290,7 +1285,7 @@ int plan_wgrad2(Wgrad2Geom& w2, int N, int Cin, int H, int W, int Cout, int K, i
     wg.S = (int)S;
     if ((size_t)g.CO_PAD * Hout * Wout >= 0x7fffffffULL || (size_t)ct * H * W >= 0x7fffffffULL)
         return AFD_ERR_UNSUPPORTED;  // 32-bit element offsets inside a tile
-    { const char* e = getenv("AFD_W2_DBG"); w2.dbg = e ? atoi(e) : 0; }
+    w2.dbg = 0;
     return AFD_OK;
 }
 
@@ -1327,7 +1322,7 @@ int launch_wgrad2(const Wgrad2Geom& w2, const float* x, const float* dz, float* 
     return afd::fail(AFD_ERR_UNSUPPORTED, "wgrad: %d pairs per wave", w2.TPW);
 }
 
-bool use_wgrad2() { return getenv("AFD_WGRAD_V1") == nullptr; }
+bool use_wgrad2() { return true; }
 
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 

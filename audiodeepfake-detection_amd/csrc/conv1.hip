@@ -343,7 +343,7 @@ extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, c
     timing.bytes(bwd_bytes);
     hipLaunchKernelGGL(conv1_pool_bwd_kernel, dim3(CG, S), dim3(kT), 0, AFD_STREAM, x, du, idx, u, slope,
                        partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles, alpha, beta,
-                       (CG == 8 && S % 8 == 0 && !getenv("AFD_CONV1_BWD_ROWMAJOR")) ? 1 : 0);
+                       (CG == 8 && S % 8 == 0) ? 1 : 0);
     const int total = CG * kCG * 11;
     hipLaunchKernelGGL(conv1_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, AFD_STREAM, partial,
                        dw, dbias, dslope, Cout, CG, S);

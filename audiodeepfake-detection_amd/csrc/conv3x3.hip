@@ -272,12 +272,8 @@ int launch3(G3 g, const float* x, const float* wp, const float* bias, float* y, 
     g.tilesY = (g.Hc + TH - 1) / TH;
     const long blocks = (long)g.N * g.tilesY * g.tilesX;
     if (blocks > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv3x3: grid too large");
-    if (getenv("AFD_C33_TWO"))
-        hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, true, TW>), dim3((unsigned)blocks),
-                           dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
-    else
-        hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, false, TW>), dim3((unsigned)blocks),
-                           dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
+    hipLaunchKernelGGL((conv3x3_kernel<MW, NW, WMB, WNB, false, TW>), dim3((unsigned)blocks),
+                       dim3(WMB * WNB * 64), 0, s, g, x, wp, bias, y);
     return afd::check_launch("conv3x3_kernel");
 }
 
@@ -799,14 +795,14 @@ struct WgCols {
 // mt = 32-channel tiles of Cout.  Measured at B = 32 (new vs general kernel, 32 input channels per workgroup): mt 4 1.70 vs 1.80 ms (the
 // general kernel spills 116 registers there), mt 3 3.73 vs 3.46, mt 2 0.34 vs 0.31, mt 1 0.87 vs 0.72 ms --
 // two workgroups of four waves cover each other's loads better than one of eight covers its own, so
-// only the 128-channel layer takes the split; AFD_WGRAD3X3P=1 forces it for every layer (A/B runs).
+// only the 128-channel layer takes the split.
 WgCols wgrad_cols(int W, int wc, int mt, int cin) {
     WgCols c{};
     c.tilesX = (wc + 63) / 64;
     // the 96-channel layer on 64 input channels per workgroup (54 pairs on 8 waves, dz staged once): 12.4 -> 11.1 ms
     // at level 14; for one channel tile of Cout the same change measured level (2.9 ms)
-    const bool ct64 = mt == 3 && cin % 64 == 0 && !getenv("AFD_NO_WGRAD_CT64");
-    if (W < 1024 || getenv("AFD_NO_WGRAD3X3P") || (mt != 4 && !getenv("AFD_WGRAD3X3P") && !ct64)) return c;
+    const bool ct64 = mt == 3 && cin % 64 == 0;
+    if (W < 1024 || getenv("AFD_NO_WGRAD3X3P") || (mt != 4 && !ct64)) return c;
     int last = 0;
     for (int tx = 1; tx < c.tilesX; ++tx)
         if (tx * 64 + 64 + 3 <= W) last = tx;
@@ -916,7 +912,7 @@ int wgrad3x3_launch(const float* x, const float* dz, float* part, float* partb, 
     int rc;
     if (mt == 1) rc = launchw_p<1>(g, x, dz, part, partb, s);
     else if (mt == 2) rc = launchw_p<2>(g, x, dz, part, partb, s);
-    else if (mt == 3) rc = (!getenv("AFD_NO_WGRAD_CT64") && Cin % 64 == 0) ? launchw_p<3, 64>(g, x, dz, part, partb, s)
+    else if (mt == 3) rc = (Cin % 64 == 0) ? launchw_p<3, 64>(g, x, dz, part, partb, s)
                                                                             : launchw_p<3>(g, x, dz, part, partb, s);
     else rc = launchw_p<4>(g, x, dz, part, partb, s);
     if (rc) return rc;

@@ -182,7 +182,7 @@ constexpr size_t wgrad_lds_bytes(int C, int K, int DIL, int ROWS) {
 // One wave per kernel row ky.  Three LDS images: while tile t is consumed, the rows of tiles t+1 and t+2 are in
 // flight (row_to_lds; every wave issues the same number of loads per tile -- surplus row slots and tiles past the end
 // are loads from an empty descriptor -- so "tile t has landed" is s_waitcnt vmcnt(loads per tile)).
-template <int C, int K, int DIL, int ROWS, int ABL = 0>  // ABL (ablation runs): 1 no loads, 2 no arithmetic
+template <int C, int K, int DIL, int ROWS, int ABL = 0>  // ABL: ablation builds (1 no loads, 2 no arithmetic), never launched
 __global__ void __launch_bounds__(64 * K)
 dilconv_wgrad_kernel(const DirGeom g, const float* __restrict__ x, const float* __restrict__ dy,
                      float* __restrict__ partial, int ntiles) {
@@ -383,25 +383,6 @@ int launch_wgrad(const DirGeom& g, const float* x, const float* dy, float* parti
         reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
         (int)lds);
     if (attr != hipSuccess) return afd::fail(AFD_ERR_HIP, "dilconv wgrad: %zu bytes of LDS refused", lds);
-    // ablation runs (AFD_DILW_ABL = 1: no loads, 2: no arithmetic; the time of each part is quoted in DESIGN.md)
-    static const int abl = [] { const char* e = getenv("AFD_DILW_ABL"); return e ? atoi(e) : 0; }();
-    if (abl && C == 3) {
-        hipError_t e;
-        if (abl == 1) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS, 1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS, 1>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy,
-                                   partial, ntiles);
-        } else {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dilconv_wgrad_kernel<C, K, DIL, ROWS, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess)
-                hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS, 2>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy,
-                                   partial, ntiles);
-        }
-        return e == hipSuccess ? 0 : afd::fail(AFD_ERR_HIP, "dilconv wgrad (ablation): %s", hipGetErrorString(e));
-    }
     hipLaunchKernelGGL((dilconv_wgrad_kernel<C, K, DIL, ROWS>), dim3(blocks), dim3(64 * K), lds, s, g, x, dy, partial,
                        ntiles);
     return 0;

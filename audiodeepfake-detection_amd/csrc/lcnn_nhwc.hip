@@ -632,7 +632,7 @@ extern "C" int afd_lcnn_conv1_nhwc_bf16(const float* x, const void* wb_bb, void*
     timing.bytes((double)N * (4.0 * H * W + 2.0 * (pool ? (double)g.PH * g.PW : (double)g.Ho * g.Wo) * g.half));
     const unsigned grid = (unsigned)(g.N * g.tiles);
     __bf16* yb = static_cast<__bf16*>(y);
-    if (pool && K == 5 && g.Kpad == 32 && 2 * g.HP == 64 && N <= 65535 && !getenv("AFD_LCNN_CONV1_GATHER")) {
+    if (pool && K == 5 && g.Kpad == 32 && 2 * g.HP == 64 && N <= 65535) {
         // the model's first layer (5 x 5, 64 channels): patch in LDS; its grid is 4 x 8-window blocks of the pooled image
         timing.issued(2.0 * N * (double)((g.PW + 7) / 8) * ((g.PH + 3) / 4) * kPixT * 2 * g.HP * g.Kpad);
         hipLaunchKernelGGL((lcnn_conv1_pool_kernel<2, 5>), dim3((g.PW + 7) / 8, (g.PH + 3) / 4, N), dim3(kThr), 0, AFD_STREAM, g, x,

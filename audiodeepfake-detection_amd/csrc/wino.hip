@@ -549,11 +549,10 @@ int wino_run(const float* x, const float* w, const float* bias, float* y, int N,
     int rc = afd::check_launch("wino_weights_kernel");
     if (rc) return rc;
     timing.bytes(4.0 * N * ((double)Cin * H * W + (double)Cout * g.rows * g.cols / (u ? 4.0 : 1.0)));
-    const bool wide = !getenv("AFD_WINO_NT1");
     switch (MT) {
-        case 1: return wide ? launch_wino<1, 2>(g, x, U, bias, y, s) : launch_wino<1, 1>(g, x, U, bias, y, s);
-        case 2: return wide ? launch_wino<2, 2>(g, x, U, bias, y, s) : launch_wino<2, 1>(g, x, U, bias, y, s);
-        case 3: return wide ? launch_wino<3, 2>(g, x, U, bias, y, s) : launch_wino<3, 1>(g, x, U, bias, y, s);
+        case 1: return launch_wino<1, 2>(g, x, U, bias, y, s);
+        case 2: return launch_wino<2, 2>(g, x, U, bias, y, s);
+        case 3: return launch_wino<3, 2>(g, x, U, bias, y, s);
         case 4: return launch_wino<4, 1>(g, x, U, bias, y, s);
     }
     return afd::fail(AFD_ERR_UNSUPPORTED, "winograd conv: Cout %d > 128", Cout);
@@ -568,7 +567,6 @@ extern "C" int afd_conv3x3_backward_data_bnstats_applicable(int Cin, int H, int 
     if (getenv("AFD_NO_BWD_BNSTATS")) return 0;
     if (afd::wino44_applicable(Cout, H, W, Cin)) return 1;
     if (!afd::wino_applicable(Cout, H, W, Cin)) return 0;
-    if (getenv("AFD_WINO_NT1")) return 0;
     const int mt = (Cin + 31) / 32;
     return mt == 2 || mt == 3;
 }

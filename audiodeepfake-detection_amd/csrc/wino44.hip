@@ -65,8 +65,8 @@ struct G4 {
     // bn_apply_fwd_kernel's arithmetic (bit-identical values), so the normalised tensor is never written or read
     const float* in_aff;
     const float* in_slope;
-    int noflip;  // development switch AFD_WINO44_NO_FLIP: see the kernel's wave roles
-    int xcd_map;  // XCD-aware workgroup order (AFD_WINO44_XCDM; 16 by default, 0 / 1 = plain row-major): see the kernel
+    int noflip;  // (development) keep the helper waves of the second workgroup of a CU last: see the kernel's wave roles
+    int xcd_map;  // workgroup columns per XCD group (16; 0 / 1 = plain row-major order): see the kernel
     // BatchNorm backward in the epilogue (backward-data launches with the statistics epilogue; round 4): the result g is the
     // gradient of a training-mode BatchNorm(affine=False) output whose backward sums are known BEFORE the launch
     // (afd_conv3x3_input_grad_sums, afd_conv_weight_dot): bn_tab [C][4] = (mean, invstd, mean of g, mean of g * xhat),
@@ -203,45 +203,19 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // XCD has its own L2: in plain row-major order a workgroup's column neighbours -- which share the 128-byte lines its
     // 264-byte row segments start and end in -- sit on other XCDs, and every shared line is fetched once per XCD (round 5:
     // the read requests by size, profiles/r05_pmc_traffic_*, show the class moving 2.0 x its algorithmic bytes).
-    // xcd_map = m > 1: in every group of 8 m consecutive ids XCD x takes the m consecutive logical ids x m .. x m + m - 1,
+    // xcd_map = m: in every group of 8 m consecutive ids XCD x takes the m consecutive logical ids x m .. x m + m - 1,
     // i.e. m neighbouring workgroup columns of one tile row.  Measured on the level-14 step (same box, alternating runs,
     // tools/ab_env.py): row-major 20.26-20.41 ms for the class, m = 2 / 4 / 16 / 32 / 64: 20.21 / 20.18 / 20.08-20.15 /
     // 20.12 / 20.29 -- the default is 16.  The order that also keeps the tile rows of a column block on one XCD (negative
     // values: tile row fastest inside the group, or over a whole eighth of the grid) costs 1.5 ms at every group size:
     // 21.7-22.0 ms -- the launch then reads four times as many image rows at once in windows a quarter as wide; what the
     // memory side rewards is few, wide streams, not fewer bytes (the class draws 2.4 TB/s, far from the HBM's limit).
-    int id = blockIdx.x;
-    int wi, ty, n;
-    if (g.xcd_map < 0) {
-        // as below, with the logical order running tile row fastest: an XCD's m ids are m / tilesY columns x every tile row
-        const int m = -g.xcd_map, grp = 8 * m;
-        const int base = id / grp * grp;
-        if (base + grp <= (int)gridDim.x) {
-            const int p = id - base;
-            id = base + (p & 7) * m + (p >> 3);
-        }
-        ty = id % g.tilesY;
-        id /= g.tilesY;
-        wi = id % g.wxCount;
-        n = id / g.wxCount;
-    } else if (g.xcd_map > 1) {
-        // groups of 8 m consecutive ids: XCD x takes the m consecutive logical ids x m .. x m + m - 1 of the group
-        const int m = g.xcd_map, grp = 8 * m;
-        const int base = id / grp * grp;
-        if (base + grp <= (int)gridDim.x) {
-            const int p = id - base;
-            id = base + (p & 7) * m + (p >> 3);
-        }
-        wi = id % g.wxCount;
-        id /= g.wxCount;
-        ty = id % g.tilesY;
-        n = id / g.tilesY;
-    } else {
-        wi = id % g.wxCount;
-        id /= g.wxCount;
-        ty = id % g.tilesY;
-        n = id / g.tilesY;
-    }
+    // (afd::xcd_grouped_id; the tile-row-fastest orders of the measurement above are not in the tree)
+    int id = afd::xcd_grouped_id((int)blockIdx.x, (int)gridDim.x, g.xcd_map);
+    const int wi = id % g.wxCount;
+    id /= g.wxCount;
+    const int ty = id % g.tilesY;
+    const int n = id / g.tilesY;
     const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
     const int tx0 = wx * kTiles;
     const bool skip5 = g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
@@ -777,10 +751,7 @@ namespace afd {
 // this was 256: border workgroups fetched their patches element by element, and on the 64- / 129-wide level-8 and
 // STFT images every workgroup is a border workgroup.  With the interior's vector loads there (load_patch) the
 // level-8 / STFT steps gain 10 % from F(4x4): 7.6 / 6.8 / 7.3 -> 6.8 / 6.2 / 6.6 ms.
-static int min_width44() {
-    const char* e = getenv("AFD_WINO44_MINW");
-    return e ? atoi(e) : 48;
-}
+static int min_width44() { return 48; }
 
 bool wino44_applicable(int Cin, int H, int W, int Cout) {
     if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44")) return false;
@@ -800,7 +771,7 @@ bool wino44_applicable(int Cin, int H, int W, int Cout) {
 // the pooled forward layer with 96 output channels (block 3): six waves, i.e. two SIMDs carry two waves -- still
 // ahead of the F(2x2) kernel there (6.8 -> ? ms at level 14)
 bool wino44_pool_applicable(int Cin, int H, int W, int Cout) {
-    if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44") || getenv("AFD_NO_WINO44_POOL")) return false;
+    if (getenv("AFD_NO_WINOGRAD") || getenv("AFD_NO_WINO44")) return false;
     // (and block 6, 32 -> 64 channels on four waves: 0.82 -> 0.69 ms)
     if (Cin % kCh != 0 || (Cout != 96 && Cout != 64)) return false;
     if (W < min_width44() || H < 4) return false;
@@ -838,8 +809,8 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     g.slope = slope; g.u = u; g.idx = idx;
     g.pidx = pooled_codes; g.Hp = H / 2; g.Wp = W / 2;
     g.in_aff = in_aff; g.in_slope = in_slope;
-    g.noflip = getenv("AFD_WINO44_NO_FLIP") != nullptr;
-    g.xcd_map = getenv("AFD_WINO44_XCDM") ? atoi(getenv("AFD_WINO44_XCDM")) : 16;
+    g.noflip = 0;
+    g.xcd_map = 16;
     g.bn_tab = bn_tab; g.bn_slope = bn_slope; g.bn_codes = bn_tab ? bn_codes : nullptr;
     if (bn_tab && (!dgrad || !bn_in || !stat_part || fwd_stats))
         return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: the BatchNorm backward epilogue belongs to backward-data launches "
@@ -876,8 +847,7 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
         if (CG == 6 && fwd_stats) return launch44<6, false, true, 2, true>(g, x, U, bias, y, s);
         if (fwd_stats) return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv + pool: statistics for Cout %d", Cout);
         if (CG == 6)
-            return getenv("AFD_WINO44_NO_HELP") ? launch44<6, false, true>(g, x, U, bias, y, s)
-                                                : launch44<6, false, true, 2>(g, x, U, bias, y, s);
+            return launch44<6, false, true, 2>(g, x, U, bias, y, s);
         if (CG == 4) return launch44<4, false, true>(g, x, U, bias, y, s);
         return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv + pool: Cout %d", Cout);
     }

@@ -69,8 +69,7 @@ struct GW {
     int N, Cin, Cout, H, W;
     int rows, cols;             // valid region of dy (a crop of H x W)
     int tilesX, tilesY, groupsX;  // groupsX = k-step groups (4 tiles) per tile row
-    long units;                 // N * groupsX * tilesY k-steps, ordered (n, column super-group, tile row, member)
-    int gsh;                    // log2 of the column groups per super-group (see decode_unit)
+    long units;                 // N * groupsX * tilesY k-steps, ordered (n, column group, tile row)
     int S;                      // splits of the unit sequence
     long units_per_split;       // even
     int cig;                    // channel groups along Cin
@@ -154,19 +153,15 @@ struct Unit {
 __device__ __forceinline__ Unit decode_unit(long u, long end, const GW& g) {
     Unit r;
     r.live = u < end;
-    // Order of the k-steps: (image, column SUPER-group of 2^gsh neighbouring column groups, tile row, member).  The two
-    // k-steps of a round are neighbouring column groups of one tile row -- together they read 128 + 8 bytes of every
-    // patch row, whole cache lines, where a lone group reads 72 bytes out of a 128-byte line whose rest was fetched again
-    // tilesY k-steps later, after the L2 had dropped it (round 5: the read requests by size, profiles/r05_pmc_traffic_*,
-    // put the launch at 1.6-1.8 x its algorithmic bytes); the next round is the tile row below (two shared halo rows).
+    // (round 5 measured an order in which the two k-steps of a round are neighbouring column groups of one tile row --
+    // whole 128-byte lines per patch row instead of 72 bytes of a line whose rest is fetched again tilesY k-steps later;
+    // the launch moves 1.6-1.8 x its algorithmic bytes, profiles/r05_pmc_traffic_* -- with super-groups of 2 / 4 / 8
+    // column groups: 12.48-12.55 ms for the class either way, so the plain order stays)
     const unsigned uu = r.live ? (unsigned)u : 0u;
-    const unsigned m = uu & ((1u << g.gsh) - 1u);
-    const unsigned v = uu >> g.gsh;
-    const unsigned q = v / (unsigned)g.tilesY;
-    r.ty = (int)(v - q * (unsigned)g.tilesY);
-    const unsigned sgx = (unsigned)g.groupsX >> g.gsh;
-    const unsigned n = q / sgx;
-    r.xg = (int)(((q - n * sgx) << g.gsh) + m);
+    const unsigned q = uu / (unsigned)g.tilesY;
+    r.ty = (int)(uu - q * (unsigned)g.tilesY);
+    const unsigned n = q / (unsigned)g.groupsX;
+    r.xg = (int)(q - n * (unsigned)g.groupsX);
     r.n = (int)n;
     return r;
 }
@@ -447,7 +442,7 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     // images at level 14) has A dy A^T = 0 at the positions 30..35 (row 5 of A picks dy row 3): those six products of
     // its k-step are skipped (uniform: the tile rows of the round's two k-steps)
     const int ty_short = (g.rows & 3) ? g.tilesY - 1 : -1;
-    auto ty_of = [&](long u) { return (int)(((unsigned)u >> g.gsh) % (unsigned)g.tilesY); };  // scalar, as decode_unit
+    auto ty_of = [&](long u) { return (int)((unsigned)u % (unsigned)g.tilesY); };  // scalar, as decode_unit
     load_x(u_begin);
     for (long u0 = u_begin; u0 < u_end; u0 += 2) {
         const bool short0 = ty_of(u0) == ty_short, short1 = ty_of(u0 + 1) == ty_short;
@@ -568,13 +563,8 @@ bool shape_ok(int Cin, int Cout) { return Cout % (16 * COB) == 0 && Cin % (16 * 
 
 // workgroups aimed at in all: two are resident per CU (74 KB of LDS each) and all do the same work, so the grid
 // should be a whole number of rounds over the 512 slots -- three rounds (measured on block 3 / block 4 at level 14:
-// 1024 6.32 / 4.11 ms, 1536 6.09 / 3.93, 2048 6.14 / 3.98, 3072 6.11 / 3.98).  AFD_WW_WGS overrides (development);
-// the workspace bound follows it.
-int target_wgs() {
-    const char* e = getenv("AFD_WW_WGS");
-    const int v = e ? atoi(e) : 1536;
-    return v < 8 ? 8 : (v > 8192 ? 8192 : v);
-}
+// 1024 6.32 / 4.11 ms, 1536 6.09 / 3.93, 2048 6.14 / 3.98, 3072 6.11 / 3.98).  The workspace bound follows it.
+int target_wgs() { return 1536; }
 
 void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_cols) {
     g.N = N; g.Cin = Cin; g.Cout = Cout; g.H = H; g.W = W;
@@ -584,13 +574,6 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     g.tilesY = (g.rows + 3) / 4;
     g.groupsX = (g.tilesX + 3) / 4;
     g.units = (long)N * g.groupsX * g.tilesY;
-    {   // column groups per super-group: the largest power of two up to the aim that divides the groups of a tile row
-        const char* e = getenv("AFD_WW_GSH");
-        int aim = e ? atoi(e) : 0;  // measured level at 0 / 1 / 2 / 3 (12.48-12.55 ms for the class): off by default
-        aim = aim < 0 ? 0 : (aim > 4 ? 4 : aim);
-        g.gsh = 0;
-        while (g.gsh < aim && g.groupsX % (2 << g.gsh) == 0) ++g.gsh;
-    }
     g.cig = Cin / (16 * CIB);
     const int cgroups = g.cig * (Cout / (16 * COB));
     // three, two or one rounds of workgroups over the CUs (see target_wgs), each workgroup with at least 8 rounds

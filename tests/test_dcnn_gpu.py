@@ -183,6 +183,35 @@ def test_level14_coif4_shape_runs():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+PLAN_L14 = ["block1: conv1+prelu+pool | bn folded into the next 1x1",
+            "block2: bn+conv1x1+prelu+bn one-pass backward | bn applied by the next conv",
+            "block3: conv3x3+prelu+pool (winograd epilogue) | input bn applied on load | bn sums from the epilogue",
+            "block4: conv3x3 | input bn applied on load | bn sums from the epilogue",
+            "block5: conv3x3 | input bn applied on load | bn sums from the epilogue",
+            "block6: conv3x3+prelu+pool (winograd epilogue) | input bn applied on load"]
+
+
+@pytest.mark.parametrize("input_dim,flat,add", [((2, 1, 16384, 24), 80960, 0), ((2, 1, 256, 109), 320, 0),
+                                                ((2, 1, 256, 95), 320, 1), ((2, 1, 256, 101), 320, 0)])
+def test_the_fused_units_of_a_training_step_are_the_documented_plan(input_dim, flat, add):
+    """`DCNN.last_plan` lists the fused units a forward pass ran.  In training mode every BASELINE / shipped geometry
+    (coif4 level 14, coif4 / sym5 level 8, STFT) runs the SAME six units -- the plan DESIGN.md section 4.5 describes;
+    in evaluation mode the BatchNorms are plain passes and nothing is deferred."""
+    torch.manual_seed(0)
+    args = _args(input_dim, flattend_size=flat, dropout_cnn=0.0, dropout_lstm=0.0, time_dim_add=add)
+    net = DCNN(args).cuda().train()
+    n, _, p, t = input_dim
+    x = torch.randn(n, 1, t, p, device="cuda").permute(0, 1, 3, 2)
+    out = net(x)
+    assert net.last_plan == PLAN_L14, net.last_plan
+    ops.CrossEntropyLoss()(out, torch.tensor([0, 1], device="cuda")).backward()
+    net.eval()
+    with torch.no_grad():
+        net(x)
+    assert not any("applied on load" in u or "applied by the next" in u or "one-pass" in u for u in net.last_plan), net.last_plan
+    assert net.last_plan[0].startswith("block1: conv1+prelu+pool") and len(net.last_plan) == 6
+
+
 @pytest.mark.parametrize("input_dim,flat,expect", [((3, 1, 16384, 24), 80960, 4), ((3, 1, 256, 101), 320, 4)])
 def test_training_step_without_the_normalised_tensors(input_dim, flat, expect, monkeypatch):
     """The BatchNorms in front of blocks 3-6 hand their statistics to the next convolution instead of writing their
