@@ -660,13 +660,15 @@ __global__ void linear_mean_bwd_x_kernel(const float* __restrict__ dy, const flo
 }
 
 // dw[o][f] = (1/TD) sum_b dy[b][o] sum_t x[b][t][f];  db[o] = sum_b dy[b][o]
-// block = 64 features x 4 batch groups (F is 320 in the shipped configs: one thread per
-// feature looping over the whole batch would be two workgroups of serial loads)
+// block = 64 features x 16 batch groups (F is 320 in the shipped configs: five workgroups; with 4 groups a thread
+// walked 32 frames x 13 time steps of dependent 4-byte loads -- 74 us at B = 128 for 2 x 320 results; now 8 frames per
+// thread with the time steps of a frame requested together)
+constexpr int kLinGroups = 16;
 template <int O>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * kLinGroups)
 linear_mean_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                          float* __restrict__ dw, float* __restrict__ db, int B, int TD, int F) {
-    __shared__ float red[O][4][65];
+    __shared__ float red[O][kLinGroups][65];
     const int fl = threadIdx.x & 63;
     const int g = threadIdx.x >> 6;
     const int f = blockIdx.x * 64 + fl;
@@ -674,15 +676,16 @@ linear_mean_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ 
 #pragma unroll
     for (int o = 0; o < O; ++o) acc[o] = 0.f;
     if (f < F) {
-        for (int b = g; b < B; b += 4) {
-            float s0 = 0.f, s1 = 0.f;
+        for (int b = g; b < B; b += kLinGroups) {
+            const float* xb = x + (size_t)b * TD * F + f;
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
             int t = 0;
-            for (; t + 1 < TD; t += 2) {
-                s0 += x[((size_t)b * TD + t) * F + f];
-                s1 += x[((size_t)b * TD + t + 1) * F + f];
+            for (; t + 3 < TD; t += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += xb[(size_t)(t + u) * F];
             }
-            if (t < TD) s0 += x[((size_t)b * TD + t) * F + f];
-            const float sx = s0 + s1;
+            for (; t < TD; ++t) s[0] += xb[(size_t)t * F];
+            const float sx = (s[0] + s[1]) + (s[2] + s[3]);
 #pragma unroll
             for (int o = 0; o < O; ++o) acc[o] = fmaf(sx, dy[(size_t)b * O + o], acc[o]);
         }
@@ -692,8 +695,12 @@ linear_mean_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ 
     __syncthreads();
     if (g == 0 && f < F) {
 #pragma unroll
-        for (int o = 0; o < O; ++o)
-            dw[(size_t)o * F + f] = (red[o][0][fl] + red[o][1][fl] + red[o][2][fl] + red[o][3][fl]) / (float)TD;
+        for (int o = 0; o < O; ++o) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < kLinGroups; ++k) v += red[o][k][fl];  // fixed order: deterministic
+            dw[(size_t)o * F + f] = v / (float)TD;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < O) {
         float sb = 0.f;
@@ -1225,7 +1232,7 @@ extern "C" int afd_linear_mean_backward(const float* x, const float* w, const fl
     afd::ScopedBytes timing(AFD_K_ELEMENTWISE, 8.0 * (double)B * TD * F, AFD_STREAM);
     hipLaunchKernelGGL(linear_mean_bwd_x_kernel<2>, dim3(grid1d(F, 64), B), dim3(kT), 0, AFD_STREAM,
                        dy, w, dx, TD, F);
-    hipLaunchKernelGGL(linear_mean_bwd_w_kernel<2>, dim3((F + 63) / 64), dim3(kT), 0, AFD_STREAM, x,
+    hipLaunchKernelGGL(linear_mean_bwd_w_kernel<2>, dim3((F + 63) / 64), dim3(64 * kLinGroups), 0, AFD_STREAM, x,
                        dy, dw, db, B, TD, F);
     return afd::check_launch("linear_mean_bwd kernels");
 }
