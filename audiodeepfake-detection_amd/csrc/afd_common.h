@@ -69,6 +69,16 @@ int dilconv_backward_weight(const float* x, const float* dy, float* dw, float* d
                             int H, int W, int K, int pad, int dil, void* ws, size_t ws_bytes,
                             hipStream_t s);
 
+// dilconv_mfma.hip: the dilated stack at 5..16 channels on the f32 MFMA, image band resident in LDS
+bool dilmfma_applicable(int Cin, int Cout, int H, int W, int K, int pad, int dil);
+size_t dilmfma_workspace_bytes(int N, int C, int H, int W, int K, int pad, int dil);
+int dilmfma_forward(const float* x, const float* w, const float* bias, float* y, int N, int C, int H, int W, int K, int pad,
+                    int dil, void* ws, size_t ws_bytes, hipStream_t s);
+int dilmfma_backward_data(const float* dy, const float* w, float* dx, int N, int C, int H, int W, int K, int pad, int dil,
+                          void* ws, size_t ws_bytes, hipStream_t s);
+int dilmfma_backward_weight(const float* x, const float* dy, float* dw, float* dbias, int N, int C, int H, int W, int K,
+                            int pad, int dil, void* ws, size_t ws_bytes, hipStream_t s);
+
 // conv1x1.hip: 1x1 convolutions as GEMMs over flattened pixels
 bool conv1x1_applicable(int Cin, int Cout, int K, int pad, int dil);
 bool conv1x1_wgrad_applicable(int Cin, int Cout);

@@ -1374,6 +1374,10 @@ extern "C" size_t afd_conv2d_workspace_bytes(int N, int Cin, int H, int W, int C
         const size_t b = align_up(afd::dilconv_workspace_bytes(Cin, K));
         if (b > need) need = b;
     }
+    if (afd::dilmfma_applicable(Cin, Cout, H, W, K, pad, dil)) {
+        const size_t b = align_up(afd::dilmfma_workspace_bytes(N, Cin, H, W, K, pad, dil));
+        if (b > need) need = b;
+    }
     if (afd::conv3x3_applicable(Cin, H, W, Cout, K, pad, dil)) {
         const size_t b = align_up(afd::conv3x3_workspace_bytes(Cin, Cout));
         if (b > need) need = b;
@@ -1417,6 +1421,8 @@ extern "C" int afd_conv2d_forward_cropped(const float* x, const float* w, const 
     if (out_rows < 1 || out_cols < 1) return afd::fail(AFD_ERR_ARG, "conv fwd: empty crop");
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_forward(x, w, bias, y, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
+    if (afd::dilmfma_applicable(Cin, Cout, H, W, K, pad, dil))
+        return afd::dilmfma_forward(x, w, bias, y, N, Cin, H, W, K, pad, dil, ws, ws_bytes, static_cast<hipStream_t>(stream));
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
         return afd::conv1x1_forward(x, w, bias, y, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
     if (afd::conv3x3_applicable(Cin, H, W, Cout, K, pad, dil))
@@ -1495,6 +1501,8 @@ extern "C" int afd_conv2d_backward_data(const float* dy, const float* w, float* 
     if (Cin > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "conv dgrad: Cin %d > 128", Cin);
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_backward_data(dy, w, dx, N, Cin, H, W, K, pad, dil, static_cast<hipStream_t>(stream));
+    if (afd::dilmfma_applicable(Cin, Cout, H, W, K, pad, dil))
+        return afd::dilmfma_backward_data(dy, w, dx, N, Cin, H, W, K, pad, dil, ws, ws_bytes, static_cast<hipStream_t>(stream));
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil))
         return afd::conv1x1_backward_data(dy, w, dx, N, Cin, Cout, (long)H * W, static_cast<hipStream_t>(stream));
     if (afd::conv3x3_applicable(Cout, H, W, Cin, K, dil * (K - 1) - pad, dil))
@@ -1543,6 +1551,10 @@ extern "C" int afd_conv2d_backward_weight_sums(const float* x, const float* dy, 
     if (dy_rows < 1 || dy_cols < 1) return afd::fail(AFD_ERR_ARG, "conv wgrad: empty crop");
     if (afd::dilconv_applicable(Cin, Cout, K, dil))
         return afd::dilconv_backward_weight(x, dy, dw, dbias, N, Cin, H, W, K, pad, dil, ws, ws_bytes,
+                                            static_cast<hipStream_t>(stream));
+    if (afd::dilmfma_applicable(Cin, Cout, H, W, K, pad, dil) && dy_rows >= H + 2 * pad - dil * (K - 1)
+        && dy_cols >= W + 2 * pad - dil * (K - 1))
+        return afd::dilmfma_backward_weight(x, dy, dw, dbias, N, Cin, H, W, K, pad, dil, ws, ws_bytes,
                                             static_cast<hipStream_t>(stream));
     if (afd::conv1x1_applicable(Cin, Cout, K, pad, dil) && afd::conv1x1_wgrad_applicable(Cin, Cout))
         return afd::conv1x1_backward_weight(x, dy, dw, dbias, N, Cin, Cout, (long)H * W, ws, ws_bytes,

@@ -79,7 +79,7 @@ WORKLOADS = {
     "coif4-l8-frontend": ("packets", "coif4", 256, 0, "frontend", "packets-coif4 level-8 front end only"),
 }
 DEFAULT_BATCH = {"haar-l14-frontend": 4096}
-MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv1x1", "conv_wgrad_1x1", "stft", "lcnn_bf16")
+MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv1x1", "conv_wgrad_1x1", "stft", "lcnn_bf16")  # (conv_direct mixes vector-ALU and matrix kernels: never the dominant class)
 # rocprof kernel names of each timing class (profiles/r*_pmc_traffic.json is keyed by kernel); every kernel the
 # library launches in a step belongs to exactly one class, so that the classes add up to the step
 CLASS_KERNELS = {
@@ -88,7 +88,8 @@ CLASS_KERNELS = {
     "conv_winograd": ("wino_conv_kernel", "wino44_conv_kernel", "wino_weights_kernel", "wino44_weights_kernel"),
     "conv_wgrad": ("wino44_wgrad_kernel", "wino44_wgrad_reduce_kernel", "wino44_wgrad_g_kernel", "wgrad3x3_kernel",
                    "wgrad3x3p_kernel", "wgrad_reduce_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),
-    "conv_direct": ("dilconv_direct_kernel", "dilconv_wgrad_kernel", "dilconv_reduce_kernel"),
+    "conv_direct": ("dilconv_direct_kernel", "dilconv_wgrad_kernel", "dilconv_reduce_kernel", "dilmfma_conv_kernel",
+                    "dilmfma_wgrad_kernel", "dilmfma_weights_kernel", "dilmfma_reduce1_kernel", "dilmfma_reduce2_kernel"),
     "conv_wgrad_1x1": ("conv1x1_wgrad_kernel", "conv1x1_fused_bwd_kernel", "conv1x1_fused_bwd_reduce_kernel"),
     "conv_first": ("conv1_pool_fwd_kernel", "conv1_pool_bwd_kernel", "conv1_bwd_reduce_kernel"),
     "batchnorm": ("bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel", "bn_bwd_apply_kernel",
