@@ -46,7 +46,8 @@ for k in sorted(agg):
     if "TCC_HIT_sum" in v and "TCC_MISS_sum" in v and v["TCC_HIT_sum"] + v["TCC_MISS_sum"]:
         der.append(f"L2 hit rate {100 * v['TCC_HIT_sum'] / (v['TCC_HIT_sum'] + v['TCC_MISS_sum']):.1f} %; TCC_MISS x 64 B = {v['TCC_MISS_sum'] * 64 / 1e9:.3f} GB")
     if "FETCH_SIZE" in v:
-        der.append(f"FETCH_SIZE = {v['FETCH_SIZE'] * 1024 / 1e9:.3f} GB raw (KB units; doubled for 16-byte-per-lane streams per the guide)")
+        der.append(f"FETCH_SIZE = {v['FETCH_SIZE'] * 1024 / 1e9:.3f} GB raw (KB units) = {2 * v['FETCH_SIZE'] * 1024 / 1e9:.3f} GB of memory-side reads "
+                   "(gfx950 tallies a 128-byte request as 64; the requests by size of profiles/r05_pmc_traffic_* show every kernel's reads are 128-byte requests)")
     if "WRITE_SIZE" in v:
         der.append(f"WRITE_SIZE = {v['WRITE_SIZE'] * 1024 / 1e9:.3f} GB")
     if "TCP_PENDING_STALL_CYCLES_sum" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"]:

@@ -1,6 +1,6 @@
-# Round-end evidence: rocprofv3 kernel statistics of the headline bench and the front-end workloads, copied
+# Round-end evidence: rocprofv3 kernel statistics of the headline bench and the other workloads, copied
 # into profiles/ (run through gpurun; rocprofv3 gets the program itself after `--`).
-#   tools/round_profile.sh <round tag, e.g. r02>
+#   tools/round_profile.sh <round tag, e.g. r05>
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() {  # name, bench flags...
@@ -14,6 +14,7 @@ run() {  # name, bench flags...
 run bench_coif4l14_b128 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 --no-frontends --no-secondary &&
 run bench_sym5l14_b128 --workload sym5-l14 --steps 5 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run bench_coif4l8_b128 --workload coif4-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
+run bench_sym5l8_b128 --workload sym5-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run bench_stft_b128 --workload stft --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run frontend_coif4l14_b128 --workload coif4-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
 run frontend_coif4l14_b4096 --workload coif4-l14-frontend --batch 4096 --steps 20 --warmup 5 --cpu-frames 0 &&
@@ -21,4 +22,5 @@ run frontend_sym5l14_b128 --workload sym5-l14-frontend --steps 30 --warmup 5 --c
 run frontend_sym5l14_b4096 --workload sym5-l14-frontend --batch 4096 --steps 20 --warmup 5 --cpu-frames 0 &&
 run frontend_haarl14_b4096 --workload haar-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
 run lcnn_eval_bf16 --workload stft-lcnn-eval-bf16 --steps 30 --warmup 5 --cpu-frames 0 &&
+run lcnn_eval_bf16_b1024 --workload stft-lcnn-eval-bf16 --batch 1024 --steps 20 --warmup 5 --cpu-frames 0 &&
 cp profiles/${tag}_*kernel_stats.csv profiles/${tag}_*_line.json gpurun_out/
