@@ -86,7 +86,9 @@ _SIGNATURES = {
     "afd_conv2d_backward_weight_cropped": (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
     "afd_conv2d_backward_weight_sums": (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 10 + [c_p, c_sz, c_p]),
     "afd_conv1_pool_workspace_bytes": (c_sz, [c_i] * 5),
-    "afd_conv1_pool_forward": (c_i, [c_p] * 6 + [c_i] * 5 + [c_p]),
+    "afd_conv1_pool_stats_workspace_bytes": (c_sz, [c_i] * 5),
+    "afd_conv1_pool_stats_applicable": (c_i, [c_i] * 5),
+    "afd_conv1_pool_forward": (c_i, [c_p] * 8 + [c_sz] + [c_i] * 5 + [c_p]),
     "afd_conv1_pool_backward": (c_i, [c_p] * 8 + [c_i] * 5 + [c_p, c_sz, c_p]),
     "afd_conv1_pool_backward_affine": (c_i, [c_p] * 10 + [c_i] * 5 + [c_p, c_sz, c_p]),
     "afd_conv1x1_prelu_bn_backward_applicable": (c_i, [c_i, c_i]),

@@ -106,6 +106,8 @@ class DCNN(nn.Module):
                     and conv.dilation == (1, 1) and not h.requires_grad):
                 # single-channel first block: conv + PReLU + pool in one kernel
                 link = {} if fold_next else None
+                if fold_next and self.training:
+                    link["want_stats"] = True  # the folded BatchNorm takes its batch sums from the first block's launch
                 plan_log.append(f"block{step + 1}: conv1+prelu+pool" + (" | bn folded into the next 1x1" if fold_next else ""))
                 h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0], link)
                 if fold_next:

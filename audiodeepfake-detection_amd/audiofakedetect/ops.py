@@ -478,9 +478,19 @@ class _Conv1PReLUPool(torch.autograd.Function):
         hp, wp = (h + 2 * pad - 2) // 2, (wd + 2 * pad - 2) // 2
         u = torch.empty((n, cout, hp, wp), dtype=torch.float32, device=x.device)
         idx = torch.empty((n, cout, hp, wp), dtype=torch.uint8, device=x.device)
+        # a training-mode BatchNorm behind the pool (the consumer set link["want_stats"]) takes its batch sums from this
+        # launch: no statistics pass over u
+        sums = sws = None
+        if (link is not None and link.get("want_stats") and not os.environ.get("AFD_NO_FWD_STATS")
+                and lib.afd_conv1_pool_stats_applicable(n, h, wd, cout, pad)):  # wide rows only (level 14)
+            sums = torch.empty(2 * cout + 1, dtype=torch.float64, device=x.device)
+            sws = _ws(lib.afd_conv1_pool_stats_workspace_bytes(n, h, wd, cout, pad), x.device, "stats")
         _native.check(lib.afd_conv1_pool_forward(
             _native.ptr(x), _native.ptr(w), _native.ptr(b), _native.ptr(slope), _native.ptr(u),
-            _native.ptr(idx), n, h, wd, cout, pad, _native.stream_ptr()), "afd_conv1_pool_forward")
+            _native.ptr(idx), _native.ptr(sums), _native.ptr(sws), sws.numel() if sws is not None else 0, n, h, wd, cout,
+            pad, _native.stream_ptr()), "afd_conv1_pool_forward")
+        if sums is not None:
+            link["fwd_sums"] = sums
         _tap("pool", idx)
         ctx.save_for_backward(x, u, idx, slope)
         ctx.cfg = (n, h, wd, cout, pad, b is not None, tuple(w.shape))
@@ -1137,11 +1147,14 @@ def _bn_finalize_sums(sums, c, count, bn, sync):
     return mean, invstd, (cnt if dist_on else count)
 
 
-def _bn_batch_stats(x, slope, c, n, hw, bn, sync):
-    """Training-mode statistics of PReLU(x) (or x): (mean, invstd, count); updates bn's running buffers."""
-    sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
-    _native.check(_lib().afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c, hw,
-                                      _native.stream_ptr()), "afd_bn_stats")
+def _bn_batch_stats(x, slope, c, n, hw, bn, sync, pre_sums=None):
+    """Training-mode statistics of PReLU(x) (or x): (mean, invstd, count); updates bn's running buffers.  `pre_sums`:
+    the packed sums from the producer's epilogue (no pass over x)."""
+    sums = pre_sums
+    if sums is None:
+        sums = torch.empty(2 * c + 1, dtype=torch.float64, device=x.device)
+        _native.check(_lib().afd_bn_stats(_native.ptr(x), _native.ptr(slope), _native.ptr(sums), n, c, hw,
+                                          _native.stream_ptr()), "afd_bn_stats")
     return _bn_finalize_sums(sums, c, float(n * hw), bn, sync)
 
 
@@ -1165,7 +1178,8 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         cout = w.shape[0]
         hw = h * wd
         dev = u.device
-        mean1, invstd1, cnt1 = _bn_batch_stats(u, None, c, n, hw, bn1, sync)
+        pre1 = link.pop("fwd_sums", None) if link is not None else None  # from the first block's forward launch
+        mean1, invstd1, cnt1 = _bn_batch_stats(u, None, c, n, hw, bn1, sync, pre1)
         w2 = _f32c(w).reshape(cout, c)
         wf, bf = _fold_forward(w2, b, mean1, invstd1)
         z = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)

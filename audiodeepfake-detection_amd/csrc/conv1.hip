@@ -45,16 +45,44 @@ constexpr int kFP = 4;  // pooled pixels per thread of the forward kernel
 // the kernel moves 4.4 GB of results against 0.2 GB of input and was bound by its narrow stores), and the
 // 4 x (2 kFP + 2) input patch is shared by the pixels.  The two outputs of a window row share a weight and take
 // horizontally adjacent samples: one packed FMA (v_pk_fma_f32, weight broadcast from a scalar register) does both.
+// Sum of a value over the 64 lanes of a wave on the vector ALU alone (DPP: quad permutes, row mirrors, row broadcasts);
+// the total ends in lane 63.  (A shuffle tree through ds_bpermute is a chain of LDS round trips: round 3 measured the
+// statistics epilogue of this kernel at +0.9 ms with it.)
+#define AFD_DPP_ADD(v, ctrl, rows) \
+    (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (rows), 0xF, false))
+__device__ __forceinline__ float wave_sum63(float v) {
+    AFD_DPP_ADD(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+    AFD_DPP_ADD(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+    AFD_DPP_ADD(v, 0x141, 0xF);  // row_half_mirror
+    AFD_DPP_ADD(v, 0x140, 0xF);  // row_mirror: every lane holds its row's sum
+    AFD_DPP_ADD(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    AFD_DPP_ADD(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 holds the wave's sum
+    return v;
+}
+#undef AFD_DPP_ADD
+
+// STATS (round 5): the kernel also sums, per channel, the pooled values and their squares over its workgroup's pixels --
+// the batch statistics of the BatchNorm behind the pool (reference models.py:258-260) -- into one partial row
+// [sum | sum of squares] per workgroup: the statistics pass over the 3.5 GB pooled tensor (0.6 ms at level 14) is gone
+template <bool STATS>
 __global__ void __launch_bounds__(kT)
 conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                       const float* __restrict__ bias, const float* __restrict__ slope,
                       float* __restrict__ u, unsigned char* __restrict__ idx, int H, int W, int Cout,
-                      int pad, int Hp, int Wp) {
+                      int pad, int Hp, int Wp, float* __restrict__ stat_part) {
     constexpr int PC = 2 * kFP + 2;  // patch columns
+    __shared__ float wsum[STATS ? kT / 64 : 1][STATS ? 2 * 128 : 1];  // [wave][sum | squares][channel <= 128]
     const int px0 = (blockIdx.x * kT + threadIdx.x) * kFP;
     const int py = blockIdx.y;
     const int n = blockIdx.z;
-    if (px0 >= Wp) return;
+    if (!STATS && px0 >= Wp) return;
+    const bool live = px0 < Wp;  // STATS: the threads stay for the reductions; dead lanes of a live wave compute on zeros
+    // a wave entirely past the row (narrow images: 129 pooled columns use 33 of a workgroup's 256 threads) only zeroes its
+    // cells of the cross-wave sum
+    const bool wave_live = (int)((blockIdx.x * kT + (threadIdx.x & ~63)) * kFP) < Wp;  // uniform per wave
+    if (STATS && !wave_live) {
+        for (int e = threadIdx.x & 63; e < 2 * 128; e += 64) wsum[threadIdx.x >> 6][e] = 0.f;
+    }
     const float a = slope[0];
     const bool mono = a > 0.f;  // uniform
     const float* xn = x + (size_t)n * H * W;
@@ -80,7 +108,8 @@ conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     const size_t plane = (size_t)Hp * Wp;
     size_t o = ((size_t)n * Cout * Hp + py) * Wp + px0;
     const bool whole = px0 + kFP <= Wp;
-    for (int co = 0; co < Cout; ++co, o += plane) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int co = 0; co < (STATS && !wave_live ? 0 : Cout); ++co, o += plane) {
         const float* wc = w + co * 9;  // uniform address: scalar loads
         const float b = bias ? bias[co] : 0.f;
         float best[kFP];
@@ -119,11 +148,26 @@ conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
             best[j] = bst;
             code |= (unsigned)(bi | (zb <= 0.f ? 4 : 0)) << (8 * j);
         }
+        if constexpr (STATS) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < kFP; ++j) {
+                const float v = (live && px0 + j < Wp) ? best[j] : 0.f;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+            }
+            s1 = wave_sum63(s1);
+            s2 = wave_sum63(s2);
+            if (lane == 63) {
+                wsum[wave][co] = s1;
+                wsum[wave][128 + co] = s2;
+            }
+        }
         if (whole) {
             f4u1 v4 = {best[0], best[1], best[2], best[3]};
             *reinterpret_cast<f4u1*>(u + o) = v4;
             *reinterpret_cast<u32u1*>(idx + o) = code;
-        } else {
+        } else if (live) {
 #pragma unroll
             for (int j = 0; j < kFP; ++j)
                 if (px0 + j < Wp) {
@@ -132,6 +176,34 @@ conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                 }
         }
     }
+    if constexpr (STATS) {
+        __syncthreads();
+        // one partial row [sum(Cout) | squares(Cout)] per workgroup, waves added in a fixed order
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int e = threadIdx.x; e < 2 * Cout; e += kT) {
+            const int which = e / Cout, c = e - which * Cout;
+            float v = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < kT / 64; ++wv) v += wsum[wv][which * 128 + c];
+            stat_part[(size_t)wg * 2 * Cout + e] = v;
+        }
+    }
+}
+
+// sums[e] (e < 2 Cout) = sum over the workgroups' partial rows, in double precision: one workgroup per output
+__global__ void __launch_bounds__(256)
+conv1_stats_reduce_kernel(const float* __restrict__ part, int rows, int C2, double* __restrict__ sums) {
+    __shared__ double red[256];
+    const int e = blockIdx.x;
+    double s = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) s += (double)part[(size_t)r * C2 + e];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[e] = red[0];
 }
 
 // partial[split][cg][kCG][11]: 9 weight gradients, bias gradient, slope gradient
@@ -295,20 +367,50 @@ extern "C" size_t afd_conv1_pool_workspace_bytes(int N, int H, int W, int Cout, 
     return (size_t)bwd_splits(tiles, CG) * CG * kCG * 11 * sizeof(float);
 }
 
+extern "C" size_t afd_conv1_pool_stats_workspace_bytes(int N, int H, int W, int Cout, int pad) {
+    const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
+    if (Hp < 1 || Wp < 1 || Cout < 1 || Cout > 128) return 0;
+    return (size_t)N * Hp * ((Wp + kT * kFP - 1) / (kT * kFP)) * 2 * Cout * sizeof(float);
+}
+
+// Whether the sums are worth taking in the forward launch.  On a row narrower than one workgroup (level 8 / STFT: 129
+// pooled columns, 33 live threads of 256) the per-channel wave sums cost more than the statistics pass they replace
+// (conv_first 0.48 -> 0.64 ms against batchnorm 0.66 -> 0.61 ms at batch 128); at level 14 (8193 columns) the launch
+// saves 0.5 ms of the step.  The kernel itself is correct at every width.
+extern "C" int afd_conv1_pool_stats_applicable(int N, int H, int W, int Cout, int pad) {
+    const int Wp = (W + 2 * pad - 2) / 2;
+    return afd_conv1_pool_stats_workspace_bytes(N, H, W, Cout, pad) > 0 && Wp >= kT * kFP;
+}
+
 extern "C" int afd_conv1_pool_forward(const float* x, const float* w, const float* bias,
-                                      const float* slope, float* u, uint8_t* idx, int N, int H, int W,
-                                      int Cout, int pad, afd_stream_t stream) {
+                                      const float* slope, float* u, uint8_t* idx, double* sums, void* stat_ws,
+                                      size_t stat_ws_bytes, int N, int H, int W, int Cout, int pad,
+                                      afd_stream_t stream) {
     if (!x || !w || !slope || !u || !idx) return afd::fail(AFD_ERR_ARG, "conv1 fwd: null pointer");
     const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
     if (N < 1 || Cout < 1 || Hp < 1 || Wp < 1 || pad < 0) return afd::fail(AFD_ERR_ARG, "conv1 fwd: bad geometry");
     if (Hp > 65535 || N > 65535) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 fwd: grid too large");
+    if (sums) {
+        if (Cout > 128) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 fwd + sums: Cout %d > 128", Cout);
+        if (!stat_ws || stat_ws_bytes < afd_conv1_pool_stats_workspace_bytes(N, H, W, Cout, pad))
+            return afd::fail(AFD_ERR_WORKSPACE, "conv1 fwd + sums: statistics workspace too small");
+    }
     // bytes: the one-channel image in, pooled values + argmax codes out
     const double fwd_bytes = (double)N * (4.0 * H * W + 5.0 * Cout * Hp * Wp);
     afd::ScopedTiming timing(AFD_K_CONV_FIRST, fwd_bytes, AFD_STREAM);
     timing.bytes(fwd_bytes);
-    hipLaunchKernelGGL(conv1_pool_fwd_kernel, dim3((Wp + kT * kFP - 1) / (kT * kFP), Hp, N), dim3(kT), 0, AFD_STREAM,
-                       x, w, bias, slope, u, idx, H, W, Cout, pad, Hp, Wp);
-    return afd::check_launch("conv1_pool_fwd_kernel");
+    const dim3 grid((Wp + kT * kFP - 1) / (kT * kFP), Hp, N);
+    if (!sums) {
+        hipLaunchKernelGGL(conv1_pool_fwd_kernel<false>, grid, dim3(kT), 0, AFD_STREAM, x, w, bias, slope, u, idx, H, W, Cout, pad,
+                           Hp, Wp, nullptr);
+        return afd::check_launch("conv1_pool_fwd_kernel");
+    }
+    float* part = static_cast<float*>(stat_ws);
+    hipLaunchKernelGGL(conv1_pool_fwd_kernel<true>, grid, dim3(kT), 0, AFD_STREAM, x, w, bias, slope, u, idx, H, W, Cout, pad, Hp,
+                       Wp, part);
+    hipLaunchKernelGGL(conv1_stats_reduce_kernel, dim3(2 * Cout), dim3(256), 0, AFD_STREAM, part,
+                       (int)(grid.x * grid.y * grid.z), 2 * Cout, sums);
+    return afd::check_launch("conv1_pool_fwd_kernel(stats)");
 }
 
 extern "C" int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx,

@@ -91,7 +91,7 @@ CLASS_KERNELS = {
     "conv_direct": ("dilconv_direct_kernel", "dilconv_wgrad_kernel", "dilconv_reduce_kernel", "dilmfma_conv_kernel",
                     "dilmfma_wgrad_kernel", "dilmfma_weights_kernel", "dilmfma_reduce1_kernel", "dilmfma_reduce2_kernel"),
     "conv_wgrad_1x1": ("conv1x1_wgrad_kernel", "conv1x1_fused_bwd_kernel", "conv1x1_fused_bwd_reduce_kernel"),
-    "conv_first": ("conv1_pool_fwd_kernel", "conv1_pool_bwd_kernel", "conv1_bwd_reduce_kernel"),
+    "conv_first": ("conv1_pool_fwd_kernel", "conv1_pool_bwd_kernel", "conv1_bwd_reduce_kernel", "conv1_stats_reduce_kernel"),
     "batchnorm": ("bn_stats_kernel", "bn_apply_fwd_kernel", "bn_bwd_stats_kernel", "bn_bwd_apply_kernel",
                   "bn_finalize_kernel", "bn_bwd_means_kernel", "bn_fold_forward_kernel", "bn_fold_backward_weights_kernel",
                   "bn_fold_backward_affine_kernel", "bn_backward_coef_kernel", "wino_bnstats_reduce1_kernel",

@@ -311,11 +311,18 @@ int afd_conv2d_backward_weight_sums(const float* x, const float* dy, float* dw, 
  * only the pooled tensor u [N][Cout][Hp][Wp] and the 3-bit code idx (as afd_prelu_pool_*);
  * backward consumes du, idx, u and x and produces dw [Cout][1][3][3], dbias [Cout] (may be
  * NULL) and dslope (+=); the pre-pool activation and its gradient are never materialised.
- * Hp = (H + 2 pad - 2) / 2. */
+ * Hp = (H + 2 pad - 2) / 2.  sums != NULL (round 5; Cout <= 128): the forward launch also leaves the batch sums of the
+ * BatchNorm behind the pool (models.py:260) -- sums[c] = sum of u over batch and pixels, sums[Cout + c] = sum of u^2, in
+ * double precision from one partial row per workgroup in stat_ws (afd_conv1_pool_stats_workspace_bytes): no
+ * statistics pass over u. */
 size_t afd_conv1_pool_workspace_bytes(int N, int H, int W, int Cout, int pad);
+size_t afd_conv1_pool_stats_workspace_bytes(int N, int H, int W, int Cout, int pad);
+/* 1 when taking the sums in the forward launch is faster than a statistics pass over u (rows of at least one
+ * workgroup's 1024 pooled columns: the level-14 input); the kernel is correct at every width. */
+int afd_conv1_pool_stats_applicable(int N, int H, int W, int Cout, int pad);
 int afd_conv1_pool_forward(const float* x, const float* w, const float* bias, const float* slope,
-                           float* u, uint8_t* idx, int N, int H, int W, int Cout, int pad,
-                           afd_stream_t stream);
+                           float* u, uint8_t* idx, double* sums, void* stat_ws, size_t stat_ws_bytes, int N, int H,
+                           int W, int Cout, int pad, afd_stream_t stream);
 int afd_conv1_pool_backward(const float* x, const float* du, const uint8_t* idx, const float* u,
                             const float* slope, float* dw, float* dbias, float* dslope /* += */,
                             int N, int H, int W, int Cout, int pad, void* ws, size_t ws_bytes,

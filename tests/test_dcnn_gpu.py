@@ -73,7 +73,11 @@ def test_train_step_matches_reference():
     # runs every tensor agrees to ~1e-6; one pool flip in block 3 costs 1e-3 L2 upstream of
     # it, and the CPU fp32 reference differs from its own fp64 run by 2e-4 .. 2e-3 for the
     # same reason).  Bars: per tensor relative L2 <= 2e-2 and max <= 1e-1 of its largest
-    # entry; over all parameters together relative L2 <= 3e-3.
+    # entry; over all parameters together relative L2 <= 5e-3.  (The overall figure IS the flip
+    # noise: 2.9e-3 with the first BatchNorm's sums from a pass over its input, 3.5e-3 with the
+    # same sums from the first block's epilogue (round 5) -- whose logits (1.2e-6 against 1.5e-6)
+    # and running mean (3.7e-9 against 7.5e-9) are CLOSER to the reference; the routing-aligned
+    # test below holds 1e-4 per tensor either way.)
     num = den = 0.0
     for k, p in net.named_parameters():
         ref = g["grads"][k]
@@ -83,7 +87,7 @@ def test_train_step_matches_reference():
         assert l2 <= 2e-2 and mx <= 1e-1, f"grad {k}: rel L2 {l2:.3e}, rel max {mx:.3e}"
         num += diff.norm().item() ** 2
         den += ref.norm().item() ** 2
-    assert (num / den) ** 0.5 <= 3e-3
+    assert (num / den) ** 0.5 <= 5e-3
     opt.step()
     after = net.state_dict()
     for k, v in g["state_dict_after"].items():

@@ -442,7 +442,20 @@ def test_conv1_pool_backward_with_affine_gradient():
     idx = torch.empty(n, cout, hp, wp, dtype=torch.uint8, device="cuda")
     _native.check(lib.afd_conv1_pool_forward(_native.ptr(x), _native.ptr(conv.weight.detach().contiguous()),
                                              _native.ptr(conv.bias.detach()), _native.ptr(slope), _native.ptr(u),
-                                             _native.ptr(idx), n, h, w, cout, pad, _native.stream_ptr()), "fwd")
+                                             _native.ptr(idx), None, None, 0, n, h, w, cout, pad, _native.stream_ptr()), "fwd")
+    # the same launch with the BatchNorm batch sums in its epilogue (round 5): identical u / idx, sums equal to float64
+    # sums of u (ragged last workgroup column, 24 channels)
+    u2, idx2 = torch.empty_like(u), torch.empty_like(idx)
+    sums = torch.empty(2 * cout + 1, dtype=torch.float64, device="cuda")
+    sws = torch.empty(lib.afd_conv1_pool_stats_workspace_bytes(n, h, w, cout, pad), dtype=torch.uint8, device="cuda")
+    _native.check(lib.afd_conv1_pool_forward(_native.ptr(x), _native.ptr(conv.weight.detach().contiguous()),
+                                             _native.ptr(conv.bias.detach()), _native.ptr(slope), _native.ptr(u2),
+                                             _native.ptr(idx2), _native.ptr(sums), _native.ptr(sws), sws.numel(), n, h, w,
+                                             cout, pad, _native.stream_ptr()), "fwd + sums")
+    assert torch.equal(u2, u) and torch.equal(idx2, idx)
+    want1, want2 = u.double().sum((0, 2, 3)), (u.double() ** 2).sum((0, 2, 3))
+    assert (sums[:cout] - want1).abs().max().item() <= 2e-6 * u.double().abs().sum((0, 2, 3)).max().item()
+    assert (sums[cout:2 * cout] - want2).abs().max().item() <= 2e-6 * want2.max().item()
     du = torch.randn_like(u)
     alpha, beta = torch.randn(cout, device="cuda"), torch.randn(cout, device="cuda")
     ws = torch.empty(lib.afd_conv1_pool_workspace_bytes(n, h, w, cout, pad), dtype=torch.uint8, device="cuda")
