@@ -447,7 +447,9 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     for (long u0 = u_begin; u0 < u_end; u0 += 2) {
         const bool short0 = ty_of(u0) == ty_short, short1 = ty_of(u0 + 1) == ty_short;
         // the dy tile (four 16-byte loads) is requested here and arrives during the x transform; only the x patch
-        // (36 registers) is held across the matrix phase -- with the dy tile too the kernel spilled
+        // (36 registers) is held across the matrix phase -- with the dy tile too the kernel spilled.  (Round 5: the pooled
+        // form's tile is 6 registers and fits; requested a matrix phase ahead with the patch it measured level, 12.46-12.48
+        // against 12.43-12.44 ms for the class: the dy latency is not what the waves wait for)
         load_d(u0);
         transform_x();
         transform_d(want_bias);
