@@ -228,21 +228,32 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     // border by one column at most; in those groups (uniform branch) the two loads of a row start one column
     // in / one column early and the six values are picked by lane selects.  Tiles past tilesX (ragged last
     // group) read tile 0 of their group and are zeroed.
-    auto load_x = [&](long u0) {
+    // one row of an interior patch (two loads); `load_x` below requests a whole patch, the matrix phase deals the six
+    // rows of the coming round's patch out over its first position groups (see there)
+    const float* xc_next = nullptr;
+    auto load_x_row = [&](int r, int half = 2) {
+        const int iy = 4 * ux.ty - 1 + r;
+        const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
+        const float* row = xc_next + (size_t)iyc * g.W;  // uniform
+        if (half != 1) {
+            const f4u v = *reinterpret_cast<const f4u*>(row + loff);
+            d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w;
+        }
+        if (half != 0) {
+            const f2u w2 = *reinterpret_cast<const f2u*>(row + loff + 4);
+            d[r][4] = w2.x; d[r][5] = w2.y;
+        }
+    };
+    auto load_x = [&](long u0, bool rows_later) {
         ux = decode_unit(u0 + xks, u_end, g);
         const int iy0 = 4 * ux.ty - 1;
         x_edge = ux.xg == 0 || 16 * ux.xg + 17 > g.W || 4 * ux.xg + 3 >= g.tilesX;
         const float* xc = xblk + (size_t)ux.n * g.Cin * plane + (16 * ux.xg - 1);
+        xc_next = xc;
         if (!x_edge) {
+            if (rows_later) return;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const int iy = iy0 + r;
-                const int iyc = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
-                const float* row = xc + (size_t)iyc * g.W;  // uniform
-                const f4u v = *reinterpret_cast<const f4u*>(row + loff);
-                const f2u w2 = *reinterpret_cast<const f2u*>(row + loff + 4);
-                d[r][0] = v.x; d[r][1] = v.y; d[r][2] = v.z; d[r][3] = v.w; d[r][4] = w2.x; d[r][5] = w2.y;
-            }
+            for (int r = 0; r < 6; ++r) load_x_row(r);
         } else {
             const int tx = 4 * ux.xg + lt;
             const bool tile_ok = tx < g.tilesX;
@@ -443,19 +454,21 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
     // its k-step are skipped (uniform: the tile rows of the round's two k-steps)
     const int ty_short = (g.rows & 3) ? g.tilesY - 1 : -1;
     auto ty_of = [&](long u) { return (int)((unsigned)u % (unsigned)g.tilesY); };  // scalar, as decode_unit
-    load_x(u_begin);
+    load_x(u_begin, false);
     for (long u0 = u_begin; u0 < u_end; u0 += 2) {
         const bool short0 = ty_of(u0) == ty_short, short1 = ty_of(u0 + 1) == ty_short;
         // the dy tile (four 16-byte loads) is requested here and arrives during the x transform; only the x patch
-        // (36 registers) is held across the matrix phase -- with the dy tile too the kernel spilled.  (Round 5: the pooled
-        // form's tile is 6 registers and fits; requested a matrix phase ahead with the patch it measured level, 12.46-12.48
-        // against 12.43-12.44 ms for the class: the dy latency is not what the waves wait for)
-        load_d(u0);
+        // (36 registers) is held across the matrix phase.  The pooled form's tile (6 registers) is requested inside the
+        // matrix phase, after the patch's loads
+        if (!PDY || u0 == u_begin) load_d(u0);
         transform_x();
         transform_d(want_bias);
         __syncthreads();
-        // the coming round's patch travels during the matrix phase
-        if (u0 + 2 < u_end) load_x(u0 + 2);
+        // the coming round's patch travels during the matrix phase: its unit is decoded here, its loads are dealt out
+        // over the position groups below (an edge group's select-and-mask loads stay in one piece)
+        const bool next = u0 + 2 < u_end;
+        if (next) load_x(u0 + 2, true);
+        const bool rows_here = next && !x_edge;  // uniform
         // operands of position group pg + 1 are requested before the four matrix instructions of group pg
         const float* as0 = sets + (size_t)(2 * CIB + wa) * kSetFloats + lane * 4;
         const float* bs0 = sets + (size_t)wb * kSetFloats + lane * 4;
@@ -469,6 +482,14 @@ wino44_wgrad_kernel(const GW g, const float* __restrict__ x, const float* __rest
                 an = *reinterpret_cast<const f32x4*>(as0 + (size_t)ks1 * COB * kSetFloats + pg1 * 256);
                 bn = *reinterpret_cast<const f32x4*>(bs0 + (size_t)ks1 * CIB * kSetFloats + pg1 * 256);
             }
+            // the coming round's patch, ONE load per position group: a load instruction takes the CU's address pipeline
+            // ~16 cycles whatever its size or hit rate (the kernel taken apart), and twelve of them issued back
+            // to back by all four waves right behind the barrier kept every wave from its first matrix instruction until
+            // the pipeline had taken them: 12.6 -> 11.8 ms for the class (round 5)
+            if (it < 12 && rows_here) load_x_row(it >> 1, it & 1);
+            // (the pooled dy tile -- 2 x 2 values and their codes, 6 registers -- follows; the dense tile's 16 registers held
+            // across the matrix phase cost more than its loads at the top of the round: 12.07 against 11.76 ms for the class)
+            if (PDY && it == 12 && next) load_d(u0 + 2);
             __builtin_amdgcn_sched_barrier(0);
             const bool short_ks = ks ? short1 : short0;
 #pragma unroll
