@@ -15,6 +15,9 @@
 #include "afd_common.h"
 #include "../../include/afd_hip.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -267,6 +270,185 @@ conv1x1_kernel(const G1 g, const float* __restrict__ x, const float* __restrict_
     }
 }
 
+// The 64 x 64 forward with statistics (DCNN block 2), stores under the matrix instructions (round 5).
+// conv1x1_kernel<2, 4, false, true> writes a tile's 32 output rows (32 KB per wave) in one burst behind the tile's last
+// matrix instruction; a CU drains ~6 bytes per cycle towards memory, so its four waves sat ~20k cycles in that burst
+// with nothing else to issue -- as long as the tile's matrix instructions take (the store burst was 1.0 of the launch's
+// 2.2 ms).  Here a tile is two passes over the SAME B fragments -- output channels 0..31, then 32..63 -- with the whole
+// tile's 64 x 128 inputs resident in registers (128; 32 KB per wave in flight instead of 8-16): the rows of a finished
+// pass leave one at a time, every second k-step, under the matrix instructions of the next pass (of this tile or the
+// wave's next one), and a chunk of B is reloaded for the next tile as soon as the second pass is through with it.
+// Arithmetic, summation order of the statistics and the partial-row layout are those of conv1x1_kernel (bit-identical y).
+__global__ void __launch_bounds__(256)
+conv1x1_split_stats_kernel(const G1 g, const float* __restrict__ x, const float* __restrict__ w,
+                           const float* __restrict__ bias, float* __restrict__ y, const float* __restrict__ slope,
+                           float* __restrict__ stat_part) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [64][64], k-major; then the 64 biases
+    typedef typename VecU<4>::type vec_t;
+    constexpr int C = 64, KC = 8, NCH = 4, NW = 4;  // exactly 64 channels on both sides (the host checks)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int e = tid; e < C * C; e += 256) {
+        const int k = e / C, m = e - k * C;
+        Ws[e] = g.trans ? w[(size_t)k * C + m] : w[(size_t)m * C + k];
+    }
+    if (tid < C) Ws[C * C + tid] = bias ? bias[tid] : 0.f;
+    __syncthreads();
+    const float* Bs = Ws + C * C;
+    const unsigned HW = (unsigned)g.HW;
+    const int tstride = gridDim.x * 4;
+    const float slope_a = slope[0];
+    float s1[2][16], s2[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[m][r] = s2[m][r] = 0.f;
+    int t = afd::xcd_grouped_id((int)blockIdx.x, (int)gridDim.x, g.xcd_m) * 4 + wave;  // uniform
+    float* srow = stat_part + ((size_t)blockIdx.x * 4 + wave) * (2 * C);
+    if (t >= g.ntiles) {  // a wave without tiles still owns a (zero) partial row
+        for (int e = lane; e < 2 * C; e += 64) srow[e] = 0.f;
+        return;
+    }
+    // a tile: image n, first pixel px0 (uniform); the lane's pixels px0 + 4 l31 .. + 3 of the channel rows 2 ks + half
+    // (loads) and 4 half + (r & 3) + 8 (r >> 2) + 32 m (stores)
+    struct Tile {
+        const float* xin;
+        float* yout;
+        unsigned px0;
+        bool whole;
+    };
+    auto tile_of = [&](int tt) {
+        const int n = tt / g.tiles_per_img;
+        Tile q;
+        q.px0 = (unsigned)(tt - n * g.tiles_per_img) * (32u * NW);
+        q.xin = x + (size_t)n * C * HW + q.px0;
+        q.yout = y + (size_t)n * C * HW + q.px0;
+        q.whole = q.px0 + 32u * NW <= HW;
+        return q;
+    };
+    const unsigned lane_in = (unsigned)half * HW + 4u * (unsigned)l31;
+    const unsigned lane_out = 4u * (unsigned)half * HW + 4u * (unsigned)l31;
+    vec_t b[NCH][KC];
+    auto load_chunk = [&](const Tile& q, int c) {
+        if (q.whole) {  // uniform
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks)
+                b[c][ks] = *reinterpret_cast<const vec_t*>(q.xin + ((unsigned)((c * KC + ks) * 2) * HW + lane_in));
+        } else {
+            const unsigned p = q.px0 + 4u * (unsigned)l31;
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks) {
+                const float* src = q.xin + ((unsigned)((c * KC + ks) * 2) * HW + lane_in);
+                vec_t v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    if (p + i < HW) v[i] = src[i];
+                b[c][ks] = v;
+            }
+        }
+    };
+    // row r of a finished pass (block m of tile q): bias, store, statistics -- conv1x1_kernel's epilogue, row by row
+    auto put_row = [&](const f32x16 (&a)[NW], int m, int r, const Tile& q) {
+        const int cou = m * 32 + (r & 3) + 8 * (r >> 2);  // + 4 half
+        const float bv = Bs[cou + 4 * half];
+        float* o = q.yout + ((unsigned)cou * HW + lane_out);
+        if (q.whole) {  // uniform
+            vec_t v;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) v[i] = a[i][r] + bv;
+            *reinterpret_cast<vec_t*>(o) = v;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const float pv = v[i] > 0.f ? v[i] : slope_a * v[i];
+                s1[m][r] += pv;
+                s2[m][r] = fmaf(pv, pv, s2[m][r]);
+            }
+        } else {
+            const unsigned p = q.px0 + 4u * (unsigned)l31;
+#pragma unroll
+            for (int i = 0; i < NW; ++i)
+                if (p + i < HW) {
+                    const float zv = a[i][r] + bv;
+                    o[i] = zv;
+                    const float pv = zv > 0.f ? zv : slope_a * zv;
+                    s1[m][r] += pv;
+                    s2[m][r] = fmaf(pv, pv, s2[m][r]);
+                }
+        }
+    };
+    f32x16 acc0[NW], acc1[NW];
+    Tile cur = tile_of(t), prev = cur, nxt = cur;
+    bool have_prev = false;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load_chunk(cur, c);
+    while (true) {
+        const int tn = t + tstride;
+        const bool more = tn < g.ntiles;  // uniform
+        if (more) nxt = tile_of(tn);
+        // pass 0: output channels 0..31 of this tile; the rows of the previous tile's channels 32..63 leave meanwhile
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[i][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks) {
+                const float a = Ws[((c * KC + ks) * 2 + half) * C + l31];
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    acc0[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[c][ks][i], acc0[i], 0, 0, 0);
+                if ((ks & 1) && have_prev) put_row(acc1, 1, (c * KC + ks) >> 1, prev);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        // pass 1: channels 32..63; the rows of pass 0 leave meanwhile; a chunk of b is requested for the next tile as soon
+        // as this pass is through with it
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks) {
+                const float a = Ws[((c * KC + ks) * 2 + half) * C + 32 + l31];
+#pragma unroll
+                for (int i = 0; i < NW; ++i)
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[c][ks][i], acc1[i], 0, 0, 0);
+                if (ks & 1) put_row(acc0, 0, (c * KC + ks) >> 1, cur);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) load_chunk(nxt, c);
+        }
+        prev = cur;
+        have_prev = true;
+        if (!more) break;
+        cur = nxt;
+        t = tn;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) put_row(acc1, 1, r, prev);
+    // a register row is one output channel over the 32 lanes of a wave half
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a1 = s1[m][r], a2 = s2[m][r];
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                a1 += __shfl_xor(a1, off, 64);
+                a2 += __shfl_xor(a2, off, 64);
+            }
+            if (l31 == 0) {
+                const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                srow[co] = a1;
+                srow[C + co] = a2;
+            }
+        }
+}
+
 // sums[c] = sum over the waves' partial rows (double), sums[C + c] likewise for the squares: one wave per output,
 // lanes stride over the rows
 __global__ void __launch_bounds__(256)
@@ -437,8 +619,12 @@ int launch_gemm_stats(G1 g, const float* x, const float* w, const float* bias, c
     if (blocks > cap) blocks = cap;
     if (part_bytes < (size_t)blocks * 4 * 2 * MW * 32 * sizeof(float))
         return afd::fail(AFD_ERR_WORKSPACE, "conv1x1 stats: workspace too small");
-    hipLaunchKernelGGL((conv1x1_kernel<MW, NW, false, true>), dim3((unsigned)blocks), dim3(256), lds, s, g, x, w,
-                       bias, y, slope, nullptr, part);
+    if (MW == 2 && NW == 4 && g.Cin == 64 && g.Cout == 64 && (long)g.HW * 64 < 0x7fffffffL && !getenv("AFD_CONV1X1_ONE_PASS"))
+        hipLaunchKernelGGL(conv1x1_split_stats_kernel, dim3((unsigned)blocks), dim3(256), lds + 64 * sizeof(float), s, g, x, w,
+                           bias, y, slope, part);
+    else
+        hipLaunchKernelGGL((conv1x1_kernel<MW, NW, false, true>), dim3((unsigned)blocks), dim3(256), lds, s, g, x, w,
+                           bias, y, slope, nullptr, part);
     int rc = afd::check_launch("conv1x1_kernel(stats)");
     if (rc) return rc;
     hipLaunchKernelGGL(conv1x1_stats_reduce_kernel, dim3((2 * g.Cout + 3) / 4), dim3(256), 0, s, part,

@@ -84,7 +84,7 @@ MFMA_CLASSES = ("conv_winograd", "conv_wgrad", "conv_igemm", "conv1x1", "conv_wg
 # library launches in a step belongs to exactly one class, so that the classes add up to the step
 CLASS_KERNELS = {
     "conv_igemm": ("conv3x3_kernel", "conv_igemm_kernel"),
-    "conv1x1": ("conv1x1_kernel", "conv1x1_stats_reduce_kernel"),
+    "conv1x1": ("conv1x1_kernel", "conv1x1_split_stats_kernel", "conv1x1_stats_reduce_kernel"),
     "conv_winograd": ("wino_conv_kernel", "wino44_conv_kernel", "wino_weights_kernel", "wino44_weights_kernel"),
     "conv_wgrad": ("wino44_wgrad_kernel", "wino44_wgrad_reduce_kernel", "wino44_wgrad_g_kernel", "wgrad3x3_kernel",
                    "wgrad3x3p_kernel", "wgrad_reduce_kernel", "conv_wgrad2_kernel", "conv_wgrad_kernel"),

@@ -482,14 +482,16 @@ def test_conv1x1_epilogue_returns_batchnorm_sums():
     lib = _native.load()
     slope = torch.full((1,), 0.25, device="cuda")
 
-    for cin, co, hw in ((64, 64, 13 * 1157), (32, 40, 999), (64, 96, 4097)):
-        xx = torch.randn(2, cin, hw, device="cuda")
+    # (the 64 -> 64 launch is the two-pass kernel whose stores leave under the next pass's matrix instructions: the last
+    # case gives every wave several tiles, so rows of one tile leave during the next tile's first pass)
+    for cin, co, hw, n in ((64, 64, 13 * 1157, 2), (32, 40, 999, 2), (64, 96, 4097, 2), (64, 64, 13 * 8193, 6)):
+        xx = torch.randn(n, cin, hw, device="cuda")
         c1 = torch.nn.Conv2d(cin, co, 1).cuda()
         w1, b1 = c1.weight.detach().reshape(co, cin).contiguous(), c1.bias.detach()
-        y0 = torch.empty(2, co, hw, device="cuda")
-        wsz = lib.afd_conv2d_workspace_bytes(2, cin, 1, hw, co, 1, 0, 1)
+        y0 = torch.empty(n, co, hw, device="cuda")
+        wsz = lib.afd_conv2d_workspace_bytes(n, cin, 1, hw, co, 1, 0, 1)
         ws0 = torch.empty(max(wsz, 16), dtype=torch.uint8, device="cuda")
-        _native.check(lib.afd_conv2d_forward(_native.ptr(xx), _native.ptr(w1), _native.ptr(b1), _native.ptr(y0), 2,
+        _native.check(lib.afd_conv2d_forward(_native.ptr(xx), _native.ptr(w1), _native.ptr(b1), _native.ptr(y0), n,
                                              cin, 1, hw, co, 1, 0, 1, _native.ptr(ws0), ws0.numel(),
                                              _native.stream_ptr()), "conv")
         y1 = torch.empty_like(y0)
@@ -497,7 +499,7 @@ def test_conv1x1_epilogue_returns_batchnorm_sums():
         ws1 = torch.empty(lib.afd_conv1x1_forward_stats_workspace_bytes(co), dtype=torch.uint8, device="cuda")
         _native.check(lib.afd_conv1x1_forward_stats(
             _native.ptr(xx), _native.ptr(w1), _native.ptr(b1), _native.ptr(slope), _native.ptr(y1), _native.ptr(s2),
-            2, cin, co, hw, _native.ptr(ws1), ws1.numel(), _native.stream_ptr()), "conv stats")
+            n, cin, co, hw, _native.ptr(ws1), ws1.numel(), _native.stream_ptr()), "conv stats")
         assert torch.equal(y0, y1)
         pz = torch.where(y0 > 0, y0, 0.25 * y0).double()
         ref = torch.cat([pz.sum((0, 2)), (pz ** 2).sum((0, 2))])
