@@ -36,7 +36,6 @@ typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 constexpr int kCh = 16;     // input channels per chunk = 4 k-steps of 4
 constexpr int kTiles = 16;  // tiles per workgroup
 constexpr int kPos = 36;
-constexpr int kVBuf = kPos * kCh * kTiles;  // floats per V buffer (36 KB)
 
 struct G4 {
     int N, Cin, Cout, H, W;
