@@ -11,3 +11,15 @@ python3 tools/pmc_derive.py gpurun_out/r05_pmc_step_raw.md gpurun_out/r05_pmc_st
 bash tools/pmc_kernels.sh lcnn "lcnn|gemm|lstm|stft" gpurun_out/r05_pmc_lcnn_raw.md -- python3 bench.py --workload stft-lcnn-eval-bf16 --batch 1024 --steps 3 --warmup 1 --cpu-frames 0 > gpurun_out/pmc_lcnn.log 2>&1
 python3 tools/pmc_derive.py gpurun_out/r05_pmc_lcnn_raw.md gpurun_out/r05_pmc_lcnn.md "Hardware counters of the LCNN bf16 evaluation forward (STFT + LCNN, B = 1024)"
 tail -3 gpurun_out/round_profile.log
+# validation sweeps at the same build: random geometries through the C ABI (fold, gradient sums, F(4x4) layers, wavelet packets)
+# and the loss of a fixed batch under 40 optimizer steps for every shipped model geometry
+python3 tools/fold_fuzz.py 60 > gpurun_out/r05_fold_fuzz.txt 2>&1
+python3 tools/gradsum_fuzz.py 60 > gpurun_out/r05_gradsum_fuzz.txt 2>&1
+python3 tools/wino44_fuzz.py 60 > gpurun_out/r05_wino44_fuzz.txt 2>&1
+python3 tools/wpt_fuzz.py 80 > gpurun_out/r05_wpt_fuzz.txt 2>&1
+: > gpurun_out/r05_overfit.txt
+for w in coif4-l14 sym5-l14 coif4-l8 sym5-l8 stft; do
+  echo "== $w" >> gpurun_out/r05_overfit.txt
+  python3 tools/overfit_check.py $w 40 32 2>/dev/null >> gpurun_out/r05_overfit.txt
+done
+for f in fold_fuzz gradsum_fuzz wino44_fuzz wpt_fuzz overfit; do tail -n 2 gpurun_out/r05_$f.txt; done
