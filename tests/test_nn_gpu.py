@@ -263,8 +263,10 @@ def test_normalize_and_transpose():
     assert torch.equal(t, x.transpose(-1, -2).contiguous())
 
 
+# (the two wide shapes: rows of more than 1024 pooled columns -- the forward's four pixels per thread with a ragged last
+# thread, several workgroup columns per row in the backward; 24 and 64 channels)
 @pytest.mark.parametrize("shape,cout,pad", [((3, 1, 24, 300), 64, 2), ((2, 1, 109, 256), 64, 2),
-                                            ((2, 1, 11, 37), 20, 1)])
+                                            ((2, 1, 11, 37), 20, 1), ((2, 1, 6, 2053), 24, 2), ((2, 1, 7, 4099), 64, 1)])
 @pytest.mark.parametrize("slope", [0.25, -0.4])
 def test_fused_conv1_prelu_pool(shape, cout, pad, slope):
     """Single-channel first block fused (conv 3x3 + PReLU + MaxPool2d) vs the three torch ops."""
@@ -428,12 +430,13 @@ def test_block2_one_pass_backward(shape, cout, linked):
 
 
 @pytest.mark.gpu
-def test_conv1_pool_backward_with_affine_gradient():
+@pytest.mark.parametrize("geometry", [(2, 10, 300, 24, 2), (2, 6, 2055, 64, 2)])
+def test_conv1_pool_backward_with_affine_gradient(geometry):
     """`afd_conv1_pool_backward_affine`: the first block's backward with its incoming gradient given as
     du + alpha[c] * u + beta[c] equals the plain backward on the materialised sum."""
     torch.manual_seed(12)
     lib = _native.load()
-    n, h, w, cout, pad = 2, 10, 300, 24, 2
+    n, h, w, cout, pad = geometry
     x = torch.randn(n, 1, h, w, device="cuda")
     conv = torch.nn.Conv2d(1, cout, 3, padding=pad).cuda()
     slope = torch.full((1,), 0.25, device="cuda")
