@@ -261,7 +261,7 @@ class NativeFrameLoader:
     """
 
     def __init__(self, dataset: "CustomDataset", batch_size: int, device, shuffle: bool = True, seed: int = 0,
-                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8) -> None:
+                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8, prefetch: int = 1) -> None:
         self.ds = dataset
         self.dataset = dataset  # the attribute the trainer reads from a torch DataLoader
         self.batch_size = int(batch_size)
@@ -270,6 +270,18 @@ class NativeFrameLoader:
         self.rank, self.world, self.threads = rank, world, threads
         self.epoch = 0
         self._banks: dict = {}
+        # batches prepared ahead of the consumer by a background thread on a side stream (0: in the caller's thread,
+        # on its stream).  A trainer that reads its loss back every step (the reference's does, train_classifier.py:
+        # 981-989) only asks for batch k + 1 when step k has finished: read, copy and resampling of the next batch then
+        # all lie between two steps -- +0.9 ms on the level-14 step -- unless they were done during step k.
+        prefetch = int(os.environ.get("AFD_LOADER_PREFETCH", prefetch))
+        self.prefetch = int(prefetch) if self.device.type == "cuda" else 0
+        self._side = None
+        # reader threads of a prefetching loader: it has a whole step to read 128 windows (5.6 MB from the page cache), and
+        # more threads take the cores the trainer's own thread needs to keep the GPU's queue filled -- level-14 step,
+        # B = 128 (tools/e2e_probe.py): resident batch 44.5-44.9 ms; in the caller's thread 45.5 (16 readers) / 46.0 (1);
+        # prefetching with 16 readers 50.3, with 4 / 2 / 1: 45.3 / 45.05 / 45.2
+        self._readers = min(self.threads, 2) if self.prefetch > 0 else self.threads
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = int(epoch)
@@ -324,6 +336,61 @@ class NativeFrameLoader:
         return ring, slot
 
     def __iter__(self):
+        if self.prefetch <= 0:
+            yield from self._batches()
+            return
+        import queue
+        import threading
+
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        side = self._side
+        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def put(x) -> bool:
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
+        def worker() -> None:
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(side):  # (thread-local: the library calls below pick it up as the current stream)
+                    for item in self._batches():
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        if not put((item, ev)):
+                            return
+                put(None)
+            except BaseException as e:  # handed to the consumer
+                put(e)
+
+        th = threading.Thread(target=worker, name="afd-loader", daemon=True)
+        th.start()
+        try:
+            while True:
+                got = q.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                item, ev = got
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for t in item.values():
+                    if t.is_cuda:
+                        t.record_stream(cur)  # allocated on the side stream, used (and freed) on the consumer's
+                yield item
+        finally:
+            stop.set()
+            th.join(timeout=10.0)
+
+    def _batches(self):
         import ctypes
 
         from . import _native
@@ -351,7 +418,7 @@ class NativeFrameLoader:
                 rates = (ctypes.c_int * m)()
                 paths = (ctypes.c_char_p * m)(*[os.fsencode(str(p)) for p in batch[pos, 0]])
                 offs = (ctypes.c_longlong * m)(*[int(f) * win for f in batch[pos, 1]])
-                rc = lib.afd_wav_read_windows(paths, offs, m, win, ctypes.c_void_p(pcm.data_ptr()), rates, self.threads)
+                rc = lib.afd_wav_read_windows(paths, offs, m, win, ctypes.c_void_p(pcm.data_ptr()), rates, self._readers)
                 rate = int(rates[0]) if rc == 0 else 0
                 if rc != 0 or any(int(r) != rate for r in rates) or rate < target:
                     ok = False  # the dataset's own path raises its own errors (e.g. rate < target)

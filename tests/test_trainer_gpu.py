@@ -160,6 +160,13 @@ def test_native_loader_matches_the_dataset(tmp_path):
         ds = get_costum_dataset(data_path=str(root), save_path=str(root / "idx"), ds_type="train", seconds=1,
                                 resample_rate=22050, limit=-1)
         loader = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4)
+        assert loader.prefetch == 1  # batches prepared one ahead by a background thread on a side stream ...
+        inline = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=0)
+        for got, want in zip(loader, inline):  # ... are the batches of the in-thread form
+            assert torch.equal(got["audio"], want["audio"]) and torch.equal(got["label"], want["label"])
+        it = iter(loader)  # a consumer that stops early leaves no thread behind
+        next(it)
+        it.close()
         seen = 0
         order = loader._indices()
         for b, batch in enumerate(loader):

@@ -1,0 +1,57 @@
+"""Where the end-to-end step's extra time goes (development): the headline step fed (a) by one resident batch, (b) by
+batches of the same WAV data prepared beforehand, (c) by NativeFrameLoader in the caller's thread, (d) with its prefetch thread.
+    python3 tools/e2e_probe.py [steps]"""
+import os, sys, time, tempfile, shutil, wave
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "audiodeepfake-detection_amd"))
+import bench
+from audiofakedetect.data_loader import NativeFrameLoader, get_costum_dataset
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 14
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+args, trainer, transforms = bench.build("coif4-l14", 128, False, dev)
+trainer.model.train()
+root = tempfile.mkdtemp(prefix="afd_probe_")
+rng = np.random.default_rng(1234)
+for name in ("A_real", "B_fake"):
+    os.makedirs(os.path.join(root, name))
+    for i in range(16):
+        pcm = np.clip(rng.standard_normal(22050 * 40) * 3276.8, -32768, 32767).astype(np.int16)
+        with wave.open(os.path.join(root, name, f"{i:04d}.wav"), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(22050); f.writeframes(pcm.tobytes())
+ds = get_costum_dataset(data_path=root, save_path=os.path.join(root, "index"), ds_type="train", seconds=1, resample_rate=22050, limit=-1)
+
+def run(batches, n):
+    it = iter(batches)
+    for _ in range(3):
+        trainer._run_batch(0, next(it))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n):
+        trainer._run_batch(0, next(it))
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / n
+
+def cycle(loader):
+    e = 0
+    while True:
+        loader.set_epoch(e); e += 1
+        for b in loader:
+            yield b
+
+res = bench.synthetic_batch(128, 0, dev)
+print("resident batch          %.3f ms/step" % run(iter(lambda: res, None), steps))
+pre = [b for b in NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=0)]
+torch.cuda.synchronize()
+def rep():
+    while True:
+        for b in pre: yield b
+print("prepared WAV batches    %.3f ms/step" % run(rep(), steps))
+print("loader, caller's thread %.3f ms/step" % run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=0, threads=16)), steps))
+for th in (16, 4, 2, 1):
+    print("loader, prefetch thread, %2d reader threads %.3f ms/step" % (th, run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=1, threads=th)), steps)))
+for th in (4, 1):
+    print("loader, caller's thread, %2d reader threads %.3f ms/step" % (th, run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=0, threads=th)), steps)))
+print("resident batch          %.3f ms/step" % run(iter(lambda: res, None), steps))
+shutil.rmtree(root, ignore_errors=True)
