@@ -261,7 +261,7 @@ class NativeFrameLoader:
     """
 
     def __init__(self, dataset: "CustomDataset", batch_size: int, device, shuffle: bool = True, seed: int = 0,
-                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8, prefetch: int = 1) -> None:
+                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8, prefetch: int = 0) -> None:
         self.ds = dataset
         self.dataset = dataset  # the attribute the trainer reads from a torch DataLoader
         self.batch_size = int(batch_size)
@@ -270,8 +270,8 @@ class NativeFrameLoader:
         self.rank, self.world, self.threads = rank, world, threads
         self.epoch = 0
         self._banks: dict = {}
-        # batches prepared ahead of the consumer by a background thread on a side stream (0: in the caller's thread,
-        # on its stream).  A trainer that reads its loss back every step (the reference's does, train_classifier.py:
+        # prefetch = 1 (opt-in; AFD_LOADER_PREFETCH overrides): batches prepared one ahead of the consumer by a background
+        # thread on a side stream (0, the default: in the caller's thread, on its stream).  A trainer that reads its loss back every step (the reference's does, train_classifier.py:
         # 981-989) only asks for batch k + 1 when step k has finished: read, copy and resampling of the next batch then
         # all lie between two steps -- +0.9 ms on the level-14 step -- unless they were done during step k.
         prefetch = int(os.environ.get("AFD_LOADER_PREFETCH", prefetch))

@@ -160,11 +160,12 @@ def test_native_loader_matches_the_dataset(tmp_path):
         ds = get_costum_dataset(data_path=str(root), save_path=str(root / "idx"), ds_type="train", seconds=1,
                                 resample_rate=22050, limit=-1)
         loader = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4)
-        assert loader.prefetch == 1  # batches prepared one ahead by a background thread on a side stream ...
-        inline = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=0)
-        for got, want in zip(loader, inline):  # ... are the batches of the in-thread form
+        # prefetch=1 (opt-in): batches prepared one ahead by a background thread on a side stream ...
+        ahead = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=1)
+        assert loader.prefetch == 0 and ahead.prefetch == 1
+        for got, want in zip(ahead, loader):  # ... are the batches of the in-thread form
             assert torch.equal(got["audio"], want["audio"]) and torch.equal(got["label"], want["label"])
-        it = iter(loader)  # a consumer that stops early leaves no thread behind
+        it = iter(ahead)  # a consumer that stops early leaves no thread behind
         next(it)
         it.close()
         seen = 0
