@@ -9,16 +9,26 @@ module carries the decomposition low-pass tables itself (pywt convention:
 ``dec_len``, ``name``).
 
 Tables: haar, db2..db10 (computed by spectral factorisation, minimum phase, as
-pywt stores them), sym5 and coif4 (literal tables).
-Other wavelets can be registered with :func:`register_wavelet`.
+pywt stores them), sym5 and coif4 (literal tables), and every
+other discrete wavelet pywt names -- db11..db38, sym2..sym20, coif1..coif17, dmey,
+bior*/rbio* -- from ``wavelet_tables.py`` (data lifted from PyWavelets 1.1.1 by
+``tools/gen_wavelet_tables.py``), so that every ``--wavelet`` of the reference's launch
+scripts (scripts/start_exps.sh:3-31) and its default sym8 (utils.py:84-89) construct.
+``tests/test_oracle_wpt.py`` checks all of them against the pywt fixture
+``tests/golden/pywt_taps.npz``.  coif4 keeps the higher-precision table (it meets the
+coiflet conditions to 3e-13; pywt 1.1.1's differs from it by 2.3e-8, below half an ulp
+of the fp32 taps the kernels use).  Other wavelets can be registered with
+:func:`register_wavelet`.
 """
 
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
+
+from .wavelet_tables import TABLES as _PYWT_TABLES
 
 _SYM5 = [
     0.027333068345077982,
@@ -94,14 +104,22 @@ def _daubechies_dec_lo(order: int) -> List[float]:
 
 
 _TABLES: Dict[str, List[float]] = {}
+_HI_TABLES: Dict[str, List[float]] = {}  # only the banks whose dec_hi is not the mirror of dec_lo
 
 
-def register_wavelet(name: str, dec_lo: Sequence[float]) -> None:
-    """Register the decomposition low-pass taps of an orthogonal wavelet."""
+def register_wavelet(name: str, dec_lo: Sequence[float], dec_hi: Optional[Sequence[float]] = None) -> None:
+    """Register the decomposition filters of a two-channel bank (`dec_hi` omitted: the quadrature mirror of
+    `dec_lo`, an orthogonal wavelet)."""
     taps = [float(v) for v in dec_lo]
     if len(taps) % 2 != 0 or len(taps) < 2:
-        raise ValueError("an orthogonal wavelet filter has an even number of taps")
+        raise ValueError("a two-channel wavelet filter has an even number of taps")
     _TABLES[name] = taps
+    _HI_TABLES.pop(name, None)
+    if dec_hi is not None:
+        hi = [float(v) for v in dec_hi]
+        if len(hi) != len(taps):
+            raise ValueError("dec_lo and dec_hi must have the same length")
+        _HI_TABLES[name] = hi
 
 
 register_wavelet("haar", _daubechies_dec_lo(1))
@@ -110,6 +128,9 @@ for _n in range(2, 11):
     register_wavelet(f"db{_n}", _daubechies_dec_lo(_n))
 register_wavelet("sym5", _SYM5)
 register_wavelet("coif4", _COIF4)
+for _name, (_lo, _hi) in _PYWT_TABLES.items():
+    if _name not in _TABLES:
+        register_wavelet(_name, _lo, _hi)
 
 
 class Wavelet:
@@ -124,11 +145,15 @@ class Wavelet:
         self.name = name
         self.dec_lo = list(_TABLES[name])
         length = len(self.dec_lo)
-        self.dec_hi = [
-            (-1.0) ** (k + 1) * self.dec_lo[length - 1 - k] for k in range(length)
-        ]
-        self.rec_lo = self.dec_lo[::-1]
-        self.rec_hi = self.dec_hi[::-1]
+        if name in _HI_TABLES:
+            self.dec_hi = list(_HI_TABLES[name])
+        else:
+            self.dec_hi = [
+                (-1.0) ** (k + 1) * self.dec_lo[length - 1 - k] for k in range(length)
+            ]
+        # synthesis pair of a perfect-reconstruction bank (for an orthogonal one: the reversed analysis filters)
+        self.rec_lo = [(-1.0) ** (k + 1) * self.dec_hi[k] for k in range(length)]
+        self.rec_hi = [(-1.0) ** k * self.dec_lo[k] for k in range(length)]
         self.dec_len = length
         self.rec_len = length
 

@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int kMaxLevel = 16;
-constexpr int kMaxTaps = 32;
+constexpr int kMaxTaps = 128;  // coif17, the longest discrete wavelet of pywt, has 102 taps
 constexpr int kThreads = 512;
 constexpr int kLdsFloats = 40000;  // 160 000 B of the 163 840 B a workgroup may claim
 
@@ -366,7 +366,8 @@ extern "C" int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo
                                           sign_mean, sign_std, out, ws, ws_bytes, static_cast<hipStream_t>(stream));
         if (rc3 != 1) return rc3;
     }
-    // everything else -- 2, 12, 14, 18.. taps, levels 9..13, other frame lengths -- on the single-launch kernel below
+    // everything else -- 2 taps, 34..128 taps (coif6..17, db17..38, sym17..20, dmey), levels 9..13, other frame lengths,
+    // banks without a lattice at level 14 -- on the single-launch kernel below
     WptParams p{};
     p.x = x;
     p.out = out;

@@ -455,8 +455,17 @@ int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float*
         case 6: return launch3<6>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 8: return launch3<8>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 10: return launch3<10>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 12: return launch3<12>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 14: return launch3<14>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 16: return launch3<16>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 18: return launch3<18>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 20: return launch3<20>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 22: return launch3<22>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 24: return launch3<24>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 26: return launch3<26>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 28: return launch3<28>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 30: return launch3<30>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 32: return launch3<32>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         default: return 1;
     }
 }

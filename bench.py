@@ -66,6 +66,8 @@ WORKLOADS = {
     "coif4-l8": ("packets", "coif4", 256, 0, "train", "packets-coif4 level-8 + DCNN train step"),
     "sym5-l8": ("packets", "sym5", 256, 1, "train", "packets-sym5 level-8 + DCNN train step"),
     "sym5-l14": ("packets", "sym5", 16384, 0, "train", "packets-sym5 level-14 + DCNN train step"),
+    # the reference's DEFAULT wavelet (utils.py:84-89) at the level its launch scripts use (start_exps.sh:9)
+    "sym8-l8": ("packets", "sym8", 256, 0, "train", "packets-sym8 level-8 + DCNN train step"),
     "stft": ("stft", "none", 256, 0, "train", "STFT(n_fft 511, hop 220) + DCNN train step"),
     # BASELINE configs[4]: evaluation (forward + argmax) of the LCNN head on STFT features
     "stft-lcnn-eval": ("stft", "none", 256, 0, "eval", "STFT(n_fft 511, hop 220) + LCNN eval forward (fp32)"),
@@ -110,7 +112,7 @@ CLASS_KERNELS = {
 }
 
 
-WAVELET_TAPS = {"haar": 2, "sym5": 10, "coif4": 24}
+WAVELET_TAPS = {"haar": 2, "sym5": 10, "coif4": 24, "sym8": 16}
 
 
 def wpt_direct_flops(wavelet: str, level: int, n: int = 22050) -> float:
@@ -402,14 +404,14 @@ def frontend_lines(device, _native, launches: int = 20):
 def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3):
     """The other BASELINE configurations measured in this same process after the timed region, so that the driver's
     own run of the default command records them: configs[2] per GPU (packets-sym5 level 14), the level-8 models the
-    reference ships (coif4, sym5), configs[0] (STFT + DCNN) and configs[4] (STFT + LCNN evaluation, bf16 matrix
+    reference ships (coif4, sym5) and its default wavelet sym8, configs[0] (STFT + DCNN) and configs[4] (STFT + LCNN evaluation, bf16 matrix
     products).  Per workload: `steps` steps after `warmup` untimed ones, wall clock between device synchronisations;
     then two instrumented steps for the dominant kernel class and its fraction of the roof that bounds it.
     Never `value`."""
     import gc
 
     out = []
-    for name in ("sym5-l14", "coif4-l8", "sym5-l8", "stft", "stft-lcnn-eval-bf16"):
+    for name in ("sym5-l14", "coif4-l8", "sym5-l8", "sym8-l8", "stft", "stft-lcnn-eval-bf16"):
         kind = WORKLOADS[name][4]
         try:
             torch.manual_seed(0)

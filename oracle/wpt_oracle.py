@@ -15,20 +15,25 @@ Restates, for the wavelet-packet path of the reference:
   ``F.conv1d(., stack(flip(dec_lo), flip(dec_hi)), stride=2)``, applied recursively
   to both outputs; ``get_level`` returns the nodes in frequency (Gray code) order.
 
-PARITY PIN: the reference's own tests hold SHAPES only for this path
-(``tests/test_transforms.py:54-142``) and ptwt/pywt are not installable here, so the
-numeric parity of this restatement is pinned by (i) those shape asserts, (ii) the
-mathematical known answers in ``tests/test_oracle_wpt.py`` (Haar closed form,
-constant input, pure-tone packet index = Gray-code order, energy), (iii) agreement
-with an independent C restatement (``oracle/wpt_oracle.c``) and an independent
-torch ``F.pad``/``F.conv1d`` restatement (``oracle/torch_ref.py``).  "parity
-unpinned at the ptwt boundary" -- see DESIGN.md.
+PARITY PIN: pinned on PyWavelets.  The reference's own tests hold SHAPES only for this
+path (``tests/test_transforms.py:54-142``); its dependency pywt (``requirements.txt:5``,
+the source of the taps at ``wavelet_math.py:239``) computes the same tree as
+``pywt.WaveletPacket(x, w, mode="reflect").get_level(l, order="freq")`` -- the call the
+reference itself makes in ``scripts/freq_visual/fingerprints.py:101-106``.
+``tests/golden/make_wpt_golden.py`` (run in the build container with the interpreter
+that has pywt 1.1.1) wrote that call's float64 outputs and pywt's tap tables to
+``tests/golden/pywt_*.npz``; ``tests/test_oracle_wpt.py`` holds this restatement, the C
+one (``oracle/wpt_oracle.c``) and the torch ``F.pad``/``F.conv1d`` one
+(``oracle/torch_ref.py``) to them (<= 1e-13 with pywt's taps at levels 1, 3, 8, 14), next
+to the reference's shape asserts and the mathematical known answers (Haar closed form,
+constant input, pure-tone packet index = Gray-code order, energy).  Residual assumption:
+ptwt == pywt for ``mode="reflect"`` (ptwt is installed nowhere on this machine).
 """
 
 from __future__ import annotations
 
 import math
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -64,15 +69,17 @@ def child_length(n: int, filt_len: int) -> int:
     return (n + filt_len - 2 + (n % 2)) // 2
 
 
-def analysis_step(x: np.ndarray, dec_lo: Sequence[float]) -> Tuple[np.ndarray, np.ndarray]:
+def analysis_step(x: np.ndarray, dec_lo: Sequence[float],
+                  dec_hi: Optional[Sequence[float]] = None) -> Tuple[np.ndarray, np.ndarray]:
     """One two-channel analysis step along the last axis (ptwt ``wavedec(level=1)``).
 
     cA[i] = sum_m dec_lo[m] * xe[2i+1-m], cD likewise with dec_hi, where xe is the
-    whole-sample reflect extension of x.
+    whole-sample reflect extension of x.  `dec_hi` omitted: the quadrature mirror of
+    `dec_lo` (orthogonal wavelets); the biorthogonal families pass their own.
     """
     x = np.asarray(x, dtype=np.float64)
     lo = np.asarray(dec_lo, dtype=np.float64)
-    hi = np.asarray(dec_hi_from_lo(dec_lo), dtype=np.float64)
+    hi = np.asarray(dec_hi_from_lo(dec_lo) if dec_hi is None else dec_hi, dtype=np.float64)
     filt_len = len(lo)
     n = x.shape[-1]
     padl = filt_len - 2
@@ -118,7 +125,8 @@ def wpt_nodes_by_path(x: np.ndarray, dec_lo: Sequence[float], level: int) -> np.
     return np.stack([nodes[p] for p in graycode_paths(level)], axis=-2)
 
 
-def wpt_nodes(x: np.ndarray, dec_lo: Sequence[float], level: int) -> np.ndarray:
+def wpt_nodes(x: np.ndarray, dec_lo: Sequence[float], level: int,
+              dec_hi: Optional[Sequence[float]] = None) -> np.ndarray:
     """Level-`level` packet nodes of x[..., N] in frequency order -> [..., P, T].
 
     All nodes of a level have the same length, so a level is one vectorised analysis
@@ -128,7 +136,7 @@ def wpt_nodes(x: np.ndarray, dec_lo: Sequence[float], level: int) -> np.ndarray:
     """
     cur = np.asarray(x, dtype=np.float64)[..., None, :]
     for _ in range(level):
-        ca, cd = analysis_step(cur, dec_lo)
+        ca, cd = analysis_step(cur, dec_lo, dec_hi)
         cur = np.stack([ca, cd], axis=-2).reshape(ca.shape[:-2] + (-1, ca.shape[-1]))
     f = np.arange(1 << level)
     return cur[..., f ^ (f >> 1), :]
@@ -142,6 +150,7 @@ def packet_features(
     loss_less: bool = False,
     power: float = 2.0,
     block_norm: bool = False,
+    dec_hi: Optional[Sequence[float]] = None,
 ) -> np.ndarray:
     """``Packets.forward`` output, logical [B, C, P, T] (float64).
 
@@ -151,7 +160,7 @@ def packet_features(
     x = np.asarray(x, dtype=np.float64)
     if x.ndim == 3:
         x = x[:, 0, :]
-    nodes = wpt_nodes(x, dec_lo, level)  # [B, P, T]
+    nodes = wpt_nodes(x, dec_lo, level, dec_hi)  # [B, P, T]
     if block_norm:
         # wavelet_math.py:202-203: node / max|node| over the whole batch node tensor
         mx = np.max(np.abs(nodes), axis=(0, 2), keepdims=True)

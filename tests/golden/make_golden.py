@@ -1,6 +1,7 @@
 """Generates the golden DCNN/LCNN vectors in tests/golden/ by importing the reference.
 
 Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+(`python tests/golden/make_golden.py level14` writes only the level-14 file dcnn_level14_eval.pt).
 
 The reference's ``models.py`` imports torchsummary / timm / torchaudio at module scope for
 code paths that are out of scope here (check_dimensions, ASTModel, augmentations); those
@@ -188,5 +189,35 @@ def main():
                      for k, v in blob.items()})
 
 
+def level14():
+    """Reference-class fixtures at the headline geometry (BASELINE configs[1] / [2]): the reference's DCNN
+    (models.py:240-313) in eval mode on packet images of level 14 -- coif4 [2,1,16384,24] (time_dim 3) and sym5
+    [2,1,16384,10] (time_dim 1), flattend_size 80 960.  Weights come from recipes.fill_dcnn_state_dict (rebuilt from names
+    and shapes by the test), inputs from a seeded generator (rebuilt by the test, checked against the stored digest):
+    the file holds shapes, seeds, digests, logits and labels."""
+    models, DotDict = import_reference_models()
+    sys.path.insert(0, OUT)
+    from recipes import fill_dcnn_state_dict, level14_input
+
+    gold = {}
+    for tag, t_len in (("coif4", 24), ("sym5", 10)):
+        net = models.DCNN(dcnn_args(DotDict, (2, 1, 16384, t_len), time_dim_add=0, flattend_size=80960))
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = fill_dcnn_state_dict(shapes)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        x = level14_input(t_len)
+        with torch.no_grad():
+            y = net(x)
+        gold[tag] = {"shapes": shapes, "t_len": t_len,
+                     "x_digest": torch.stack([x.double().sum(), (x.double() ** 2).sum()]),
+                     "x_head": x.flatten()[:16].clone(), "logits": y, "labels": y.argmax(-1)}
+        print(tag, y)
+    torch.save(gold, os.path.join(OUT, "dcnn_level14_eval.pt"))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "level14":
+        level14()
+    else:
+        main()

@@ -8,6 +8,15 @@ from src.audiofakedetect.models import DCNN
 
 
 def get_config() -> dict:
+    cfg = _grid()
+    if os.environ.get("AFD_TEST_DEFAULT_WAVELET") == "1":
+        # leave --wavelet to the parser's default (sym8: 101 time steps, time_dim_add 0 as scripts/start_exps.sh:9)
+        del cfg["wavelet"]
+        cfg["time_dim_add"] = [0]
+    return cfg
+
+
+def _grid() -> dict:
     return {
         "transform": ["packets"], "wavelet": ["sym5"], "num_of_scales": [256],
         "learning_rate": [0.0004], "weight_decay": [0.001], "epochs": [1], "batch_size": [8],

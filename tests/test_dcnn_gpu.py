@@ -258,6 +258,31 @@ def test_training_step_without_the_normalised_tensors(input_dim, flat, expect, m
         assert torch.allclose(res[0][2][k], res[1][2][k], rtol=1e-6, atol=1e-7), k
 
 
+@pytest.mark.parametrize("tag", ["coif4", "sym5"])
+def test_level14_eval_matches_reference_class(tag):
+    """BASELINE configs[1] / [2] geometry against the REFERENCE CLASS itself: tests/golden/dcnn_level14_eval.pt holds
+    the eval logits of the reference's DCNN (models.py:240-313) on [2,1,16384,24] (coif4) and [2,1,16384,10] (sym5),
+    flattend_size 80 960 (tests/golden/make_golden.py level14).  Weights and inputs are rebuilt from the recipes the
+    generator used; logits within 1e-4, labels bit-exact."""
+    import sys
+
+    sys.path.insert(0, GOLD)
+    from recipes import fill_dcnn_state_dict, level14_input
+
+    g = torch.load(os.path.join(GOLD, "dcnn_level14_eval.pt"), map_location="cpu")[tag]
+    x = level14_input(g["t_len"])
+    assert torch.equal(x.flatten()[:16], g["x_head"])
+    assert torch.allclose(torch.stack([x.double().sum(), (x.double() ** 2).sum()]), g["x_digest"], rtol=1e-12)
+    net = DCNN(_args(x.shape, flattend_size=80960))
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == g["shapes"]
+    net.load_state_dict(fill_dcnn_state_dict(g["shapes"]), strict=True)
+    net.cuda().eval()
+    with torch.no_grad():
+        y = net(x.cuda())  # the permuted view [B, C, P, T] over memory [B, C, T, P], as Packets returns it
+    assert (y.cpu() - g["logits"]).abs().max().item() <= 1e-4
+    assert torch.equal(y.argmax(-1).cpu(), g["labels"])
+
+
 @pytest.mark.parametrize("wavelet,t_len", [("coif4", 24), ("sym5", 10)])
 def test_full_width_level14_step_matches_cpu_restatement(wavelet, t_len):
     """BASELINE configs[1] / configs[2] geometry at full width (16384 packets x 24 time steps for

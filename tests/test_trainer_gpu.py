@@ -29,6 +29,20 @@ def test_entry_point_runs_like_train_sh(tmp_path):
     assert "seed 0: steps 0" in out2.stdout and "results seed 0" in out2.stdout, out2.stdout[-2000:]
 
 
+def test_entry_point_with_the_default_wavelet(tmp_path):
+    """No --wavelet flag: the reference's default sym8 (utils.py:84-89), as `scripts/train.sh` runs when its fourth
+    argument is sym8 (scripts/start_exps.sh:9); flattend_size 320 / time_dim_add 0 come from the grid config."""
+    cmd = [sys.executable, "-m", "src.audiofakedetect.train_classifier", "--log-dir", str(tmp_path),
+           "--transform", "packets", "--num-of-scales", "256", "--log-scale", "--model", "modules",
+           "--init-seeds", "0", "--synthetic", "--config", os.path.join(ROOT, "tests", "synthetic_config.py")]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, AFD_TEST_DEFAULT_WAVELET="1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "seed 0: steps 2" in out.stdout, out.stdout[-2000:]
+    snaps = os.listdir(tmp_path / "models") if os.path.isdir(tmp_path / "models") else []
+    assert all("packetssym8" in f for f in snaps)
+
+
 def test_entry_point_with_block_norm_statistics(tmp_path):
     """--block-norm --calc-normalization: per-node statistics file + max-normalised features
     (reference wavelet_math.py:356-378, :436-447)."""
