@@ -80,7 +80,7 @@ def test_bench_line_has_the_contract_fields(workload):
         assert all(0.0 < f["frac_of_hbm_peak"] <= 1.0 and 0.0 < f["frac_of_f32_peak"] <= 1.0 for f in d["frontend_only"])
         # and so do the other BASELINE configurations (configs[0], [2], [4] and the shipped level-8 models)
         sec = {f["workload"]: f for f in d["secondary"]}
-        assert len(sec) == 5 and not any("error" in f for f in d["secondary"]), d["secondary"]
+        assert len(sec) == 6 and not any("error" in f for f in d["secondary"]), d["secondary"]
         for f in d["secondary"]:
             assert f["ms_per_step"] > 0 and 0.0 < f["frac"] <= 1.0 and f["dominant_class"], f
         lcnn = sec["STFT(n_fft 511, hop 220) + LCNN eval forward (bf16 matrix products)"]
