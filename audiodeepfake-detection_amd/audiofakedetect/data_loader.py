@@ -260,28 +260,46 @@ class NativeFrameLoader:
     own ``__getitem__`` (same values, slower).
     """
 
+    AUTO_STEP_MS = 15.0  # prefetch pays above this consumer step time (level-14 steps: 23-45 ms), not on the 5 ms steps
+    AUTO_PROBE = 3       # consumer gaps measured before the choice
+
     def __init__(self, dataset: "CustomDataset", batch_size: int, device, shuffle: bool = True, seed: int = 0,
-                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8, prefetch: int = 0) -> None:
+                 drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8, prefetch="auto",
+                 prefetch_readers: int = 2) -> None:
         self.ds = dataset
         self.dataset = dataset  # the attribute the trainer reads from a torch DataLoader
         self.batch_size = int(batch_size)
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())  # the worker thread needs an explicit index
         self.shuffle, self.seed, self.drop_last = shuffle, seed, drop_last
         self.rank, self.world, self.threads = rank, world, threads
         self.epoch = 0
         self._banks: dict = {}
-        # prefetch = 1 (opt-in; AFD_LOADER_PREFETCH overrides): batches prepared one ahead of the consumer by a background
-        # thread on a side stream (0, the default: in the caller's thread, on its stream).  A trainer that reads its loss back every step (the reference's does, train_classifier.py:
-        # 981-989) only asks for batch k + 1 when step k has finished: read, copy and resampling of the next batch then
-        # all lie between two steps -- +0.9 ms on the level-14 step -- unless they were done during step k.
-        prefetch = int(os.environ.get("AFD_LOADER_PREFETCH", prefetch))
-        self.prefetch = int(prefetch) if self.device.type == "cuda" else 0
+        # prefetch: 1 = batches prepared one ahead of the consumer by a background thread on a side stream; 0 = in the
+        # caller's thread, on its stream; "auto" (default; AFD_LOADER_PREFETCH=0/1 overrides) = start in the caller's
+        # thread, measure the time the consumer spends between two batches over the first AUTO_PROBE of them, and hand
+        # the rest of the epoch -- and the following epochs -- to the background thread when that is above
+        # AUTO_STEP_MS.  A trainer that reads its loss back every step (the reference's does, train_classifier.py:981-989)
+        # only asks for batch k + 1 when step k has finished: read, copy and resampling of the next batch then all lie
+        # between two steps (+1.1-1.4 ms on the 45 ms level-14 step, +0.7-0.9 when they were done during step k); on the
+        # 5 ms level-8 / STFT steps the trainer's own thread is busy issuing launches and the worker takes its core.
+        env = os.environ.get("AFD_LOADER_PREFETCH")
+        if env is not None:
+            prefetch = int(env)
+        if self.device.type != "cuda":
+            prefetch = 0
+        self.prefetch = prefetch if prefetch == "auto" else int(prefetch)
+        self._auto_choice = None  # the measured decision of an "auto" loader (kept over epochs)
+        self.consumer_ms = None   # the consumer's measured time between batches (an "auto" loader's probe)
         self._side = None
+        self._stale_workers: list = []
         # reader threads of a prefetching loader: it has a whole step to read 128 windows (5.6 MB from the page cache), and
         # more threads take the cores the trainer's own thread needs to keep the GPU's queue filled -- level-14 step,
         # B = 128 (tools/e2e_probe.py): resident batch 44.5-44.9 ms; in the caller's thread 45.5 (16 readers) / 46.0 (1);
         # prefetching with 16 readers 50.3, with 4 / 2 / 1: 45.3 / 45.05 / 45.2
-        self._readers = min(self.threads, 2) if self.prefetch > 0 else self.threads
+        self.prefetch_readers = max(1, int(prefetch_readers))
+        self._readers = self.threads
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = int(epoch)
@@ -336,16 +354,44 @@ class NativeFrameLoader:
         return ring, slot
 
     def __iter__(self):
-        if self.prefetch <= 0:
-            yield from self._batches()
+        import time
+
+        mode = self.prefetch
+        if mode == "auto" and self._auto_choice is not None:
+            mode = self._auto_choice
+        if mode == "auto":
+            # probe: the first batches in the caller's thread, timing what the consumer does between them
+            gaps = []
+            done = 0
+            for item in self._batches(0, self.AUTO_PROBE + 1):
+                t0 = time.perf_counter()
+                yield item
+                gaps.append(1e3 * (time.perf_counter() - t0))
+                done += 1
+            if done < self.AUTO_PROBE + 1:
+                return  # a short epoch: nothing left to hand over (the choice is made on a later, longer one)
+            self.consumer_ms = sum(gaps[1:]) / len(gaps[1:])  # the first gap holds the consumer's warm-up
+            self._auto_choice = 1 if self.consumer_ms >= self.AUTO_STEP_MS else 0
+            mode = self._auto_choice
+            start = done
+        else:
+            start = 0
+        if mode <= 0:
+            self._readers = self.threads
+            yield from self._batches(start)
             return
+        yield from self._prefetched(start, int(mode))
+
+    def _prefetched(self, start: int, depth: int):
         import queue
         import threading
+        import warnings
 
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
         side = self._side
-        q: "queue.Queue" = queue.Queue(maxsize=self.prefetch)
+        self._readers = min(self.threads, self.prefetch_readers)
+        q: "queue.Queue" = queue.Queue(maxsize=depth)
         stop = threading.Event()
 
         def put(x) -> bool:
@@ -361,7 +407,7 @@ class NativeFrameLoader:
             try:
                 torch.cuda.set_device(self.device)
                 with torch.cuda.stream(side):  # (thread-local: the library calls below pick it up as the current stream)
-                    for item in self._batches():
+                    for item in self._batches(start):
                         ev = torch.cuda.Event()
                         ev.record(side)
                         if not put((item, ev)):
@@ -389,8 +435,13 @@ class NativeFrameLoader:
         finally:
             stop.set()
             th.join(timeout=10.0)
+            if th.is_alive():
+                # stuck in a file read or an event wait: keep it referenced (it still owns buffers of this loader) and say so
+                self._stale_workers.append(th)
+                warnings.warn("NativeFrameLoader: the prefetch thread did not stop within 10 s; it is left running")
 
-    def _batches(self):
+    def _batches(self, start: int = 0, stop: Optional[int] = None):
+        """Batches start .. stop-1 of this epoch's order (all of them by default)."""
         import ctypes
 
         from . import _native
@@ -401,7 +452,7 @@ class NativeFrameLoader:
         target = int(self.ds.resample_rate)
         n_target = int(round(target * float(self.ds.seconds)))
         stream = torch.cuda.current_stream(self.device)
-        for b in range(len(self)):
+        for b in range(start, len(self) if stop is None else min(stop, len(self))):
             sel = idx[b * self.batch_size:(b + 1) * self.batch_size]
             batch = rows[sel]
             n = len(sel)

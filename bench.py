@@ -340,21 +340,23 @@ def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads:
         loader = NativeFrameLoader(ds, batch_size, device, shuffle=True, seed=0, drop_last=True, threads=threads)
         done, t0 = 0, None
         epoch = 0
-        while done < steps + 2:
+        untimed = loader.AUTO_PROBE + 2  # pinned buffers, first file reads, and the loader's own probe of the step time
+        while done < steps + untimed:
             loader.set_epoch(epoch)
             epoch += 1
             for batch in loader:
-                if done == 2:  # two untimed steps: pinned buffers, first file reads
+                if done == untimed:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                 trainer._run_batch(0, batch)
                 done += 1
-                if done >= steps + 2:
+                if done >= steps + untimed:
                     break
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         return {"value": batch_size * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                 "frames_on_disk": len(ds), "reader_threads": threads,
+                "loader_prefetch": loader._auto_choice, "loader_measured_step_ms": loader.consumer_ms,
                 "path": "16-bit PCM WAV files (page cache) -> afd_wav_read_windows -> pinned int16 -> H2D -> "
                         "afd_pcm16_resample -> the same train step"}
     finally:
@@ -465,6 +467,14 @@ def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3)
             out.append({"workload": WORKLOADS[name][5], "error": f"{type(exc).__name__}: {exc}"})
         gc.collect()
         torch.cuda.empty_cache()
+    # BASELINE configs[0] names a CPU path of its own ("STFT + DCNN, batch=128, CPU reference path"): the torch-CPU
+    # restatement of that configuration at the protocol's B = 128 (front end and full train step), beside its GPU figure
+    for entry in out:
+        if entry.get("workload") == WORKLOADS["stft"][5] and "error" not in entry and rank == 0:
+            try:
+                entry["cpu_baseline"] = cpu_baseline("stft", 128, 128, steps=3, fe_batches=5)
+            except Exception as exc:  # noqa: BLE001
+                entry["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
 
 

@@ -83,6 +83,9 @@ def test_bench_line_has_the_contract_fields(workload):
         assert len(sec) == 6 and not any("error" in f for f in d["secondary"]), d["secondary"]
         for f in d["secondary"]:
             assert f["ms_per_step"] > 0 and 0.0 < f["frac"] <= 1.0 and f["dominant_class"], f
+        # configs[0] names a CPU path: its own CPU leg rides on its entry, at the protocol's batch
+        c0 = sec["STFT(n_fft 511, hop 220) + DCNN train step"]["cpu_baseline"]
+        assert c0["kind"] == "port" and c0["value"] > 0 and c0["front_end_batch"] == 128 and c0["step_batch"] == 128
         lcnn = sec["STFT(n_fft 511, hop 220) + LCNN eval forward (bf16 matrix products)"]
         assert lcnn["dtype"] == "bf16"
         # configs[4]: accuracy / EER of the evaluation loop on the synthetic cross-generator labels, and the batch a

@@ -173,12 +173,29 @@ def test_native_loader_matches_the_dataset(tmp_path):
                 write_wav(root / name / f"{i}.wav", sig, rate)
         ds = get_costum_dataset(data_path=str(root), save_path=str(root / "idx"), ds_type="train", seconds=1,
                                 resample_rate=22050, limit=-1)
-        loader = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4)
-        # prefetch=1 (opt-in): batches prepared one ahead by a background thread on a side stream ...
-        ahead = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=1)
-        assert loader.prefetch == 0 and ahead.prefetch == 1
+        loader = NativeFrameLoader(ds, 8, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=0)
+        # prefetch=1: batches prepared one ahead by a background thread on a side stream ...
+        ahead = NativeFrameLoader(ds, 8, "cuda", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=1)
+        assert loader.prefetch == 0 and ahead.prefetch == 1 and ahead.device.index is not None
         for got, want in zip(ahead, loader):  # ... are the batches of the in-thread form
             assert torch.equal(got["audio"], want["audio"]) and torch.equal(got["label"], want["label"])
+        if rate == 22050:
+            # the default policy: probe the consumer's time between batches in the caller's thread, then hand the rest
+            # of the epoch (and later epochs) to the background thread iff that time is above AUTO_STEP_MS
+            import time
+
+            for pause, choice in ((0.0, 0), (0.03, 1)):
+                auto = NativeFrameLoader(ds, 2, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4)
+                plain = NativeFrameLoader(ds, 2, "cuda:0", shuffle=True, seed=3, drop_last=False, threads=4, prefetch=0)
+                assert auto.prefetch == "auto" and len(auto) > auto.AUTO_PROBE + 2
+                for _ in range(2):  # second epoch: the remembered choice from its first batch on
+                    n = 0
+                    for got, want in zip(auto, plain):
+                        assert torch.equal(got["audio"], want["audio"]) and torch.equal(got["label"], want["label"])
+                        time.sleep(pause)
+                        n += 1
+                    assert n == len(plain)
+                assert auto._auto_choice == choice, (pause, auto.consumer_ms)
         it = iter(ahead)  # a consumer that stops early leaves no thread behind
         next(it)
         it.close()
