@@ -340,7 +340,9 @@ def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads:
         loader = NativeFrameLoader(ds, batch_size, device, shuffle=True, seed=0, drop_last=True, threads=threads)
         done, t0 = 0, None
         epoch = 0
-        untimed = loader.AUTO_PROBE + 2  # pinned buffers, first file reads, and the loader's own probe of the step time
+        # untimed: pinned buffers, first file reads, the loader's own probe of the step time (AUTO_PROBE + 1 batches in the
+        # caller's thread) and the hand-over to its background thread -- the whole first epoch and two batches of the second
+        untimed = len(loader) + 2
         while done < steps + untimed:
             loader.set_epoch(epoch)
             epoch += 1
@@ -403,7 +405,7 @@ def frontend_lines(device, _native, launches: int = 20):
     return out
 
 
-def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3):
+def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3, cpu_threads: int = 16):
     """The other BASELINE configurations measured in this same process after the timed region, so that the driver's
     own run of the default command records them: configs[2] per GPU (packets-sym5 level 14), the level-8 models the
     reference ships (coif4, sym5) and its default wavelet sym8, configs[0] (STFT + DCNN) and configs[4] (STFT + LCNN evaluation, bf16 matrix
@@ -472,7 +474,7 @@ def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3)
     for entry in out:
         if entry.get("workload") == WORKLOADS["stft"][5] and "error" not in entry and rank == 0:
             try:
-                entry["cpu_baseline"] = cpu_baseline("stft", 128, 128, steps=3, fe_batches=5)
+                entry["cpu_baseline"] = cpu_baseline("stft", 128, 128, steps=3, fe_batches=5, threads=cpu_threads)
             except Exception as exc:  # noqa: BLE001
                 entry["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     return out
@@ -769,7 +771,7 @@ def main() -> None:
             fe_lines = [{"error": f"{type(exc).__name__}: {exc}"}]
     secondary = None
     if a.workload == "coif4-l14" and world == 1 and a.secondary:
-        secondary = secondary_lines(device, _native, rank)
+        secondary = secondary_lines(device, _native, rank, cpu_threads=a.cpu_threads)
         log("secondary: " + "; ".join(f"{f['workload']}: {f['ms_per_step']:.3f} ms" if "ms_per_step" in f else
                                       f"{f['workload']}: {f['error']}" for f in secondary))
     e2e = None

@@ -50,7 +50,9 @@ def rep():
 print("prepared WAV batches    %.3f ms/step" % run(rep(), steps))
 print("loader, caller's thread %.3f ms/step" % run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=0, threads=16)), steps))
 for th in (16, 4, 2, 1):
-    print("loader, prefetch thread, %2d reader threads %.3f ms/step" % (th, run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=1, threads=th)), steps)))
+    print("loader, prefetch thread, %2d reader threads %.3f ms/step" % (th, run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=1, threads=16, prefetch_readers=th)), steps)))
+auto = NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, threads=16)
+print("loader, auto policy     %.3f ms/step (choice %s after measuring %.1f ms between batches)" % (run(cycle(auto), steps + 4), auto._auto_choice, auto.consumer_ms or -1))
 for th in (4, 1):
     print("loader, caller's thread, %2d reader threads %.3f ms/step" % (th, run(cycle(NativeFrameLoader(ds, 128, dev, shuffle=True, seed=0, prefetch=0, threads=th)), steps)))
 print("resident batch          %.3f ms/step" % run(iter(lambda: res, None), steps))
