@@ -49,14 +49,13 @@ struct T3Params {
 // offsets plan_top computes.  The STD instance of the kernel takes them from here, its level loop is unrolled, and
 // every division, pitch product and image offset is a constant: the kernel is bound by instruction issue (64 % of the
 // SIMD cycles vector-ALU busy, 2 358 vector + 675 scalar instructions per wave of which 1 250 are the packed FMAs).
-template <int L> struct Std3 {
+template <int L, int NT = kTopThreads> struct Std3 {
     static constexpr int N = 22050, Ks = kKsMax;
     static constexpr int n_at(int k) {
         int n = N;
         for (int i = 0; i < k; ++i) n = (n + L - 2 + (n & 1)) / 2;
         return n;
     }
-    static constexpr int pitch_at(int k) { return padded_pitch(n_at(k), L); }
     // Outputs per work item at level k (2^(k-2) parents in a half frame, both children of each): the smallest even run
     // with which the level is ONE round of the 1024 threads.  Every level of a half frame holds about 5 500 positions
     // whatever k, so pairs (W = 2) are 2.7 rounds -- three, the last one a quarter full -- and W = 4 is 1.36 rounds, two
@@ -70,9 +69,14 @@ template <int L> struct Std3 {
     // (pitch / 4 odd: conflict-free at any W).
     static constexpr int run_at(int k) {
         const int parents = k < 2 ? 1 : 1 << (k - 2);
-        for (int w = 6; w <= 14; w += (k == Ks ? 2 : 4))
-            if (parents * ((n_at(k) + w - 1) / w) <= kTopThreads) return w;
-        return 14;
+        for (int w = 6; w <= kMaxRun; w += (k == Ks ? 2 : 4))
+            if (parents * ((n_at(k) + w - 1) / w) <= NT) return w;
+        return kMaxRun;
+    }
+    // slack behind a node: the window of an item of the node's last positions (run of the level that READS it) runs
+    // 2 (W - 1) + 3 floats past the last sample it needs (31 floats cover the runs of the 1024-thread instance)
+    static constexpr int pitch_at(int k) {
+        return padded_pitch(n_at(k), L, NT == kTopThreads || k >= Ks ? 31 : 2 * (run_at(k + 1) - 1) + 5);
     }
     static constexpr long size_at(int k) { return (k == 0 ? 1L : (1L << (k - 1))) * pitch_at(k); }
     static constexpr int off_at(int k) { return (k & 1) && k < Ks ? (int)((kTopLdsFloats - size_at(k)) & ~3L) : 0; }
@@ -80,9 +84,10 @@ template <int L> struct Std3 {
 
 // FIN: -1 = the level-Ks image is a hand-off to the deep kernel (no epilogue), else the epilogue mode
 // STD: the standard frame at 8 levels with compile-time geometry (Std3); otherwise everything comes from T3Params
-template <int L, int FIN, bool STD = false>
-__global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p) {
-    using SG = Std3<L>;
+template <int L, int FIN, bool STD = false, int NT = kTopThreads>
+__global__ void __launch_bounds__(NT) wpt3_top_kernel(const T3Params p) {
+    using SG = Std3<L, NT>;
+    constexpr int kTopThreads = NT;  // (shadows the default of wpt_shared.h inside this kernel)
     const int pN = STD ? SG::N : p.N;
     const int pKs = STD ? SG::Ks : p.Ks;
     auto n_of = [&](int k) { return STD ? SG::n_at(k) : p.n[k]; };
@@ -113,7 +118,7 @@ __global__ void __launch_bounds__(kTopThreads) wpt3_top_kernel(const T3Params p)
             const float2* xv = reinterpret_cast<const float2*>(xg);  // frames are 8-byte aligned
             const int n2 = pN >> 1;
             // 11 loads in flight per thread: the 22 050-sample frame arrives in ONE round of memory latency
-            constexpr int UN = 11;
+            constexpr int UN = 11 * 1024 / NT;
             for (int base = 0; base < n2; base += kTopThreads * UN) {
                 float2 v[UN];
 #pragma unroll
@@ -329,16 +334,27 @@ bool is_std_plan(const T3Params& p) {
     return true;
 }
 
-template <int L, int FIN, bool STD>
+// the compile-time LDS plan of an instance with its own thread count fits the arena (same rule as plan_top)
+template <int L, int NT>
+constexpr bool std_plan_fits() {
+    using SG = Std3<L, NT>;
+    for (int k = 0; k < SG::Ks; ++k) {
+        if (SG::size_at(k) > kTopLdsFloats) return false;
+        if (k + 1 < SG::Ks && SG::size_at(k) + SG::size_at(k + 1) > kTopLdsFloats) return false;
+    }
+    return true;
+}
+
+template <int L, int FIN, bool STD, int NT = kTopThreads>
 int launch_top_as(const T3Params& p, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L, FIN, STD>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L, FIN, STD, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTopLdsFloats * 4);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr = true;
     }
-    hipLaunchKernelGGL((wpt3_top_kernel<L, FIN, STD>), dim3((unsigned)p.B * 2), dim3(kTopThreads),
+    hipLaunchKernelGGL((wpt3_top_kernel<L, FIN, STD, NT>), dim3((unsigned)p.B * 2), dim3(NT),
                        (size_t)kTopLdsFloats * 4, stream, p);
     return afd::check_launch("wpt3_top_kernel");
 }
@@ -347,7 +363,17 @@ template <int L, int FIN>
 int launch_top(const T3Params& p, hipStream_t stream) {
     // the tap counts of the shipped and BASELINE configurations get the compile-time instance
     if constexpr (L == 24 || L == 10 || L == 16) {
-        if (is_std_plan<L>(p)) return launch_top_as<L, FIN, true>(p, stream);
+        if (is_std_plan<L>(p)) {
+            if constexpr (L == 10) {
+                static const int nt = getenv("AFD_WPT_TOP_THREADS") ? atoi(getenv("AFD_WPT_TOP_THREADS")) : 1024;
+                // round 6 A/B (profiles/r06_sym5_top_threads.txt): half the threads with runs of 14-22 outputs per work
+                // item (one 16-byte LDS read per 1.7 positions instead of 1.5 per position) is SLOWER, 0.467 -> 0.550 ms
+                // at level 8 / B = 4096; 256 threads with runs of 22-46 spill and take 1.9 ms.  Kept for the record.
+                static_assert(std_plan_fits<L, 512>(), "LDS plan of the 512-thread instance");
+                if (nt == 512) return launch_top_as<L, FIN, true, 512>(p, stream);
+            }
+            return launch_top_as<L, FIN, true>(p, stream);
+        }
     }
     return launch_top_as<L, FIN, false>(p, stream);
 }

@@ -13,6 +13,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 
 constexpr int kMaxTaps = 32;
 constexpr int kTopThreads = 1024;
+constexpr int kMaxRun = 46;  // longest run of outputs per work item the top kernel's compile-time instances use
 constexpr int kTopLdsFloats = 40960;  // 163 840 B: all of a CU's LDS
 constexpr int kKsMax = 8;
 
@@ -128,8 +129,8 @@ template <> struct HasShape3<16> { static constexpr bool value = true; };
 // nodes, pitch / 4 odd (node-strided 16-byte reads hit distinct banks)
 // (round 5: a work item of the top kernel covers up to 14 output positions, its window reaches 2 (14 - 1) + 3 floats past
 // the last sample an item of a node's last positions needs: 31 floats of slack instead of 5)
-constexpr int padded_pitch(int n, int L) {
-    int pitch = n + 2 * (L - 2) + 31;
+constexpr int padded_pitch(int n, int L, int slack = 31) {
+    int pitch = n + 2 * (L - 2) + slack;
     while (pitch % 8 != 4) ++pitch;
     return pitch;
 }
