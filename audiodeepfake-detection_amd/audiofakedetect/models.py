@@ -24,6 +24,44 @@ from . import ops
 from .utils import DotDict
 
 
+class _Unit:
+    """One block of the convolution stack as the plan decided it (`DCNN._plan`)."""
+
+    def __init__(self, **kw) -> None:
+        self.form = ""              # conv1_pool | onepass | bn_conv1x1 | wino_pool | conv
+        self.fold_next = False      # the block's BatchNorm is folded into the next block's 1x1 convolution
+        self.stats = False          # the block's launch also produces the following BatchNorm's batch sums
+        self.epilogue_stats = False  # (what the input fold's applicability asks about that launch)
+        self.pool_link = False      # pool -> BatchNorm hand-over exists
+        self.sum_link = False       # conv -> BatchNorm hand-over exists
+        self.pool_pass = False      # PReLU + max-pool is a pass of its own
+        self.defer = False          # the block's BatchNorm leaves its normalisation to the next 3x3 convolution
+        self.in_fold = False        # ... and this block's convolution applies the previous block's while it loads
+        self.in_shape = self.out_shape = None
+        self.text: list = []
+        self.__dict__.update(kw)
+
+    def describe(self, cnn) -> list:
+        """The `last_plan` entries of this unit."""
+        b = f"block{self.step + 1}: "
+        on_load = " | input bn applied on load" if self.in_fold else ""
+        sums = " | bn sums from the epilogue" if self.stats else ""
+        if self.form == "conv1_pool":
+            return [b + "conv1+prelu+pool" + (" | bn folded into the next 1x1" if self.fold_next else "")]
+        if self.form == "onepass":
+            return [b + "bn+conv1x1+prelu+bn one-pass backward" + (" | bn applied by the next conv" if self.defer else "")]
+        if self.form == "bn_conv1x1":
+            out = [b + "bn folded into conv1x1"]
+        elif self.form == "wino_pool":
+            out = [b + "conv3x3+prelu+pool (winograd epilogue)" + on_load + sums]
+        else:
+            k = cnn[self.conv_i].kernel_size
+            out = [b + f"conv{k[0]}x{k[1]}" + on_load + sums]
+        if self.pool_pass:
+            out.append(b + "prelu+pool pass")
+        return out
+
+
 class DCNN(nn.Module):
     """Deep CNN with dilated convolutions (reference models.py:240-317)."""
 
@@ -59,28 +97,83 @@ class DCNN(nn.Module):
         self.fc = nn.Sequential(nn.Flatten(2), nn.Linear(args.flattend_size, 2))
         self.single_gpu = not args.ddp
         self.sync_bn = bool(args.ddp)
+        self._plans: dict = {}
+        self.last_plan: list = []
 
-    def _next_normalises(self, step: int, shape) -> bool:
-        """May the BatchNorm that ends block `step`, applied to a tensor of `shape`, leave its normalisation to the
-        next block's 3x3 convolution (ops.batch_norm(defer=True))?  Mirrors the branch that block takes in `forward`."""
-        plan, cnn = self._cnn_plan, self.cnn
-        if not self.training or step + 1 >= len(plan) or plan[step][3] is None:
-            return False
-        conv_i, _, pooled, bn_i = plan[step + 1]
-        conv = cnn[conv_i]
-        after = plan[step + 2] if step + 2 < len(plan) else None
-        lib = ops._lib()
-        n, cin, h, w = shape
-        if pooled:
-            probe = SimpleNamespace(is_cuda=True, shape=shape)
-            if conv.in_channels == 1 or not ops.conv3x3_prelu_maxpool_applicable(probe, conv):
-                return False
-            folds_on = bn_i is not None and after is not None and ops.bn_conv1x1_applicable(cnn[bn_i], cnn[after[0]])
-            want_stats = (bn_i is not None and not folds_on
-                          and bool(lib.afd_conv3x3_forward_stats_applicable(cin, h, w, conv.out_channels, 1)))
-        else:
-            want_stats = bn_i is not None and conv.bias is not None
-        return ops.conv3x3_input_fold_applicable(cnn[plan[step][3]], conv, shape, pooled, want_stats)
+    # -- the fusion plan --------------------------------------------------------------------------------------------
+    def _plan(self, shape, in_grad: bool) -> tuple:
+        """The fused units of the convolution stack for an NCHW input of `shape`, decided ONCE per (geometry, mode):
+        a tuple of `_Unit` records that `forward` executes without deciding anything again.
+
+        Pass 1 walks the blocks with shape arithmetic only and picks each block's launch form; pass 2 lets a block's
+        BatchNorm leave its normalisation to the NEXT block's 3x3 convolution (`defer`) from what pass 1 recorded for
+        that block -- its form and whether its launch produces the following BatchNorm's batch sums.  Cached per
+        (shape, training, gradient mode, input gradient, data-parallel statistics, the AFD_NO_* switches)."""
+        key = (tuple(shape), self.training, torch.is_grad_enabled(), bool(in_grad), self.sync_bn, ops.plan_switches())
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        plan, cnn, training = self._cnn_plan, self.cnn, self.training
+        n, c, hh, ww = shape
+        units = []
+        pending = False  # a BatchNorm waiting to be folded into the 1x1 convolution after it
+        grad = bool(in_grad)
+        for step, (conv_i, prelu_i, pooled, bn_i) in enumerate(plan):
+            conv = cnn[conv_i]
+            nxt = plan[step + 1] if step + 1 < len(plan) else None
+            fold_next = (bn_i is not None and pooled and nxt is not None
+                         and ops.bn_conv1x1_applicable(cnn[bn_i], cnn[nxt[0]]))
+            in_shape = (n, c, hh, ww)
+            k, pad, dil = conv.kernel_size[0], conv.padding[0], conv.dilation[0]
+            zh, zw = hh + 2 * pad - dil * (k - 1), ww + 2 * pad - dil * (k - 1)
+            cout = conv.out_channels
+            u = _Unit(step=step, conv_i=conv_i, prelu_i=prelu_i, pooled=pooled, bn_i=bn_i, fold_next=fold_next)
+            if (pooled and conv.in_channels == 1 and conv.kernel_size == (3, 3) and conv.dilation == (1, 1) and not grad):
+                u.form = "conv1_pool"  # single-channel first block: conv + PReLU + pool in one kernel
+                u.stats = fold_next and training  # the folded BatchNorm takes its batch sums from this launch
+            elif (pending and not pooled and bn_i is not None
+                  and ops.bn_conv1x1_prelu_bn_applicable(cnn[plan[step - 1][3]], conv, cnn[bn_i])):
+                u.form = "onepass"  # BatchNorm -> 1x1 convolution -> PReLU -> BatchNorm with a one-pass backward
+            else:
+                u.pool_link = pooled and bn_i is not None and not fold_next
+                probe = SimpleNamespace(is_cuda=True, shape=in_shape)
+                if pending:
+                    u.form = "bn_conv1x1"  # BatchNorm (no affine) -> 1x1 convolution: one pass
+                elif pooled and ops.conv3x3_prelu_maxpool_applicable(probe, conv):
+                    u.form = "wino_pool"   # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue
+                    u.stats = u.pool_link and training
+                    # ... and whether that launch will produce the sums (what the input fold's applicability asks)
+                    u.epilogue_stats = (bn_i is not None and not fold_next and bool(
+                        ops._lib().afd_conv3x3_forward_stats_applicable(c, hh, ww, cout, 1)))
+                else:
+                    u.form = "conv"
+                    u.sum_link = not pooled and bn_i is not None and conv.bias is not None
+                    u.stats = u.sum_link and training
+                    u.epilogue_stats = u.sum_link
+                u.pool_pass = pooled and u.form != "wino_pool"
+            u.in_shape = in_shape
+            pending = fold_next
+            grad = grad or (torch.is_grad_enabled() and any(p.requires_grad for p in conv.parameters()))
+            hh, ww, c = (zh // 2, zw // 2, cout) if pooled else (zh, zw, cout)
+            u.out_shape = (n, c, hh, ww)  # what the block's BatchNorm sees (pooled tensor, or z)
+            units.append(u)
+        # pass 2: may the BatchNorm that ends block s leave its normalisation to block s + 1's convolution?
+        for s_, u in enumerate(units[:-1]):
+            v = units[s_ + 1]
+            if u.form == "conv1_pool":
+                # only the one-pass block consumes the first launch's batch sums (`bn_conv1x1` takes its own pass)
+                u.stats = u.stats and v.form == "onepass"
+            if not training or u.bn_i is None or u.fold_next or u.form == "conv1_pool":
+                continue
+            if v.form not in ("wino_pool", "conv") or (v.pooled and v.form != "wino_pool") or cnn[v.conv_i].in_channels == 1:
+                continue
+            u.defer = ops.conv3x3_input_fold_applicable(cnn[u.bn_i], cnn[v.conv_i], u.out_shape, v.pooled,
+                                                        v.epilogue_stats)
+            v.in_fold = u.defer
+        for u in units:
+            u.text = u.describe(cnn)
+        self._plans[key] = hit = tuple(units)
+        return hit
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # [batch, channels, packets, time] -> NCHW [batch, channels, time, packets]
@@ -89,90 +182,57 @@ class DCNN(nn.Module):
             # STFT features are dense [B, C, F, T]: one tiled transpose on the GPU
             h = ops.transpose_contiguous(x.contiguous())
         cnn = self.cnn
-        # the fused units this forward pass runs, in order: one entry per launch group (read by tests / tools through
-        # `last_plan`; the decisions themselves are the branches below -- shape and mode decide, nothing is cached)
-        plan_log = self.last_plan = []
-        pending_bn = None  # a BatchNorm waiting to be folded into the 1x1 convolution after it
-        link = None        # hand-over of a gradient term from block 2's backward to block 1's
-        bn_link = None     # from a BatchNorm to the 3x3 convolution after it: that layer's backward-data launch
-        #                    also produces the BatchNorm's backward sums
-        for step, (conv_i, prelu_i, pooled, bn_i) in enumerate(self._cnn_plan):
-            conv = cnn[conv_i]
-            slope = cnn[prelu_i].weight
-            nxt = self._cnn_plan[step + 1] if step + 1 < len(self._cnn_plan) else None
-            fold_next = (bn_i is not None and pooled and nxt is not None
-                         and ops.bn_conv1x1_applicable(cnn[bn_i], cnn[nxt[0]]))
-            if (pooled and conv.in_channels == 1 and conv.kernel_size == (3, 3)
-                    and conv.dilation == (1, 1) and not h.requires_grad):
-                # single-channel first block: conv + PReLU + pool in one kernel
-                link = {} if fold_next else None
-                if fold_next and self.training:
-                    link["want_stats"] = True  # the folded BatchNorm takes its batch sums from the first block's launch
-                plan_log.append(f"block{step + 1}: conv1+prelu+pool" + (" | bn folded into the next 1x1" if fold_next else ""))
+        units = self._plan(tuple(h.shape), h.requires_grad)
+        # the fused units this forward pass runs, in order: one entry per launch group (read by tests / tools)
+        self.last_plan = [t for u in units for t in u.text]
+        # Run-time hand-overs between the autograd functions of neighbouring units (tensors of THIS step: batch sums,
+        # gradient terms); which of them exist is the plan's decision:
+        link = None     # block 1 -> block 2: the folded BatchNorm's batch sums forward, a gradient term backward
+        bn_link = None  # a BatchNorm -> the 3x3 convolution after it: statistics forward (a deferred BatchNorm's
+        #                 (mean, invstd)), the BatchNorm's backward sums from that convolution's backward-data launch
+        z = None
+        for u in units:
+            conv, slope = cnn[u.conv_i], cnn[u.prelu_i].weight
+            bn = cnn[u.bn_i] if u.bn_i is not None else None
+            if u.form == "conv1_pool":
+                link = {} if u.fold_next else None
+                if u.stats:
+                    link["want_stats"] = True
                 h = ops.conv1_prelu_maxpool(h, conv.weight, conv.bias, slope, conv.padding[0], link)
-                if fold_next:
-                    pending_bn = cnn[bn_i]
-                elif bn_i is not None:
-                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn)
+                if bn is not None and not u.fold_next:
+                    h = ops.batch_norm(h, bn, None, self.sync_bn)
                 continue
-            fused_pool = False
-            if (pending_bn is not None and not pooled and bn_i is not None
-                    and ops.bn_conv1x1_prelu_bn_applicable(pending_bn, conv, cnn[bn_i])):
-                # training step of block 2: BatchNorm -> 1x1 convolution -> PReLU -> BatchNorm with a one-pass backward
+            if u.form == "onepass":
                 bn_link = {}
-                # (the second BatchNorm's result is not stored when block 3's convolution can build it while it loads)
-                zshape = (h.shape[0], conv.out_channels, h.shape[2], h.shape[3])
-                plan_log.append(f"block{step + 1}: bn+conv1x1+prelu+bn one-pass backward"
-                                + (" | bn applied by the next conv" if self._next_normalises(step, zshape) else ""))
-                h = ops.bn_conv1x1_prelu_bn(h, pending_bn, conv.weight, conv.bias, slope, cnn[bn_i],
-                                            self.sync_bn, link, bn_link, self._next_normalises(step, zshape))
-                pending_bn = link = None
+                h = ops.bn_conv1x1_prelu_bn(h, cnn[units[u.step - 1].bn_i], conv.weight, conv.bias, slope, bn,
+                                            self.sync_bn, link, bn_link, u.defer)
+                link = None
                 continue
             link = None
-            sum_link = None
             in_link, bn_link = bn_link, None
-            # from a pool to the BatchNorm right behind it: that BatchNorm's backward runs inside the pool's
-            pool_link = {} if (pooled and bn_i is not None and not fold_next) else None
-            if pending_bn is not None:
-                # BatchNorm (no affine) -> 1x1 convolution: one pass, normalised tensor never written
-                plan_log.append(f"block{step + 1}: bn folded into conv1x1")
-                z = ops.bn_conv1x1(h, pending_bn, conv.weight, conv.bias, self.sync_bn)
-                pending_bn = None
-            elif pooled and ops.conv3x3_prelu_maxpool_applicable(h, conv):
-                # 3x3 conv + PReLU + 2x2 max-pool in the Winograd epilogue: the conv output is never written
-                if pool_link is not None and self.training:
+            pool_link = {} if u.pool_link else None  # pool -> the BatchNorm right behind it (its backward runs in the pool's)
+            sum_link = {} if u.sum_link else None    # conv -> PReLU -> BatchNorm: the bias gradient comes from the BatchNorm's backward
+            if u.form == "bn_conv1x1":
+                z = ops.bn_conv1x1(h, cnn[units[u.step - 1].bn_i], conv.weight, conv.bias, self.sync_bn)
+            elif u.form == "wino_pool":
+                if u.stats:
                     pool_link["want_stats"] = True  # the BatchNorm behind it takes its batch sums from that launch
-                plan_log.append(f"block{step + 1}: conv3x3+prelu+pool (winograd epilogue)"
-                                + (" | input bn applied on load" if in_link and in_link.get("fold") is not None else "")
-                                + (" | bn sums from the epilogue" if pool_link and pool_link.get("want_stats") else ""))
                 h = ops.conv3x3_prelu_maxpool(h, conv.weight, conv.bias, slope, in_link, pool_link)
-                fused_pool = True
             else:
-                # conv -> (PReLU) -> BatchNorm without a pool in between: the BatchNorm's backward hands the
-                # per-channel sums of its result (this layer's bias gradient) over
-                sum_link = {} if (not pooled and bn_i is not None and conv.bias is not None) else None
-                if sum_link is not None and self.training:
+                if u.stats:
                     sum_link["want_stats"] = True  # the BatchNorm of PReLU(z) takes its batch sums from this launch
                     sum_link["stats_slope"] = slope
-                plan_log.append(f"block{step + 1}: conv{conv.kernel_size[0]}x{conv.kernel_size[1]}"
-                                + (" | input bn applied on load" if in_link and in_link.get("fold") is not None else "")
-                                + (" | bn sums from the epilogue" if sum_link and sum_link.get("want_stats") else ""))
-                z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=pooled,
+                z = ops.conv2d(h, conv.weight, conv.bias, conv.padding[0], conv.dilation[0], pooled=u.pooled,
                                bn_link=in_link, out_link=sum_link)
-            if pooled:
-                if not fused_pool:
-                    plan_log.append(f"block{step + 1}: prelu+pool pass")
+            if u.pooled:
+                if u.pool_pass:
                     h = ops.prelu_maxpool2x2(z, slope, pool_link)
-                if fold_next:
-                    pending_bn = cnn[bn_i]
-                elif bn_i is not None:
+                if bn is not None and not u.fold_next:
                     bn_link = {}
-                    h = ops.batch_norm(h, cnn[bn_i], None, self.sync_bn, bn_link, pool_link,
-                                       defer=self._next_normalises(step, tuple(h.shape)))
+                    h = ops.batch_norm(h, bn, None, self.sync_bn, bn_link, pool_link, defer=u.defer)
             else:
                 bn_link = {}
-                h = ops.batch_norm(z, cnn[bn_i], slope, self.sync_bn, bn_link, sum_link=sum_link,
-                                   defer=self._next_normalises(step, tuple(z.shape)))
+                h = ops.batch_norm(z, bn, slope, self.sync_bn, bn_link, sum_link=sum_link, defer=u.defer)
         # Dropout + [batch, channels, time, packets] -> [batch, time, channels, packets]
         h = ops.dropout_permute(h, cnn[-1].p, self.training)
         dil = self.dil_conv

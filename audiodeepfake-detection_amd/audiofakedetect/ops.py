@@ -36,6 +36,13 @@ def _lib():
     return _native.load()
 
 
+def plan_switches() -> tuple:
+    """The development switches (AFD_* environment variables) a fusion plan was decided under: part of its cache key
+    (the applicability predicates here and in the library read them when they are asked)."""
+    import os
+    return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("AFD_")))
+
+
 def _ws(nbytes: int, device, lane: str = "main") -> torch.Tensor:
     """Grow-only scratch buffer per device and stream lane (conv weight slabs / wgrad partial slabs)."""
     key = (device.type, device.index, lane)

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,19 @@ inline int check_launch(const char* what) {
     if (e != hipSuccess) return fail(AFD_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return AFD_OK;
 }
+
+// "done once on this device": a function attribute (hipFuncSetAttribute: dynamic LDS above 64 KB) belongs to the device
+// the launch goes to, so a process that drives a second GPU has to set it there too.  One bit per device ordinal.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    static unsigned long long bit() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool done() const { return (mask.load(std::memory_order_acquire) & bit()) != 0; }
+    void mark() { mask.fetch_or(bit(), std::memory_order_release); }
+};
 
 // per-kernel HIP-event timing (afd_timing_enable); `work` = algorithmic flops (direct form) or bytes
 bool timing_on();

@@ -900,11 +900,11 @@ size_t wgrad_ws_floats(const WgradGeom& wg) {
 template <int NTW>
 int launch_wgrad_t(const WgradGeom& wg, const float* x, const float* dz, float* part, float* partb,
                    hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NTW>),
+    static afd::PerDeviceOnce attr_set;
+    if (!attr_set.done()) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<NTW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * wg.c.N * wg.c.Cout * (double)wg.c.Hout *
                                                    wg.c.Wout * wg.c.Cin * wg.c.K * wg.c.K, s);
@@ -936,7 +936,6 @@ struct Wgrad2Geom {
     int bufFloats; // one LDS buffer: dz [CO_PAD][PIXP] | patch | pixoff [PIX + 8]
     int nDz;       // dz rows staged per loader thread = CO_PAD / 4
     int nPatch;    // patch elements staged per loader thread
-    int dbg;       // development switches (AFD_W2_DBG): 1 no loader work, 2 no MFMA loop
 };
 
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
@@ -984,7 +983,7 @@ __device__ __forceinline__ void w2_stage_tile(const Wgrad2Geom& w2, const float*
     // same SIMD does not get, so the per-item index arithmetic below would not hide behind
     // the matrix work, it would add to it.
     const bool interior = ox0 + g.PIX <= g.Wout && ix0 >= 0 && ix0 + g.PC <= g.W && iy0 >= 0 &&
-                          iy0 + g.PR <= g.H && cin_left >= g.CI_T && !(w2.dbg & 16);
+                          iy0 + g.PR <= g.H && cin_left >= g.CI_T;
     if (interior) {
         const float* xb = xn + (size_t)iy0 * g.W + ix0;
 #pragma unroll
@@ -1110,7 +1109,7 @@ conv_wgrad2_kernel(const Wgrad2Geom w2, const float* __restrict__ x, const float
         __syncthreads();
         for (; tile < ntiles; tile += wg.S) {
             const long tnext = tile + wg.S;
-            if (tnext < ntiles && !(w2.dbg & 1))
+            if (tnext < ntiles)
                 w2_stage_tile(w2, x, dz, tnext, chunk, ltid, dzo, xo, smem + (cur ^ 1) * w2.bufFloats, bsl);
             __syncthreads();
             cur ^= 1;
@@ -1153,7 +1152,7 @@ conv_wgrad2_kernel(const Wgrad2Geom w2, const float* __restrict__ x, const float
     int cur = 0;
     __syncthreads();  // the first tile is staged
     for (long tile = split; tile < ntiles; tile += wg.S) {
-        if (!(w2.dbg & 2)) {
+        {
             const float* buf = smem + cur * w2.bufFloats;
             // RECT tile: pixel k of the tile sits k columns into the patch row, so every
             // fragment address is a per-lane base plus a compile-time offset (pixels past
@@ -1285,19 +1284,18 @@ int plan_wgrad2(Wgrad2Geom& w2, int N, int Cin, int H, int W, int Cout, int K, i
     wg.S = (int)S;
     if ((size_t)g.CO_PAD * Hout * Wout >= 0x7fffffffULL || (size_t)ct * H * W >= 0x7fffffffULL)
         return AFD_ERR_UNSUPPORTED;  // 32-bit element offsets inside a tile
-    w2.dbg = 0;
     return AFD_OK;
 }
 
 template <int TPW>
 int launch_wgrad2_t(const Wgrad2Geom& w2, const float* x, const float* dz, float* part, float* partb,
                     hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static afd::PerDeviceOnce attr_set;
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad2_kernel<TPW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_set.mark();
     }
     const ConvGeom& g = w2.w.c;
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * g.N * g.Cout * (double)g.Hout * g.Wout * g.Cin * g.K * g.K, s);

@@ -675,12 +675,12 @@ int launch_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N
     if (nt > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1x1 wgrad: too many tiles");
     constexpr int ROWS = (COT + CIT) * 32;
     const size_t lds = (size_t)2 * ROWS * kPitch * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_wgrad_kernel<COT, CIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "conv1x1 wgrad: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     long blocks = (long)num_cus() * kWgBlocksPerCu;
     if (blocks > nt) blocks = nt;

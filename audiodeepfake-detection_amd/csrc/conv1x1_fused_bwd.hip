@@ -376,15 +376,15 @@ extern "C" int afd_conv1x1_prelu_bn_backward(const float* g, const float* z, con
     const int cap = fused_blocks();
     if (blocks > cap) blocks = cap;
     constexpr size_t lds = (size_t)kLdsFloats * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fused_bwd_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1x1_fused_bwd_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "conv1x1 fused backward: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     // waves past the tile count return before writing a slab: zero the workspace rows they own
     const int nslabs = (int)blocks * kWaves;

@@ -735,12 +735,12 @@ template <int MT, int CT = 32>
 int launchw_p(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
     constexpr size_t lds = (size_t)(2 * (MT * 32 * kWPitch + CT * 3 * 68) + MT * 32 * 16) * 4;  // two tile images
     static_assert(lds <= 160 * 1024, "two tile images fit the LDS");
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3p_kernel<MT, CT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad3x3: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((wgrad3x3p_kernel<MT, CT>), dim3(g.S, g.nchunks * 32 / CT), dim3(512), lds, s, g, x, dz, part, partb);
     return afd::check_launch("wgrad3x3p_kernel");
@@ -749,12 +749,12 @@ int launchw_p(const GW& g, const float* x, const float* dz, float* part, float* 
 template <int MT, int CT, int TPW, int TW>
 int launchw_t(const GW& g, const float* x, const float* dz, float* part, float* partb, hipStream_t s) {
     constexpr size_t lds = (size_t)(MT * 32 * kWPitch + CT * (kWPix / TW + 2) * (TW + 4) + MT * 32 * 16) * 4;
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<MT, CT, TPW, TW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wgrad3x3: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((wgrad3x3_kernel<MT, CT, TPW, TW>), dim3(g.S, g.nchunks), dim3(256), lds, s, g, x, dz,
                        part, partb);

@@ -323,12 +323,12 @@ int run_conv(const float* x, const float* w, const float* bias, float* y, int N,
     float* Wt = static_cast<float*>(ws);
     hipLaunchKernelGGL(dilmfma_weights_kernel, dim3((K * K * 256 + 255) / 256), dim3(256), 0, s, w, Wt, C, K, dgrad);
     const size_t lds = (size_t)C * g.plane * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dilmfma_conv_kernel<K, DIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "dilated conv (mfma): %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((dilmfma_conv_kernel<K, DIL>), dim3((unsigned)(N * g.parts)), dim3(kThreadsD), lds, s, g, x, Wt, bias, y);
     return afd::check_launch("dilmfma_conv_kernel");
@@ -347,12 +347,12 @@ int run_wgrad(const float* x, const float* dy, float* dw, float* dbias, int N, i
     const size_t red = (size_t)(K * K * 256 + kThreadsD) * sizeof(float);
     if (red > lds) lds = red;
     if (lds > (size_t)afd::kLdsBytes) return afd::fail(AFD_ERR_UNSUPPORTED, "dilated wgrad (mfma): LDS");
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dilmfma_wgrad_kernel<K, DIL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, afd::kLdsBytes);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "dilated wgrad (mfma): %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     float* slabs = static_cast<float*>(ws);
     hipLaunchKernelGGL((dilmfma_wgrad_kernel<K, DIL>), dim3((unsigned)nslabs), dim3(kThreadsD), lds, s, g, x, dy, slabs);
@@ -380,7 +380,9 @@ size_t ws_bytes_for(int N, int C, int Hin, int Win, int pad) {
 namespace afd {
 
 // Cin == Cout in 5..16, the three (K, dilation) pairs of the reference's stack, and a band that fits LDS -- forward
-// geometry (H, W, pad); the backward-data launch (input = the forward's output, padding (K-1) dil - pad) must fit too
+// geometry (H, W, pad); the backward-data launch (input = the forward's output, padding (K-1) dil - pad) must fit too.
+// The batch size does not enter feasibility (plan<> asks for at least one row band per workgroup, R = 1 always fits when a
+// band fits; N only sets the grid), so the probe plans with a nominal N = 128 while the launches plan with the real one.
 bool dilmfma_applicable(int Cin, int Cout, int H, int W, int K, int pad, int dil) {
     if (getenv("AFD_NO_DIRECT_CONV")) return false;
     if (Cin != Cout || Cin < 5 || Cin > 16 || pad < 0) return false;

@@ -264,11 +264,11 @@ extern "C" int afd_stft_forward(const float* x, int B, int N, int n_fft, int hop
     p.seg = (tg - 1) * hop + n_fft;
     p.segpad = (p.seg + 3) & ~3;
     const size_t lds = ((size_t)p.segpad + 2 * kMargin + 2 * kABuf) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static afd::PerDeviceOnce attr_set;
+    if (!attr_set.done()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_mfma_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set.mark();
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int waves = tg / 32;

@@ -457,15 +457,15 @@ template <int MT, int NT, bool POOL, bool BST = false>
 int launch_wino_t(GW g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * 16 * 32 * kTiles * sizeof(float);  // 128 KB: two epilogue images (V double buffer inside)
     static_assert(2 * 16 * kCh * kTiles * NT * sizeof(float) <= lds, "V double buffer fits the epilogue image");
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, false, POOL, BST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_conv_kernel<MT, NT, true, POOL, BST>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd conv: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     g.wgX = (g.tilesX + kTiles * NT - 1) / (kTiles * NT);
     const long rows = (long)g.N * g.tilesY;

@@ -706,15 +706,15 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * kPos * 64 * KS * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
     const long rows = (long)g.N * g.tilesY;

@@ -675,15 +675,15 @@ int wino44_wgrad_run(const float* x, const float* dy, float* dw, float* dbias, i
     g.partb = dbias ? red + m : nullptr;
     const int cgroups = g.cig * (Cout / (16 * COB));
     const size_t lds = (size_t)kSets * kSetFloats * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_wgrad_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd backward-weight: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     afd::ScopedTiming timing(AFD_K_CONV_WGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     // 36 GEMMs [Cout x Cin] with K = every tile of every k-step (tile padding included)

@@ -294,15 +294,15 @@ int make_plan(WptParams& p) {
 
 template <int LT>
 int launch(const WptParams& p, hipStream_t stream) {
-    static bool attr_set = false;
+    static afd::PerDeviceOnce attr_set;
     const size_t lds_bytes = (size_t)kLdsFloats * sizeof(float);
-    if (!attr_set) {
+    if (!attr_set.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt_fused_kernel<LT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
         if (e != hipSuccess)
             return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_set.mark();
     }
     const unsigned grid = (unsigned)p.B << p.K1;
     const int C = (p.flags & AFD_WPT_SIGN) ? 2 : 1;

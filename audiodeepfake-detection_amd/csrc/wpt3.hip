@@ -347,12 +347,12 @@ constexpr bool std_plan_fits() {
 
 template <int L, int FIN, bool STD, int NT = kTopThreads>
 int launch_top_as(const T3Params& p, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt3_top_kernel<L, FIN, STD, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kTopLdsFloats * 4);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((wpt3_top_kernel<L, FIN, STD, NT>), dim3((unsigned)p.B * 2), dim3(NT),
                        (size_t)kTopLdsFloats * 4, stream, p);

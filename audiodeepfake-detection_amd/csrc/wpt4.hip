@@ -546,12 +546,12 @@ template <int L, int MODE, bool SIGN, int GRP>
 int launch4g(const D4Params& q, int B, hipStream_t stream) {
     constexpr size_t lds = (size_t)Plan4<L, GRP>::lds_floats * 4;
     constexpr int kD4Group = GRP, kD4Threads = 32 * GRP;
-    static bool attr = false;
-    if (!attr) {
+    static afd::PerDeviceOnce attr;
+    if (!attr.done()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wpt4_deep_kernel<L, MODE, SIGN, GRP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "wpt: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
+        attr.mark();
     }
     hipLaunchKernelGGL((wpt4_deep_kernel<L, MODE, SIGN, GRP>), dim3((unsigned)B * (256 / kD4Group)), dim3(kD4Threads), lds,
                        stream, q);

@@ -549,7 +549,10 @@ int afd_lstm_step_bf16_pair(const float* const* pre, const void* const* wh_bf16,
  * (hh = lane / 32, r = lane % 32) of (tile, k-step) is weight_hh[(r / 8) H + 8 tile + r % 8][16 k-step + 8 hh + e], i.e.
  * weight_hh.view(4, H/8, 8, H/16, 2, 8).permute(1, 3, 4, 0, 2, 5) -- a wave's operand load is 1 KB of consecutive bytes.
  * A workgroup owns 32 batch rows of one direction and walks the T steps alone (the recurrence couples only the units of
- * one batch row): h in LDS, c in registers.  H a multiple of 16 up to 256.  Same arithmetic as afd_lstm_step_bf16. */
+ * one batch row): h in LDS, c in registers.  H a multiple of 16 up to 256.  Same products and accumulation order as
+ * afd_lstm_step_bf16; the gates use the hardware exponential and reciprocal (sigmoid = 1 / (1 + exp(-x)), tanh = 2 sigmoid(2x) - 1),
+ * where the step kernel calls expf / tanhf: the two agree to 2e-3 of the largest output over a layer (tests/test_lcnn_gpu.py),
+ * not bit for bit. */
 int afd_blstm_layer_bf16(const float* pre_fwd, const float* pre_rev, const void* wh_fwd_bf16, const void* wh_rev_bf16,
                          float* out, int T, int B, int H, afd_stream_t stream);
 /* One step of the LSTM backward pass (BPTT of nn.LSTM inside BLSTMLayer, models.py:212-237):

@@ -219,7 +219,7 @@ def test_the_fused_units_of_a_training_step_are_the_documented_plan(input_dim, f
 @pytest.mark.parametrize("input_dim,flat,expect", [((3, 1, 16384, 24), 80960, 4), ((3, 1, 256, 101), 320, 4)])
 def test_training_step_without_the_normalised_tensors(input_dim, flat, expect, monkeypatch):
     """The BatchNorms in front of blocks 3-6 hand their statistics to the next convolution instead of writing their
-    result (ops.batch_norm(defer=True), DCNN._next_normalises): at the level-14 and the level-8 geometry all four do,
+    result (ops.batch_norm(defer=True), decided by DCNN._plan): at the level-14 and the level-8 geometry all four do,
     and logits and every gradient equal those of the step with AFD_NO_INPUT_FOLD=1 to the run-to-run noise of either
     path (the layer-level test holds the launches bit-equal)."""
     torch.manual_seed(3)
