@@ -308,7 +308,9 @@ bool plan_top(T3Params& p, int L) {
     long size[kKsMax + 1];
     for (int k = 0; k <= p.Ks; ++k) {
         // node = [L-2 left pad | n samples | L-2 (+1) right pad | up to 3 floats an odd node's last item reads]
-        const int pitch = padded_pitch(p.n[k], L);
+        // (31 floats of slack behind a node cover the runs of the compile-time instances, L = 10 / 16 / 24; the run-time
+        // instance works in pairs and 5 suffice -- which is what lets the 60-tap coif10 keep two levels in LDS)
+        const int pitch = padded_pitch(p.n[k], L, (L == 10 || L == 16 || L == 24) ? 31 : 5);
         p.pitch[k] = pitch;
         const long nodes = k == 0 ? 1 : (1L << (k - 1));
         size[k] = nodes * pitch;
@@ -476,7 +478,7 @@ int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float*
         p.rlo[m] = dec_lo[L - 1 - m];
         p.rhi[m] = dec_hi[L - 1 - m];
     }
-    switch (L) {
+    switch (L) {  // every even length up to kMaxTaps (db2..db32, sym2..sym20, coif1..coif10, dmey, bior / rbio)
         case 4: return launch3<4>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 6: return launch3<6>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 8: return launch3<8>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
@@ -492,6 +494,22 @@ int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float*
         case 28: return launch3<28>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 30: return launch3<30>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         case 32: return launch3<32>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 34: return launch3<34>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 36: return launch3<36>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 38: return launch3<38>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 40: return launch3<40>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 42: return launch3<42>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 44: return launch3<44>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 46: return launch3<46>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 48: return launch3<48>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 50: return launch3<50>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 52: return launch3<52>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 54: return launch3<54>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 56: return launch3<56>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 58: return launch3<58>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 60: return launch3<60>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 62: return launch3<62>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
+        case 64: return launch3<64>(p, dec_lo, dec_hi, out, ws, level, t_len, stream);
         default: return 1;
     }
 }

@@ -11,7 +11,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-constexpr int kMaxTaps = 32;
+constexpr int kMaxTaps = 64;  // the top kernel's limit (coif10: 60, dmey: 62); longer banks take wpt.hip's kernel (128)
 constexpr int kTopThreads = 1024;
 constexpr int kMaxRun = 46;  // longest run of outputs per work item the top kernel's compile-time instances use
 constexpr int kTopLdsFloats = 40960;  // 163 840 B: all of a CU's LDS
