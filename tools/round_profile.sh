@@ -16,6 +16,7 @@ run bench_sym5l14_b128 --workload sym5-l14 --steps 5 --warmup 3 --cpu-frames 0 -
 run bench_coif4l8_b128 --workload coif4-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run bench_sym5l8_b128 --workload sym5-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run bench_stft_b128 --workload stft --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
+run bench_sym8l8_b128 --workload sym8-l8 --steps 10 --warmup 3 --cpu-frames 0 --e2e-steps 0 &&
 run frontend_coif4l14_b128 --workload coif4-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
 run frontend_coif4l14_b4096 --workload coif4-l14-frontend --batch 4096 --steps 20 --warmup 5 --cpu-frames 0 &&
 run frontend_sym5l14_b128 --workload sym5-l14-frontend --steps 30 --warmup 5 --cpu-frames 0 &&
