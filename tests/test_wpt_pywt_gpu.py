@@ -82,3 +82,36 @@ def test_default_wavelet_constructs():
     got, _ = Packets()(x)
     assert got.shape == (3, 1, 256, 101)
     _check(got[:, 0], core["sym8/8"])
+
+
+def test_the_reference_side_stub_of_integration_md_runs_as_written():
+    """INTEGRATION.md shows the ctypes stub a maintainer would put in the reference's wavelet_math.py.  The code block is
+    executed verbatim (with the in-repo `Wavelet` standing in for `pywt.Wavelet`: the stub reads dec_lo / dec_hi /
+    dec_len only) and its result is held to the pywt fixture, at level 8 and at level 14 (workspace path)."""
+    import re
+    import sys
+    import types
+
+    from audiofakedetect import _native, wavelets
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# reference-side stub.*?)```", text, re.S).group(1)
+    block = block.replace('ctypes.CDLL("libafd_hip.so")', f'ctypes.CDLL("{_native.LIB_PATH}")')
+    fake_pywt = types.ModuleType("pywt")
+    fake_pywt.Wavelet = wavelets.Wavelet
+    saved = sys.modules.get("pywt")
+    sys.modules["pywt"] = fake_pywt
+    try:
+        ns: dict = {}
+        exec(compile(block, "INTEGRATION.md", "exec"), ns)
+    finally:
+        if saved is None:
+            del sys.modules["pywt"]
+        else:
+            sys.modules["pywt"] = saved
+    core, deep = _load("pywt_wpt_core.npz"), _load("pywt_wpt_l14.npz")
+    out, _ = ns["packets_mi355x"](torch.from_numpy(core["x"]), wavelets.Wavelet("sym8"), 8, False, False, 2.0)
+    _check(out[:, 0], core["sym8/8"])
+    out, _ = ns["packets_mi355x"](torch.from_numpy(deep["x"]), wavelets.Wavelet("coif4"), 14, False, False, 2.0)
+    _check(out[0, 0], deep["coif4"].astype(np.float64))
