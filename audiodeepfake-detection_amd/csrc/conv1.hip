@@ -207,11 +207,22 @@ conv1_stats_reduce_kernel(const float* __restrict__ part, int rows, int C2, doub
 }
 
 // partial[split][cg][kCG][11]: 9 weight gradients, bias gradient, slope gradient
+//
+// A workgroup takes every S-th tile (256 pooled pixels of one pooled row) of the flat tile list: at any moment the
+// chip works on S consecutive tiles, i.e. a contiguous band of every channel plane (few, wide streams).  Round 6
+// (same-box A/B of five builds, profiles/r06_conv1_bwd_ab.txt; class conv_first = this launch + the forward one):
+//   as it was (two integer divisions per tile on the scalar unit, 31 scalar instructions per pixel and channel)  3.61 ms
+//   tile coordinates advanced by carries instead, wave sums through DPP (kept)                                    3.50
+//   + the PReLU branch as arithmetic                                                                               3.58
+//   + patch rows as one 16-byte load (or two 8-byte loads) per lane instead of four 4-byte loads                    3.97
+//   a workgroup walking DOWN the pooled rows of a column tile (two patch rows carried over, constant address steps) 3.89
+// The wide patch loads lose although they are the same bytes in a quarter of the instructions: neighbouring lanes'
+// 16-byte windows overlap by half, and the one-channel image is the only operand every channel group re-reads.
 __global__ void __launch_bounds__(kT)
 conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
                       const unsigned char* __restrict__ idx, const float* __restrict__ u,
                       const float* __restrict__ slope, float* __restrict__ partial, int N, int H,
-                      int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalTiles,
+                      int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalUnits,
                       const float* __restrict__ aff_alpha, const float* __restrict__ aff_beta, int xcd_split) {
     __shared__ float red[kT / 64][kCG * 11];
     // The channel groups of one split read the same input patches (the one-channel image, 4 rows x 2 KB per tile).  As
@@ -248,52 +259,63 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
         for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
     }
     const size_t plane = (size_t)Hp * Wp;
-    const int ntiles = (int)totalTiles;  // < 2^31 (checked by the host): 32-bit tile arithmetic
+    const int ntiles = (int)totalUnits;  // N * Hp * tilesX < 2^31 (checked by the host): 32-bit tile arithmetic
+    const int nch = min(kCG, Cout - cg * kCG);  // live channels of this group (uniform)
+    // tile t = (image row `row` = n * Hp + py, column tile xc); t advances by S: (row, xc) by (S / tilesX, S % tilesX) with a
+    // carry, (n, py) likewise -- no division in the loop
+    const int dRow = S / tilesX, dXc = S - dRow * tilesX;
+    int row = split / tilesX, xc = split - row * tilesX;
+    int n = row / Hp, py = row - n * Hp;
+    const int dN = dRow / Hp, dPy = dRow - dN * Hp;
     for (int t = split; t < ntiles; t += S) {
-        const int row = t / tilesX;
-        const int xc = t - row * tilesX;
-        const int n = row / Hp;
-        const int py = row - n * Hp;
         const int px = xc * kT + threadIdx.x;
-        if (px >= Wp) continue;
-        float p[4][4];
-        load_patch(x + (size_t)n * H * W, H, W, py, px, pad, p);
-        const size_t o0 = (((size_t)n * Cout + cg * kCG) * Hp + py) * Wp + px;
-        // all 3 * kCG loads of the pixel in flight before the first use (a load -> FMA chain
-        // per channel pays one HBM latency per channel)
-        int code[kCG];
-        float gv[kCG], uv[kCG];
+        if (px < Wp) {
+            const float* xn = x + (size_t)n * H * W;
+            float p[4][4];
+            load_patch(xn, H, W, py, px, pad, p);
+            const size_t o = (((size_t)n * Cout + cg * kCG) * Hp + py) * Wp + px;
+            // all 3 * kCG loads of the pixel in flight before the first use (a load -> FMA chain
+            // per channel pays one HBM latency per channel)
+            int code[kCG];
+            float gv[kCG], uv[kCG];
 #pragma unroll
-        for (int c = 0; c < kCG; ++c) {
-            const bool ok = cg * kCG + c < Cout;
-            const size_t o = o0 + (size_t)c * plane;
-            code[c] = ok ? idx[o] : 0;
-            gv[c] = ok ? du[o] : 0.f;
-            uv[c] = ok ? u[o] : 0.f;
-        }
-#pragma unroll
-        for (int c = 0; c < kCG; ++c) {
-            float g = fmaf(al[c], uv[c], gv[c] + be[c]);
-            if (code[c] & 4) {
-                accs[c] += g * uv[c] * inva;
-                g *= a;
+            for (int c = 0; c < kCG; ++c) {
+                const bool ok = c < nch;
+                const size_t oc = o + (size_t)c * plane;
+                code[c] = ok ? idx[oc] : 0;
+                gv[c] = ok ? du[oc] : 0.f;
+                uv[c] = ok ? u[oc] : 0.f;
             }
-            accb[c] += g;
-            const int pos = code[c] & 3;
-            const float g0 = pos == 0 ? g : 0.f, g1 = pos == 1 ? g : 0.f;
-            const float g2 = pos == 2 ? g : 0.f, g3 = pos == 3 ? g : 0.f;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    float s = acc[c][ky * 3 + kx];
-                    s = fmaf(g0, p[ky][kx], s);
-                    s = fmaf(g1, p[ky][kx + 1], s);
-                    s = fmaf(g2, p[ky + 1][kx], s);
-                    s = fmaf(g3, p[ky + 1][kx + 1], s);
-                    acc[c][ky * 3 + kx] = s;
+            for (int c = 0; c < kCG; ++c) {
+                float g = fmaf(al[c], uv[c], gv[c] + be[c]);
+                if (code[c] & 4) {  // winner was <= 0: the slope's gradient takes g * z = g * u / a, the gradient passes scaled by a
+                    accs[c] += g * uv[c] * inva;
+                    g *= a;
                 }
+                accb[c] += g;
+                const int pos = code[c] & 3;
+                const float g0 = pos == 0 ? g : 0.f, g1 = pos == 1 ? g : 0.f;
+                const float g2 = pos == 2 ? g : 0.f, g3 = pos == 3 ? g : 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float sacc = acc[c][ky * 3 + kx];
+                        sacc = fmaf(g0, p[ky][kx], sacc);
+                        sacc = fmaf(g1, p[ky][kx + 1], sacc);
+                        sacc = fmaf(g2, p[ky + 1][kx], sacc);
+                        sacc = fmaf(g3, p[ky + 1][kx + 1], sacc);
+                        acc[c][ky * 3 + kx] = sacc;
+                    }
+            }
         }
+        xc += dXc;
+        int carry = 0;
+        if (xc >= tilesX) { xc -= tilesX; carry = 1; }
+        py += dPy + carry;
+        n += dN;
+        while (py >= Hp) { py -= Hp; ++n; }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -301,9 +323,8 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
 #pragma unroll
         for (int k = 0; k < 11; ++k) {
             float v = k < 9 ? acc[c][k] : (k == 9 ? accb[c] : accs[c]);
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[wave][c * 11 + k] = v;
+            v = wave_sum63(v);
+            if (lane == 63) red[wave][c * 11 + k] = v;
         }
     }
     __syncthreads();
