@@ -223,7 +223,8 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
                       const unsigned char* __restrict__ idx, const float* __restrict__ u,
                       const float* __restrict__ slope, float* __restrict__ partial, int N, int H,
                       int W, int Cout, int pad, int Hp, int Wp, int tilesX, long totalUnits,
-                      const float* __restrict__ aff_alpha, const float* __restrict__ aff_beta, int xcd_split) {
+                      const float* __restrict__ aff_alpha, const float* __restrict__ aff_beta, int xcd_split,
+                      unsigned wp_magic) {
     __shared__ float red[kT / 64][kCG * 11];
     // The channel groups of one split read the same input patches (the one-channel image, 4 rows x 2 KB per tile).  As
     // grid (cg, split) the eight groups of a split had consecutive block ids -- one per XCD, the image fetched once per
@@ -259,21 +260,23 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
         for (int k = 0; k < 9; ++k) acc[c][k] = 0.f;
     }
     const size_t plane = (size_t)Hp * Wp;
-    const int ntiles = (int)totalUnits;  // N * Hp * tilesX < 2^31 (checked by the host): 32-bit tile arithmetic
+    const int ntiles = (int)totalUnits;  // N * tiles per image < 2^31 (checked by the host): 32-bit tile arithmetic
     const int nch = min(kCG, Cout - cg * kCG);  // live channels of this group (uniform)
-    // tile t = (image row `row` = n * Hp + py, column tile xc); t advances by S: (row, xc) by (S / tilesX, S % tilesX) with a
-    // carry, (n, py) likewise -- no division in the loop
-    const int dRow = S / tilesX, dXc = S - dRow * tilesX;
-    int row = split / tilesX, xc = split - row * tilesX;
-    int n = row / Hp, py = row - n * Hp;
-    const int dN = dRow / Hp, dPy = dRow - dN * Hp;
+    // Tiles run over the FLATTENED pooled pixels of an image (f = py * Wp + px, contiguous in du / u / idx): kT consecutive
+    // f per tile whatever the row length -- a 129-column row (level 8 / STFT) filled half of a 256-column tile, the 8 193
+    // columns of level 14 left a 33rd tile with one pixel.  tile t = (image n, tile tf of the image); t advances by S:
+    // (n, tf) by (S / tilesX, S % tilesX) with a carry -- no division in the loop; tilesX = tiles per image here.
+    const int dN = S / tilesX, dTf = S - dN * tilesX;
+    int n = split / tilesX, tf = split - n * tilesX;
     for (int t = split; t < ntiles; t += S) {
-        const int px = xc * kT + threadIdx.x;
-        if (px < Wp) {
+        const unsigned f = (unsigned)tf * kT + threadIdx.x;
+        if (f < (unsigned)plane) {
             const float* xn = x + (size_t)n * H * W;
+            const int py = (int)(wp_magic ? __umulhi(f, wp_magic) : f / (unsigned)Wp);
+            const int px = (int)f - py * Wp;
             float p[4][4];
             load_patch(xn, H, W, py, px, pad, p);
-            const size_t o = (((size_t)n * Cout + cg * kCG) * Hp + py) * Wp + px;
+            const size_t o = ((size_t)n * Cout + cg * kCG) * plane + f;
             // all 3 * kCG loads of the pixel in flight before the first use (a load -> FMA chain
             // per channel pays one HBM latency per channel)
             int code[kCG];
@@ -310,12 +313,9 @@ conv1_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ du,
                     }
             }
         }
-        xc += dXc;
-        int carry = 0;
-        if (xc >= tilesX) { xc -= tilesX; carry = 1; }
-        py += dPy + carry;
+        tf += dTf;
         n += dN;
-        while (py >= Hp) { py -= Hp; ++n; }
+        if (tf >= tilesX) { tf -= tilesX; ++n; }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -384,7 +384,7 @@ extern "C" size_t afd_conv1_pool_workspace_bytes(int N, int H, int W, int Cout, 
     const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
     if (Hp < 1 || Wp < 1) return 0;
     const int CG = (Cout + kCG - 1) / kCG;
-    const long tiles = (long)N * Hp * ((Wp + kT - 1) / kT);
+    const long tiles = (long)N * (((long)Hp * Wp + kT - 1) / kT);
     return (size_t)bwd_splits(tiles, CG) * CG * kCG * 11 * sizeof(float);
 }
 
@@ -452,9 +452,12 @@ extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, c
     const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
     if (N < 1 || Cout < 1 || Hp < 1 || Wp < 1) return afd::fail(AFD_ERR_ARG, "conv1 bwd: bad geometry");
     const int CG = (Cout + kCG - 1) / kCG;
-    const int tilesX = (Wp + kT - 1) / kT;
-    const long tiles = (long)N * Hp * tilesX;
-    if (tiles > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 bwd: too many tiles");
+    const int tilesX = (int)(((long)Hp * Wp + kT - 1) / kT);  // tiles of kT consecutive pooled pixels per image
+    const long tiles = (long)N * tilesX;
+    if (tiles > 0x7fffffffL || (long)Hp * Wp > 0x7fffffffL) return afd::fail(AFD_ERR_UNSUPPORTED, "conv1 bwd: too many tiles");
+    // row of a flat pixel index by multiply-high: exact while f * (magic * Wp - 2^32) < 2^32 for every f < Hp * Wp
+    unsigned wp_magic = (unsigned)((0x100000000ULL + (unsigned)Wp - 1) / (unsigned)Wp);
+    if (((unsigned long long)wp_magic * Wp - 0x100000000ULL) * (unsigned long long)((long)Hp * Wp) >= 0x100000000ULL) wp_magic = 0;
     const int S = bwd_splits(tiles, CG);
     if (!ws || ws_bytes < (size_t)S * CG * kCG * 11 * sizeof(float))
         return afd::fail(AFD_ERR_WORKSPACE, "conv1 bwd: workspace too small");
@@ -466,7 +469,7 @@ extern "C" int afd_conv1_pool_backward_affine(const float* x, const float* du, c
     timing.bytes(bwd_bytes);
     hipLaunchKernelGGL(conv1_pool_bwd_kernel, dim3(CG, S), dim3(kT), 0, AFD_STREAM, x, du, idx, u, slope,
                        partial, N, H, W, Cout, pad, Hp, Wp, tilesX, tiles, alpha, beta,
-                       (CG == 8 && S % 8 == 0) ? 1 : 0);
+                       (CG == 8 && S % 8 == 0) ? 1 : 0, wp_magic);
     const int total = CG * kCG * 11;
     hipLaunchKernelGGL(conv1_bwd_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, AFD_STREAM, partial,
                        dw, dbias, dslope, Cout, CG, S);
