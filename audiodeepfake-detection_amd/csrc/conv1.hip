@@ -38,7 +38,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4u1 __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned u32u1 __attribute__((aligned(1)));
 
-constexpr int kFP = 4;  // pooled pixels per thread of the forward kernel
+constexpr int kFwdPixels = 4;  // pooled pixels per thread of the forward kernel's row form
 
 // A thread owns kFP consecutive pooled pixels of one row: its results leave as one 16-byte store of u and one
 // 4-byte store of the codes per channel (a wave writes 1 KB + 256 B per instruction instead of 256 B + 64 B --
@@ -64,17 +64,29 @@ __device__ __forceinline__ float wave_sum63(float v) {
 // STATS (round 5): the kernel also sums, per channel, the pooled values and their squares over its workgroup's pixels --
 // the batch statistics of the BatchNorm behind the pool (reference models.py:258-260) -- into one partial row
 // [sum | sum of squares] per workgroup: the statistics pass over the 3.5 GB pooled tensor (0.6 ms at level 14) is gone
-template <bool STATS>
+// FLAT (round 6; narrow images, one pooled pixel per thread): the threads run over the FLATTENED pooled pixels of an image
+// (f = py * Wp + px) instead of over one row -- on the 129-column rows of the level-8 / STFT model the row form filled
+// 33 lanes of one wave per row (the kernel is bound by its vector instructions: 0.18 -> 0.10 ms at batch 128).
+template <bool STATS, int kFP = 4, bool FLAT = false>
 __global__ void __launch_bounds__(kT)
 conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                       const float* __restrict__ bias, const float* __restrict__ slope,
                       float* __restrict__ u, unsigned char* __restrict__ idx, int H, int W, int Cout,
                       int pad, int Hp, int Wp, float* __restrict__ stat_part) {
+    static_assert(!FLAT || (kFP == 1 && !STATS), "the flat form takes one pixel per thread and no statistics");
     constexpr int PC = 2 * kFP + 2;  // patch columns
     __shared__ float wsum[STATS ? kT / 64 : 1][STATS ? 2 * 128 : 1];  // [wave][sum | squares][channel <= 128]
-    const int px0 = (blockIdx.x * kT + threadIdx.x) * kFP;
-    const int py = blockIdx.y;
+    int px0, py;
     const int n = blockIdx.z;
+    if constexpr (FLAT) {
+        const unsigned f = blockIdx.x * kT + threadIdx.x;
+        if (f >= (unsigned)(Hp * Wp)) return;
+        py = (int)(f / (unsigned)Wp);
+        px0 = (int)f - py * Wp;
+    } else {
+        px0 = (blockIdx.x * kT + threadIdx.x) * kFP;
+        py = blockIdx.y;
+    }
     if (!STATS && px0 >= Wp) return;
     const bool live = px0 < Wp;  // STATS: the threads stay for the reductions; dead lanes of a live wave compute on zeros
     // a wave entirely past the row (narrow images: 129 pooled columns use 33 of a workgroup's 256 threads) only zeroes its
@@ -163,11 +175,15 @@ conv1_pool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                 wsum[wave][128 + co] = s2;
             }
         }
-        if (whole) {
-            f4u1 v4 = {best[0], best[1], best[2], best[3]};
-            *reinterpret_cast<f4u1*>(u + o) = v4;
-            *reinterpret_cast<u32u1*>(idx + o) = code;
-        } else if (live) {
+        if constexpr (kFP == 4) {
+            if (whole) {
+                f4u1 v4 = {best[0], best[1], best[2], best[3]};
+                *reinterpret_cast<f4u1*>(u + o) = v4;
+                *reinterpret_cast<u32u1*>(idx + o) = code;
+                continue;
+            }
+        }
+        if (live) {
 #pragma unroll
             for (int j = 0; j < kFP; ++j)
                 if (px0 + j < Wp) {
@@ -391,7 +407,7 @@ extern "C" size_t afd_conv1_pool_workspace_bytes(int N, int H, int W, int Cout, 
 extern "C" size_t afd_conv1_pool_stats_workspace_bytes(int N, int H, int W, int Cout, int pad) {
     const int Hp = (H + 2 * pad - 2) / 2, Wp = (W + 2 * pad - 2) / 2;
     if (Hp < 1 || Wp < 1 || Cout < 1 || Cout > 128) return 0;
-    return (size_t)N * Hp * ((Wp + kT * kFP - 1) / (kT * kFP)) * 2 * Cout * sizeof(float);
+    return (size_t)N * Hp * ((Wp + kT * kFwdPixels - 1) / (kT * kFwdPixels)) * 2 * Cout * sizeof(float);
 }
 
 // Whether the sums are worth taking in the forward launch.  On a row narrower than one workgroup (level 8 / STFT: 129
@@ -400,7 +416,7 @@ extern "C" size_t afd_conv1_pool_stats_workspace_bytes(int N, int H, int W, int 
 // saves 0.5 ms of the step.  The kernel itself is correct at every width.
 extern "C" int afd_conv1_pool_stats_applicable(int N, int H, int W, int Cout, int pad) {
     const int Wp = (W + 2 * pad - 2) / 2;
-    return afd_conv1_pool_stats_workspace_bytes(N, H, W, Cout, pad) > 0 && Wp >= kT * kFP;
+    return afd_conv1_pool_stats_workspace_bytes(N, H, W, Cout, pad) > 0 && Wp >= kT * kFwdPixels;
 }
 
 extern "C" int afd_conv1_pool_forward(const float* x, const float* w, const float* bias,
@@ -420,6 +436,14 @@ extern "C" int afd_conv1_pool_forward(const float* x, const float* w, const floa
     const double fwd_bytes = (double)N * (4.0 * H * W + 5.0 * Cout * Hp * Wp);
     afd::ScopedTiming timing(AFD_K_CONV_FIRST, fwd_bytes, AFD_STREAM);
     timing.bytes(fwd_bytes);
+    if (!sums && Wp < 512 && (long)Hp * Wp < 0x7fffffffL) {
+        // narrow rows: threads over the flattened pooled pixels of an image
+        const dim3 fgrid((unsigned)(((long)Hp * Wp + kT - 1) / kT), 1, N);
+        hipLaunchKernelGGL((conv1_pool_fwd_kernel<false, 1, true>), fgrid, dim3(kT), 0, AFD_STREAM, x, w, bias, slope, u, idx, H, W,
+                           Cout, pad, Hp, Wp, nullptr);
+        return afd::check_launch("conv1_pool_fwd_kernel(flat)");
+    }
+    constexpr int kFP = 4;
     const dim3 grid((Wp + kT * kFP - 1) / (kT * kFP), Hp, N);
     if (!sums) {
         hipLaunchKernelGGL(conv1_pool_fwd_kernel<false>, grid, dim3(kT), 0, AFD_STREAM, x, w, bias, slope, u, idx, H, W, Cout, pad,
