@@ -705,10 +705,8 @@ extern "C" int afd_conv3x3_forward_stats_applicable(int Cin, int H, int W, int C
     return (Cout == 128 || Cout == 32) && afd::wino44_applicable(Cin, H, W, Cout) ? 1 : 0;
 }
 
-static long fwd_stat_rows(int N, int rows, int cols) {
-    const int tilesX = (cols + 3) / 4, tilesY = (rows + 3) / 4;
-    return (long)N * tilesY * ((tilesX + 15) / 16);
-}
+// (the F(4x4) launch pair's workgroups over the rows x cols outputs it computes: wino44.hip knows its own forms)
+static long fwd_stat_rows(int N, int rows, int cols) { return afd::wino44_stat_rows(N, rows, cols); }
 
 extern "C" size_t afd_conv3x3_forward_stats_workspace_bytes(int N, int H, int W, int Cout) {
     const size_t slots = 2 * ((size_t)(Cout + 31) / 32 * 32);

@@ -64,6 +64,10 @@ struct G4 {
     // bn_apply_fwd_kernel's arithmetic (bit-identical values), so the normalised tensor is never written or read
     const float* in_aff;
     const float* in_slope;
+    // border launch, round 6: the last workgroup column holds ONE live tile (129-column images: 33 tile columns = 2 x 16 + 1;
+    // 8 193 columns: 128 x 16 + 1) -- instead of one workgroup per tile row with 15 dead tiles, `tail_groups` workgroups per
+    // image take that tile column of 16 tile rows each (tile slot = tile row).  0 = off.
+    int tail_groups;
     int noflip;  // (development) keep the helper waves of the second workgroup of a CU last: see the kernel's wave roles
     int xcd_map;  // workgroup columns per XCD group (16; 0 / 1 = plain row-major order): see the kernel
     // BatchNorm backward in the epilogue (backward-data launches with the statistics epilogue; round 4): the result g is the
@@ -211,19 +215,36 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // memory side rewards is few, wide streams, not fewer bytes (the class draws 2.4 TB/s, far from the HBM's limit).
     // (afd::xcd_grouped_id; the tile-row-fastest orders of the measurement above are not in the tree)
     int id = afd::xcd_grouped_id((int)blockIdx.x, (int)gridDim.x, g.xcd_map);
-    const int wi = id % g.wxCount;
-    id /= g.wxCount;
-    const int ty = id % g.tilesY;
-    const int n = id / g.tilesY;
-    const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
-    const int tx0 = wx * kTiles;
-    const bool skip5 = g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
+    const int tl = lane & 15;  // tile slot of this lane (transform role and D fragment alike)
+    // TAIL (border launches of images whose last workgroup column holds one live tile): ids past the left-edge
+    // workgroups are tail workgroups -- tile slot tl = tile row 16 tg + tl of tile column tilesX - 1.  There the tile row
+    // is per lane; everything below that is marked "uniform" in terms of ty is uniform in the other workgroups only, and
+    // the two uniform shortcuts of the matrix loop (skip5, row0_only: both skip products with zero operands) are off.
+    const long left_wgs = (long)g.N * g.tilesY;
+    const bool tail = BORDER && g.tail_groups > 0 && id >= left_wgs;  // uniform
+    int ty, n, tx_lane;
+    if (tail) {
+        const int id2 = id - (int)left_wgs;
+        n = id2 / g.tail_groups;
+        const int tyl = (id2 - n * g.tail_groups) * kTiles + tl;
+        ty = tyl < g.tilesY ? tyl : g.tilesY - 1;
+        tx_lane = tyl < g.tilesY ? g.tilesX - 1 : g.tilesX;  // (a slot past the last tile row is a dead tile)
+    } else {
+        const int wxc = (BORDER && g.tail_groups > 0) ? 1 : g.wxCount;
+        const int wi = id % wxc;
+        id /= wxc;
+        ty = id % g.tilesY;
+        n = id / g.tilesY;
+        const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
+        tx_lane = wx * kTiles + tl;
+    }
+    const bool skip5 = !tail && g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
     // PIN: the dense gradient has 2 Hp live rows; a tile row whose patches start on the last of them (4 ty - 1 =
     // 2 Hp - 1: the fourth tile row of block 3's 13-row backward-data at level 14, one output row) has a single
     // non-zero patch row, row 0, and column 0 of B^T is (4, 0, 0, 0, 0, 0): only transform row 0 -- positions 0..5 --
     // is non-zero.  Those workgroups run 6 of the 36 products per chunk (they ran 30) and fetch only those operands:
     // block 3's backward-data 5.50 -> 5.23 ms (a shorter transform for them on top measured level, with spills).
-    const bool row0_only = PIN && 4 * ty - 1 == 2 * g.Hp - 1;  // uniform
+    const bool row0_only = !tail && PIN && 4 * ty - 1 == 2 * g.Hp - 1;  // uniform
 
     // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
     // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
@@ -236,13 +257,12 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     const bool xf = HELP ? (wave & 2) != 0 : tid < CHK * kTiles;
     const bool mm = wave < CG;  // matrix wave
     const int tq = HELP ? (wave & 1) + ((wave >> 2) << 1) : (wave & 3);  // which quarter of a chunk's channels
-    const int tl = lane & 15;
     // the patch of channel 4 ks_t + kq_t of the chunk: KS = 4: wave = kq_t, lane = (ks_t, tile); KS = 2: wave = ks_t,
     // lane = (kq_t, tile)
     const int kq_t = KS == 4 ? tq : (lane >> 4);
     const int ksx = KS == 4 ? (lane >> 4) : (wave & 1);
     const int ch = 4 * ksx + kq_t;
-    const int txp = tx0 + tl;
+    const int txp = tx_lane;
     const int iy0 = 4 * ty - 1, ix0 = 4 * txp - 1;
     const size_t plane = (size_t)g.H * g.W;
     const float* xn = x + (size_t)n * g.Cin * plane;
@@ -472,7 +492,7 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // output transform in registers: Y = A^T M A; D fragment: column (tile) = lane & 15, rows (channels) = 4 (lane >> 4) + j
     const int kq = lane >> 4;
     const int oy = 4 * ty;
-    const int txe = tx0 + tl;
+    const int txe = tx_lane;
     const int ox = 4 * txe;
     // BST: the BatchNorm outputs at channel j's output positions, requested one channel ahead from clamped (always
     // valid) addresses; products are masked where they are used
@@ -703,6 +723,19 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     }
 }
 
+}  // namespace
+namespace afd {
+// Tail workgroups per image (0 = the plain border form): the last workgroup column holds exactly one live tile and there
+// are at least two tile rows to pack (AFD_NO_WINO44_TAIL=1 keeps one workgroup per tile row there)
+int wino44_tail_groups(int tilesX, int tilesY) {
+    static const bool off = getenv("AFD_NO_WINO44_TAIL") != nullptr;
+    const int wgX = (tilesX + kTiles - 1) / kTiles;
+    if (off || wgX < 2 || tilesX - kTiles * (wgX - 1) != 1 || tilesY < 2) return 0;
+    return (tilesY + kTiles - 1) / kTiles;
+}
+}  // namespace afd
+namespace {
+
 template <int CG, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false>
 int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * kPos * 64 * KS * sizeof(float);
@@ -727,7 +760,11 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
         const bool skip5 = g.rows - 4 * ty <= 3;
         pos_rows += row0_only ? 6.0 : (skip5 ? 30.0 : (double)kPos);
     }
-    afd::timing_annotate(2.0 * pos_rows * (16.0 * CG) * ((double)kTiles * g.wgX) * (double)g.N * g.Cin, -1.0);
+    g.tail_groups = afd::wino44_tail_groups(g.tilesX, g.tilesY);
+    // (tail workgroups multiply all 36 positions of their 16 tile slots)
+    const double slots = g.tail_groups ? pos_rows * kTiles * (g.wgX - 1) + (double)kPos * kTiles * g.tail_groups
+                                       : pos_rows * kTiles * g.wgX;
+    afd::timing_annotate(2.0 * slots * (16.0 * CG) * (double)g.N * g.Cin, -1.0);
     // interior workgroup columns: every patch column inside the image (6 columns from 4 tx - 1)
     const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
     const int edge = g.wgX >= 2 ? 2 : 1;
@@ -741,7 +778,8 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
         g.part_row0 = (int)(rows * inner);
     }
     g.wxCount = edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * edge)), dim3((CG + HELP) * 64), lds, s, g,
+    const long border_wgs = g.tail_groups ? rows + (long)g.N * g.tail_groups : rows * edge;
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)border_wgs), dim3((CG + HELP) * 64), lds, s, g,
                        x, U, bias, y);
     return afd::check_launch("wino44_conv_kernel");
 }
@@ -789,7 +827,9 @@ size_t wino44_workspace_bytes(int Cin, int Cout) {
 // workgroups (= partial rows of the statistics epilogue) of a launch pair over N images of H x W outputs
 long wino44_stat_rows(int N, int H, int W) {
     const int tilesX = (W + 3) / 4, tilesY = (H + 3) / 4;
-    return (long)N * tilesY * ((tilesX + kTiles - 1) / kTiles);
+    const int wgX = (tilesX + kTiles - 1) / kTiles;
+    const int tg = wino44_tail_groups(tilesX, tilesY);
+    return tg ? (long)N * (tilesY * (wgX - 1) + tg) : (long)N * tilesY * wgX;
 }
 
 int wino44_run(const float* x, const float* w, const float* bias, float* y, int N, int Cin, int H, int W,

@@ -844,6 +844,8 @@ def _issued_winograd(fn):
     (2, 64, 13, 1030, 96, "dgrad"),   # 13 rows: the last tile row has ONE live row
     (2, 128, 5, 300, 96, "dgrad"),    # five rows: a full tile row and one live row
     (1, 96, 10, 517, 128, "fwd"),     # ten rows: two full tile rows and a two-row one
+    (3, 64, 55, 129, 96, "dgrad"),    # block 3 backward-data at level 8 / STFT: 33 tile columns = 2 x 16 + 1 -> tail form
+    (2, 64, 70, 65, 96, "dgrad"),     # 17 tile columns, 18 tile rows: two tail workgroups per image, the second ragged
 ])
 def test_winograd_f44_layers(case):
     """wino44.hip, Winograd F(4x4, 3x3): against float64 at the stated bar for that kernel -- 2e-5 of the largest
@@ -852,9 +854,15 @@ def test_winograd_f44_layers(case):
     n, cg_in, h, w, cg_out, direction = case
     g = torch.Generator().manual_seed(sum(case[:5]))
     # (tile rows x 36 positions; 30 in a last tile row with at most three live output rows)
-    tiles_x = -(-(-(-w // 4)) // 16) * 16
+    tx = -(-w // 4)
+    tiles_x = -(-tx // 16) * 16
     ty = -(-h // 4)
-    pos_tiles = ((ty - 1) * 36 + (30 if h - 4 * (ty - 1) <= 3 else 36)) * tiles_x
+    pos_rows = (ty - 1) * 36 + (30 if h - 4 * (ty - 1) <= 3 else 36)
+    pos_tiles = pos_rows * tiles_x
+    if tx % 16 == 1 and tx > 16 and ty >= 2:
+        # round 6, tail form: the one live tile of the last workgroup column is packed 16 tile rows per workgroup
+        # (all 36 positions there) instead of one workgroup with 15 dead tiles per tile row
+        pos_tiles = pos_rows * (tiles_x - 16) + 36 * 16 * -(-ty // 16)
     if direction == "fwd":
         x = torch.randn(n, cg_in, h, w, generator=g)
         wt = torch.randn(cg_out, cg_in, 3, 3, generator=g) / (cg_in * 9) ** 0.5
