@@ -262,6 +262,15 @@ class Trainer:
         else:
             self.optimizer.step()
         self.step_total += 1
+        if self.step_total == 2:
+            # Everything alive after two steps -- modules, plan, scratch buffers, the library binding: ~270 000 tracked
+            # objects -- is long-lived.  Python's first full collection over them is a 120-140 ms stall that otherwise lands
+            # somewhere in the first hundred steps (tools/step_drift.py: 25 steps' worth at level 8); frozen, the
+            # collector only ever walks what the steps themselves leave behind.
+            import gc
+
+            gc.collect()
+            gc.freeze()
         stats = getattr(self.loss_fun, "last_stats", None)
         self.last_stats = stats
         if self.sync_every_step:

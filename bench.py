@@ -405,7 +405,7 @@ def frontend_lines(device, _native, launches: int = 20):
     return out
 
 
-def secondary_lines(device, _native, rank: int, steps: int = 5, warmup: int = 3, cpu_threads: int = 16):
+def secondary_lines(device, _native, rank: int, steps: int = 20, warmup: int = 5, cpu_threads: int = 16):
     """The other BASELINE configurations measured in this same process after the timed region, so that the driver's
     own run of the default command records them: configs[2] per GPU (packets-sym5 level 14), the level-8 models the
     reference ships (coif4, sym5) and its default wavelet sym8, configs[0] (STFT + DCNN) and configs[4] (STFT + LCNN evaluation, bf16 matrix
