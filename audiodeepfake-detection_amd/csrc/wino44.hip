@@ -186,7 +186,8 @@ __device__ __forceinline__ void at6v(const f32x2 m0, const f32x2 m1, const f32x2
 // transform the 128 patches of an 8-channel chunk; 37 KB of LDS, four workgroups per CU)
 typedef unsigned u32b __attribute__((aligned(1)));
 
-template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false>
+template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false,
+          bool TAIL = false>
 __global__ void __launch_bounds__((CG + HELP) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
@@ -216,23 +217,22 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // (afd::xcd_grouped_id; the tile-row-fastest orders of the measurement above are not in the tree)
     int id = afd::xcd_grouped_id((int)blockIdx.x, (int)gridDim.x, g.xcd_map);
     const int tl = lane & 15;  // tile slot of this lane (transform role and D fragment alike)
-    // TAIL (border launches of images whose last workgroup column holds one live tile): ids past the left-edge
-    // workgroups are tail workgroups -- tile slot tl = tile row 16 tg + tl of tile column tilesX - 1.  There the tile row
-    // is per lane; everything below that is marked "uniform" in terms of ty is uniform in the other workgroups only, and
-    // the two uniform shortcuts of the matrix loop (skip5, row0_only: both skip products with zero operands) are off.
-    const long left_wgs = (long)g.N * g.tilesY;
-    const bool tail = BORDER && g.tail_groups > 0 && id >= left_wgs;  // uniform
+    // TAIL (its own instantiation and launch, for images whose last workgroup column holds ONE live tile): tile slot tl of
+    // workgroup (n, tg) is tile row 16 tg + tl of tile column tilesX - 1.  There the tile row is per lane -- what is marked
+    // "uniform" below in terms of ty is uniform in the other instantiations only (as a per-lane value in every border
+    // workgroup it cost the level-8 step 0.25 ms: every workgroup is a border workgroup there) -- and the two uniform
+    // shortcuts of the matrix loop (skip5, row0_only: both skip products with zero operands) are off.
+    static_assert(!TAIL || BORDER, "tail workgroups take the border form's masks");
+    constexpr bool tail = TAIL;
     int ty, n, tx_lane;
-    if (tail) {
-        const int id2 = id - (int)left_wgs;
-        n = id2 / g.tail_groups;
-        const int tyl = (id2 - n * g.tail_groups) * kTiles + tl;
+    if constexpr (TAIL) {
+        n = id / g.tail_groups;
+        const int tyl = (id - n * g.tail_groups) * kTiles + tl;
         ty = tyl < g.tilesY ? tyl : g.tilesY - 1;
         tx_lane = tyl < g.tilesY ? g.tilesX - 1 : g.tilesX;  // (a slot past the last tile row is a dead tile)
     } else {
-        const int wxc = (BORDER && g.tail_groups > 0) ? 1 : g.wxCount;
-        const int wi = id % wxc;
-        id /= wxc;
+        const int wi = id % g.wxCount;
+        id /= g.wxCount;
         ty = id % g.tilesY;
         n = id / g.tilesY;
         const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
@@ -746,6 +746,9 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr.mark();
     }
@@ -777,10 +780,16 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
                            s, g, x, U, bias, y);
         g.part_row0 = (int)(rows * inner);
     }
-    g.wxCount = edge;
-    const long border_wgs = g.tail_groups ? rows + (long)g.N * g.tail_groups : rows * edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)border_wgs), dim3((CG + HELP) * 64), lds, s, g,
+    // border workgroup columns: the left one and the right one -- or, when the right one holds a single live tile, the left
+    // one here and that tile column in its own launch, 16 tile rows per workgroup
+    g.wxCount = g.tail_groups ? 1 : edge;
+    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * g.wxCount)), dim3((CG + HELP) * 64), lds, s, g,
                        x, U, bias, y);
+    if (g.tail_groups) {
+        g.part_row0 += (int)(rows * g.wxCount);
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, true>), dim3((unsigned)((long)g.N * g.tail_groups)),
+                           dim3((CG + HELP) * 64), lds, s, g, x, U, bias, y);
+    }
     return afd::check_launch("wino44_conv_kernel");
 }
 
