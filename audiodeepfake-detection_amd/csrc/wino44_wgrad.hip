@@ -603,11 +603,20 @@ void plan(GW& g, int N, int Cin, int H, int W, int Cout, int dy_rows, int dy_col
     // of its own; a smaller problem gets as many splits as that allows
     const long max_s = g.units / 16 > 0 ? g.units / 16 : 1;
     long S = 0;
-    for (int rounds = 3; rounds >= 1 && !S; --rounds) {
-        long cand = (long)target_wgs() * rounds / 3 / cgroups;
-        if (cand >= 8) cand = cand / 8 * 8;  // the grid is cgroups * ceil(S / 8) * 8 workgroups: do not pass the aim
-        if (cand >= 1 && cand <= max_s) S = cand;
-    }
+    // ... and, round 6, with at least kMinUnits units of its own where the problem allows it: every workgroup writes a
+    // [36][32][32] slab (147 KB) that the reduce kernel reads again, and on the small level-8 / STFT layers three rounds
+    // of workgroups meant 28 rounds of work per slab (level-8 step: conv_wgrad 1.13 -> 1.05 ms with one round)
+    // (same box, conv_wgrad per step with no floor / 128 / 256 units: level 8 1.141 / 1.050 / 1.054 ms, level 14 coif4 11.77 /
+    // 11.73 / 11.67, sym5 6.70 / 6.59 / -)
+    constexpr long kMinUnits = 256;
+    // pass 0: the most rounds that leave kMinUnits per workgroup; pass 1 (none does): the fewest rounds that fit at all
+    for (int pass = 0; pass < 2 && !S; ++pass)
+        for (int k = 0; k < 3 && !S; ++k) {
+            const int rounds = pass == 0 ? 3 - k : 1 + k;
+            long cand = (long)target_wgs() * rounds / 3 / cgroups;
+            if (cand >= 8) cand = cand / 8 * 8;  // the grid is cgroups * ceil(S / 8) * 8 workgroups: do not pass the aim
+            if (cand >= 1 && cand <= max_s && (pass == 1 || g.units / cand >= kMinUnits)) S = cand;
+        }
     if (!S) S = max_s;
     // never more splits than the workspace bound holds slabs for (wino44_wgrad_workspace_floats: with more channel
     // groups than workgroups aimed at, every candidate above is 0 and max_s could pass it)
