@@ -17,6 +17,7 @@
 #include "../../include/afd_hip.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -68,6 +69,12 @@ struct G4 {
     // 8 193 columns: 128 x 16 + 1) -- instead of one workgroup per tile row with 15 dead tiles, `tail_groups` workgroups per
     // image take that tile column of 16 tile rows each (tile slot = tile row).  0 = off.
     int tail_groups;
+    // round 6: a last tile row with at most TWO live output rows (the second tile row of the 6-row images of blocks 4-6
+    // at level 14) runs F(2x4): the 4-point vertical transform of F(2, 3) with the 6-point horizontal one -- 24 positions
+    // (transform rows 0..3) instead of the 30 the F(4x4) form needs there.  Its filter table [chunk][24][cg][lane][k-step]
+    // follows the F(4x4) one at float offset u_short_off (0 = no such tile row in this launch).
+    int u_short_off;
+    int ty0, tyCount;  // tile rows of this launch (the F(2x4) tile row is launched apart)
     int noflip;  // (development) keep the helper waves of the second workgroup of a CU last: see the kernel's wave roles
     int xcd_map;  // workgroup columns per XCD group (16; 0 / 1 = plain row-major order): see the kernel
     // BatchNorm backward in the epilogue (backward-data launches with the statistics epilogue; round 4): the result g is the
@@ -100,18 +107,33 @@ __device__ __forceinline__ float g_row(int i, float a, float b, float c) {
     }
 }
 
-// U table: [chunk][position][cg][lane][kstep (KS)] = U_p[16 cg + (lane & 15)][4 KS chunk + 4 kstep + (lane >> 4)]
+// F(2, 3) vertical transform of the filter (G2, 4 x 3)
+__device__ __forceinline__ float g2_row(int i, float a, float b, float c) {
+    switch (i) {
+        case 0: return a;
+        case 1: return 0.5f * (a + b + c);
+        case 2: return 0.5f * (a - b + c);
+        default: return c;
+    }
+}
+
+// U table: [chunk][position][cg][lane][kstep (KS)] = U_p[16 cg + (lane & 15)][4 KS chunk + 4 kstep + (lane >> 4)];
+// behind it (short_total > 0) the F(2x4) table of the short last tile row: the same with 24 positions, vertical G2
 __global__ void wino44_weights_kernel(const float* __restrict__ w, float* __restrict__ U, int Cin, int Cout,
-                                      int CG, int nchunks, int dgrad, int KS) {
-    const int total = nchunks * kPos * CG * KS * 64;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+                                      int CG, int nchunks, int dgrad, int KS, int short_total) {
+    const int main_total = nchunks * kPos * CG * KS * 64;
+    const int total = main_total + short_total;
+    for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < total; i0 += gridDim.x * blockDim.x) {
+        const bool shrt = i0 >= main_total;
+        const int i = shrt ? i0 - main_total : i0;
+        const int npos = shrt ? 24 : kPos;
         const int ks = i % KS;
         const int lane = (i / KS) & 63;
         int r = i / (64 * KS);
         const int cg = r % CG;
         r /= CG;
-        const int p = r % kPos;
-        const int chunk = r / kPos;
+        const int p = r % npos;
+        const int chunk = r / npos;
         const int co = 16 * cg + (lane & 15);
         const int ci = 4 * KS * chunk + 4 * ks + (lane >> 4);
         float v = 0.f;
@@ -126,10 +148,11 @@ __global__ void wino44_weights_kernel(const float* __restrict__ w, float* __rest
             const int xi = p / 6, nu = kSlotPos[p - 6 * xi];  // p is a SLOT of the transform row (see bt6h)
             float t[3];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) t[kx] = g_row(xi, g[0][kx], g[1][kx], g[2][kx]);
+            for (int kx = 0; kx < 3; ++kx)
+                t[kx] = shrt ? g2_row(xi, g[0][kx], g[1][kx], g[2][kx]) : g_row(xi, g[0][kx], g[1][kx], g[2][kx]);
             v = g_row(nu, t[0], t[1], t[2]);
         }
-        U[i] = v;
+        U[i0] = v;
     }
 }
 
@@ -187,7 +210,7 @@ __device__ __forceinline__ void at6v(const f32x2 m0, const f32x2 m1, const f32x2
 typedef unsigned u32b __attribute__((aligned(1)));
 
 template <int CG, bool BORDER, bool BST, bool POOL = false, int HELP = 0, bool FST = false, int KS = 4, bool PIN = false,
-          bool TAIL = false>
+          bool TAIL = false, bool SHORT2 = false>
 __global__ void __launch_bounds__((CG + HELP) * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restrict__ U,
                    const float* __restrict__ bias, float* __restrict__ y) {
@@ -233,18 +256,23 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     } else {
         const int wi = id % g.wxCount;
         id /= g.wxCount;
-        ty = id % g.tilesY;
-        n = id / g.tilesY;
+        ty = g.ty0 + id % g.tyCount;  // the launch covers tile rows ty0 .. ty0 + tyCount - 1
+        n = id / g.tyCount;
         const int wx = BORDER ? (wi == 0 ? 0 : g.wgX - 1) : wi + 1;
         tx_lane = wx * kTiles + tl;
     }
-    const bool skip5 = !tail && g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
+    const bool skip5 = !tail && !SHORT2 && g.rows - 4 * ty <= 3;  // uniform: see the matrix loop
     // PIN: the dense gradient has 2 Hp live rows; a tile row whose patches start on the last of them (4 ty - 1 =
     // 2 Hp - 1: the fourth tile row of block 3's 13-row backward-data at level 14, one output row) has a single
     // non-zero patch row, row 0, and column 0 of B^T is (4, 0, 0, 0, 0, 0): only transform row 0 -- positions 0..5 --
     // is non-zero.  Those workgroups run 6 of the 36 products per chunk (they ran 30) and fetch only those operands:
     // block 3's backward-data 5.50 -> 5.23 ms (a shorter transform for them on top measured level, with spills).
-    const bool row0_only = !tail && PIN && 4 * ty - 1 == 2 * g.Hp - 1;  // uniform
+    const bool row0_only = !tail && !SHORT2 && PIN && 4 * ty - 1 == 2 * g.Hp - 1;  // uniform
+    // F(2x4) tile row (G4::u_short_off): a last tile row with at most two live output rows -- its own instantiation and
+    // launches (the kernel sits at its 256-register budget: with both forms in one instantiation every instance spilled
+    // 600-970 bytes per thread)
+    static_assert(!SHORT2 || !TAIL, "the tail workgroups multiply F(4x4) in every tile slot");
+    constexpr bool short2 = SHORT2;
 
     // transform role (threads 0..255): wave w holds the channels 4 ks + w of the chunk, lane = (ks, tile): its 36
     // values go to V[position][(w * 16 + tile) * 4 + ks] -- a wave's 64 lanes write 64 consecutive floats
@@ -389,6 +417,29 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         }
         }
         f32x2 t[6][3];  // t = B^T d, column pairs
+        float* vb = V + buf * VB + (kq_t * 16 + tl) * KS + ksx;
+        if constexpr (SHORT2) {  // F(2, 3) down the columns (patch rows 0..3), transform rows 0..3 = positions 0..23
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x2 d0 = {d[0][2 * c], d[0][2 * c + 1]}, d1 = {d[1][2 * c], d[1][2 * c + 1]};
+                const f32x2 d2 = {d[2][2 * c], d[2][2 * c + 1]}, d3 = {d[3][2 * c], d[3][2 * c + 1]};
+                t[0][c] = d0 - d2;
+                t[1][c] = d1 + d2;
+                t[2][c] = d2 - d1;
+                t[3][c] = d1 - d3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f32x2 o[3];
+                bt6h(t[r][0], t[r][1], t[r][2], o);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    vb[(r * 6 + 2 * q) * PS] = o[q].x;
+                    vb[(r * 6 + 2 * q + 1) * PS] = o[q].y;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             f32x2 o[6];
@@ -398,7 +449,6 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
 #pragma unroll
             for (int r = 0; r < 6; ++r) t[r][c] = o[r];
         }
-        float* vb = V + buf * VB + (kq_t * 16 + tl) * KS + ksx;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             f32x2 o[3];
@@ -420,10 +470,13 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
     // the scalar offset -- the 36 offsets of a chunk cost scalar adds.  As 64-bit lane addresses (global_load) they
     // cost two vector instructions per load, 72 per chunk INSIDE the matrix loop, where vector and f32 matrix
     // instructions share the issue.  Reads past the table (there are none) would return zero.
-    const unsigned ubytes = (unsigned)g.nchunks * kPos * CG * PS * 4u;
+    const unsigned ubytes = (unsigned)g.nchunks * (kPos + (g.u_short_off ? 24 : 0)) * CG * PS * 4u;
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(U), 0, (int)ubytes, 0x00020000);
     const unsigned ulane = (unsigned)lane * KS * 4u;
-    const unsigned Uw = (unsigned)wave * PS * 4u;  // scalar byte offset of this wave's fragments in a position block
+    // scalar byte offset of this wave's fragments in a position block (of the F(2x4) table in a short tile row) and the
+    // positions per chunk of that table
+    const unsigned Uw = (unsigned)wave * PS * 4u + (short2 ? (unsigned)g.u_short_off * 4u : 0u);
+    const unsigned upos = short2 ? 24u : (unsigned)kPos;
     if (xf) {
         load_patch(0);
         store_v(0);
@@ -451,28 +504,33 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         // queue and every fragment waits for the patch load in front of it; in one piece at position group 0 / 2 / 10
         // instead of here: 19.89 / 20.37 / 20.73 against 19.84-19.87 ms)
         if (xf && more) load_patch(c + 1);
-        const unsigned uc = Uw + (unsigned)c * kPos * CG * PS * 4u;
-        const unsigned un = Uw + (unsigned)(more ? c + 1 : c) * kPos * CG * PS * 4u;  // (the last chunk re-reads its own)
+        const unsigned uc = Uw + (unsigned)c * upos * CG * PS * 4u;
+        const unsigned un = Uw + (unsigned)(more ? c + 1 : c) * upos * CG * PS * 4u;  // (the last chunk re-reads its own)
         const float* vb = V + (c & 1) * VB + lane * KS;
         auto load_b = [&](int grp, int slot) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) b[slot][q] = *reinterpret_cast<const vk*>(vb + (3 * grp + q) * PS);
         };
-        if (HELP == 0 || mm) {
+        // NR position groups of 3: 12 for F(4x4), 8 for the F(2x4) tile row (its own copy of the loop: the counts are
+        // compile-time constants in both).  The filter fragments rotate through three register slots (group g in slot
+        // g % 3, requested two groups ahead, the next chunk's first two groups behind the last ones): the walk has NG
+        // steps, a multiple of 3 -- for F(2x4) a ninth, empty step -- so that group 0 of the next chunk lands in slot 0.
+        auto matrix_loop = [&](auto nr_tag) {
+            constexpr int NR = decltype(nr_tag)::value, NG = (NR + 2) / 3 * 3;
             load_b(0, 0);
 #pragma unroll
-            for (int grp = 0; grp < 12; ++grp) {
+            for (int grp = 0; grp < NG; ++grp) {
                 // (row0_only: groups 0 and 1 are all that is multiplied -- the other groups' operands are not fetched)
-                if (grp + 2 < 12) {
+                if (grp + 2 < NR) {
                     if (!row0_only) load_u(uc, grp + 2, (grp + 2) % 3);
-                } else {
-                    load_u(un, grp + 2 - 12, (grp + 2) % 3);
+                } else if (grp + 2 >= NG) {
+                    load_u(un, grp + 2 - NG, (grp + 2) % 3);
                 }
-                if (grp + 1 < 12 && (grp + 1 < 2 || !row0_only)) load_b(grp + 1, (grp + 1) & 1);
+                if (grp + 1 < NR && (grp + 1 < 2 || !row0_only)) load_b(grp + 1, (grp + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // positions 30..35 (transform row 5) only enter output row 3 of the tile (A^T row 3): a tile row with
                 // at most three live output rows -- the last one of the 13- and 6-row level-14 images -- skips them
-                if ((grp < 2 || !row0_only) && (grp < 10 || !skip5)) {
+                if (grp < NR && (grp < 2 || !row0_only) && (grp < 10 || !skip5)) {
 #pragma unroll
                     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -483,7 +541,8 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        if (HELP == 0 || mm) matrix_loop(std::integral_constant<int, SHORT2 ? 8 : 12>{});
         if (xf && more) store_v((c + 1) & 1);
         __syncthreads();
     }
@@ -539,7 +598,13 @@ wino44_conv_kernel(const G4 g, const float* __restrict__ x, const float* __restr
         for (int q = 0; q < 6; ++q) {
             f32x2 o[4];
             auto A = [&](int p) { return f32x2{acc[p][2 * jp], acc[p][2 * jp + 1]}; };
-            at6v(A(q), A(6 + q), A(12 + q), A(18 + q), A(24 + q), A(30 + q), o);
+            if constexpr (SHORT2) {  // A2^T (2 x 4) down the column; output rows 2, 3 of the tile do not exist
+                o[0] = A(q) + A(6 + q) + A(12 + q);
+                o[1] = A(6 + q) - A(12 + q) - A(18 + q);
+                o[2] = o[3] = f32x2{0.f, 0.f};
+            } else {
+                at6v(A(q), A(6 + q), A(12 + q), A(18 + q), A(24 + q), A(30 + q), o);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) sp[r][q] = o[r];
         }
@@ -749,46 +814,78 @@ int launch44(G4 g, const float* x, const float* U, const float* bias, float* y, 
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "winograd 4x4 conv: %s", hipGetErrorString(e));
         attr.mark();
     }
     g.wgX = (g.tilesX + kTiles - 1) / kTiles;
-    const long rows = (long)g.N * g.tilesY;
-    // 36 GEMMs [16 CG x Cin] x [Cin x 16 tiles] per workgroup, every tile computed in full
-    // (30 of them in a tile row with at most three live output rows,
-    // and 6 in the tile row whose patches have one non-zero row: the kernel's own conditions, row by row)
-    double pos_rows = 0.0;
-    for (int ty = 0; ty < g.tilesY; ++ty) {
-        const bool row0_only = PIN && 4 * ty - 1 == 2 * g.Hp - 1;
-        const bool skip5 = g.rows - 4 * ty <= 3;
-        pos_rows += row0_only ? 6.0 : (skip5 ? 30.0 : (double)kPos);
-    }
     g.tail_groups = afd::wino44_tail_groups(g.tilesX, g.tilesY);
-    // (tail workgroups multiply all 36 positions of their 16 tile slots)
-    const double slots = g.tail_groups ? pos_rows * kTiles * (g.wgX - 1) + (double)kPos * kTiles * g.tail_groups
-                                       : pos_rows * kTiles * g.wgX;
-    afd::timing_annotate(2.0 * slots * (16.0 * CG) * (double)g.N * g.Cin, -1.0);
-    // interior workgroup columns: every patch column inside the image (6 columns from 4 tx - 1)
+    // the last tile row as F(2x4) (wino44_run decided: u_short_off): never the row0_only tile row of a pooled-input launch
+    const bool last_row0 = PIN && 4 * (g.tilesY - 1) - 1 == 2 * g.Hp - 1;
+    if (last_row0) g.u_short_off = 0;
+    const bool has_short = g.u_short_off != 0;
+    const int ty_main = has_short ? g.tilesY - 1 : g.tilesY;
     const int inner = g.wgX > 2 ? g.wgX - 2 : 0;
     const int edge = g.wgX >= 2 ? 2 : 1;
-    if (rows * (inner > edge ? inner : edge) > 0x7fffffffL)
-        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: grid too large");
-    g.part_row0 = 0;
-    if (inner > 0) {
-        g.wxCount = inner;
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * inner)), dim3((CG + HELP) * 64), lds,
-                           s, g, x, U, bias, y);
-        g.part_row0 = (int)(rows * inner);
+    const int cols_main = g.tail_groups ? g.wgX - 1 : g.wgX;  // workgroup columns outside the tail launch
+    // issued flops: 36 GEMMs [16 CG x Cin] x [Cin x 16 tiles] per workgroup (tail workgroups: all 36 in every slot)
+    {
+        double pos_main = 0.0;
+        for (int ty = 0; ty < ty_main; ++ty) {
+            const bool row0_only = PIN && 4 * ty - 1 == 2 * g.Hp - 1;
+            const bool skip5 = g.rows - 4 * ty <= 3;
+            pos_main += row0_only ? 6.0 : (skip5 ? 30.0 : (double)kPos);
+        }
+        if (has_short) pos_main += 24.0;
+        const double slots = pos_main * kTiles * cols_main + (double)kPos * kTiles * g.tail_groups;
+        afd::timing_annotate(2.0 * slots * (16.0 * CG) * (double)g.N * g.Cin, -1.0);
     }
-    // border workgroup columns: the left one and the right one -- or, when the right one holds a single live tile, the left
+    if ((long)g.N * g.tilesY * (inner > edge ? inner : edge) > 0x7fffffffL)
+        return afd::fail(AFD_ERR_UNSUPPORTED, "winograd 4x4 conv: grid too large");
+    const dim3 block((CG + HELP) * 64);
+    g.part_row0 = 0;
+    // tile rows 0 .. ty_main - 1: interior workgroup columns (every patch column inside the image: 6 columns from 4 tx - 1),
+    // then the border ones -- the left one and the right one, or, when the right one holds a single live tile, the left
     // one here and that tile column in its own launch, 16 tile rows per workgroup
-    g.wxCount = g.tail_groups ? 1 : edge;
-    hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * g.wxCount)), dim3((CG + HELP) * 64), lds, s, g,
-                       x, U, bias, y);
-    if (g.tail_groups) {
+    if (ty_main > 0) {
+        const long rows = (long)g.N * ty_main;
+        g.ty0 = 0;
+        g.tyCount = ty_main;
+        if (inner > 0) {
+            g.wxCount = inner;
+            hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * inner)), block, lds, s, g, x, U,
+                               bias, y);
+            g.part_row0 += (int)(rows * inner);
+        }
+        g.wxCount = g.tail_groups ? 1 : edge;
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN>), dim3((unsigned)(rows * g.wxCount)), block, lds, s, g, x, U,
+                           bias, y);
         g.part_row0 += (int)(rows * g.wxCount);
-        hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, true>), dim3((unsigned)((long)g.N * g.tail_groups)),
-                           dim3((CG + HELP) * 64), lds, s, g, x, U, bias, y);
+    }
+    if (g.tail_groups) {  // (all tile rows, the short one included: F(4x4) there)
+        g.ty0 = 0;
+        g.tyCount = g.tilesY;
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, true>), dim3((unsigned)((long)g.N * g.tail_groups)), block, lds,
+                           s, g, x, U, bias, y);
+        g.part_row0 += (int)((long)g.N * g.tail_groups);
+    }
+    if (has_short) {  // the last tile row, F(2x4)
+        g.ty0 = g.tilesY - 1;
+        g.tyCount = 1;
+        if (inner > 0) {
+            g.wxCount = inner;
+            hipLaunchKernelGGL((wino44_conv_kernel<CG, false, BST, POOL, HELP, FST, KS, PIN, false, true>), dim3((unsigned)((long)g.N * inner)), block, lds,
+                               s, g, x, U, bias, y);
+            g.part_row0 += (int)((long)g.N * inner);
+        }
+        g.wxCount = g.tail_groups ? 1 : edge;
+        hipLaunchKernelGGL((wino44_conv_kernel<CG, true, BST, POOL, HELP, FST, KS, PIN, false, true>), dim3((unsigned)((long)g.N * g.wxCount)), block, lds,
+                           s, g, x, U, bias, y);
     }
     return afd::check_launch("wino44_conv_kernel");
 }
@@ -830,7 +927,7 @@ bool wino44_pool_applicable(int Cin, int H, int W, int Cout) {
 
 size_t wino44_workspace_bytes(int Cin, int Cout) {
     const size_t cg = (size_t)(Cout + 15) / 16;
-    return (size_t)(Cin / 4) * kPos * cg * 64 * sizeof(float);  // (either chunk depth)
+    return (size_t)(Cin / 4) * (kPos + 24) * cg * 64 * sizeof(float);  // (either chunk depth; F(4x4) table + F(2x4) table)
 }
 
 // workgroups (= partial rows of the statistics epilogue) of a launch pair over N images of H x W outputs
@@ -881,10 +978,16 @@ int wino44_run(const float* x, const float* w, const float* bias, float* y, int 
     const int CG = (Cout + 15) / 16;
     if (!x || !w || (!y && !u)) return afd::fail(AFD_ERR_ARG, "winograd 4x4 conv: null pointer");
     float* U = static_cast<float*>(ws);
-    const int total = g.nchunks * kPos * CG * KS * 64;
+    const int main_total = g.nchunks * kPos * CG * KS * 64;
+    // a last tile row with at most two live output rows runs F(2x4) from a table of its own (AFD_NO_WINO44_SHORT=1: F(4x4))
+    static const bool no_short = getenv("AFD_NO_WINO44_SHORT") != nullptr;
+    const bool has_short = !no_short && g.tilesY >= 1 && g.rows - 4 * (g.tilesY - 1) <= 2;
+    const int short_total = has_short ? g.nchunks * 24 * CG * KS * 64 : 0;
+    g.u_short_off = has_short ? main_total : 0;
+    const int total = main_total + short_total;
     afd::ScopedTiming timing(AFD_K_CONV_WINOGRAD, 2.0 * N * Cout * (double)g.rows * g.cols * Cin * 9, s);
     hipLaunchKernelGGL(wino44_weights_kernel, dim3((total + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, CG,
-                       g.nchunks, dgrad, KS);
+                       g.nchunks, dgrad, KS, short_total);
     int rc = afd::check_launch("wino44_weights_kernel");
     if (rc) return rc;
     {   // every tensor the launch touches, once: the pooled forms move 4 + 1 bytes per 2x2 window, the epilogues that

@@ -631,7 +631,7 @@ def test_conv_pool_backward_from_the_pooled_gradient(shape, cout):
     assert torch.equal(dx0, dx1)
     assert torch.allclose(ds0, ds1, rtol=3e-4, atol=1e-5)  # float atomics over the workgroups: the order differs run to run
     assert (sums0[:cin] - sums1[:cin]).abs().max().item() <= 1e-9 * max(1.0, sums0[:cin].abs().max().item())
-    _close(dw1, dw0.cpu().double(), 2e-6, "pooled wgrad")
+    _close(dw1, dw0.cpu().double(), 3e-6, "pooled wgrad")  # (two float32 summation orders over the same products)
     _close(db1, db0.cpu().double(), 2e-6, "pooled dbias")
 
     # autograd: BatchNorm -> conv + PReLU + pool -> BatchNorm, with and without the pooled backward
@@ -857,7 +857,9 @@ def test_winograd_f44_layers(case):
     tx = -(-w // 4)
     tiles_x = -(-tx // 16) * 16
     ty = -(-h // 4)
-    pos_rows = (ty - 1) * 36 + (30 if h - 4 * (ty - 1) <= 3 else 36)
+    # (the last tile row: 24 positions -- F(2x4), round 6 -- with at most two live output rows, 30 with three)
+    last = h - 4 * (ty - 1)
+    pos_rows = (ty - 1) * 36 + (24 if last <= 2 else (30 if last <= 3 else 36))
     pos_tiles = pos_rows * tiles_x
     if tx % 16 == 1 and tx > 16 and ty >= 2:
         # round 6, tail form: the one live tile of the last workgroup column is packed 16 tile rows per workgroup
