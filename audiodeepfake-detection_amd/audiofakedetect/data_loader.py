@@ -385,6 +385,7 @@ class NativeFrameLoader:
     def _prefetched(self, start: int, depth: int):
         import queue
         import threading
+        import time
         import warnings
 
         if self._side is None:
@@ -403,6 +404,9 @@ class NativeFrameLoader:
                     continue
             return False
 
+        # (tools/e2e_probe.py, level-14 step, same box: resident batch 43.96 ms, prefetching 44.64, with this pause 44.44-44.49)
+        delay = min(0.010, 0.2e-3 * self.consumer_ms) if self.consumer_ms else 0.0
+
         def worker() -> None:
             try:
                 torch.cuda.set_device(self.device)
@@ -412,6 +416,10 @@ class NativeFrameLoader:
                         ev.record(side)
                         if not put((item, ev)):
                             return
+                        # the consumer has just taken a batch and is issuing its step's launches: stay off the
+                        # interpreter lock for the first fifth of the step (at most 10 ms) before preparing the next one
+                        if delay > 0.0:
+                            time.sleep(delay)
                 put(None)
             except BaseException as e:  # handed to the consumer
                 put(e)
