@@ -43,6 +43,25 @@ def plan_switches() -> tuple:
     return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("AFD_")))
 
 
+_zero_chunks: dict = {}
+
+
+def _zeros(n: int, dtype, device) -> torch.Tensor:
+    """`n` zeros for an accumulator a kernel adds into (slope gradients, per-channel sums): a never-used slice of a chunk
+    that ONE memset zeroed, instead of a `torch.zeros` -- a memset launch -- per accumulator (a level-8 step had seven of
+    them).  A slice is handed out once and never again, so it is zero whatever happened to its neighbours; chunks are
+    replaced when used up and stay alive as long as something still refers to a slice."""
+    device = torch.device(device)
+    key = (device.type, device.index, dtype)
+    chunk = _zero_chunks.get(key)
+    if chunk is None or chunk[1] + n > chunk[0].numel():
+        chunk = [torch.zeros(max(4096, 4 * n), dtype=dtype, device=device), 0]
+        _zero_chunks[key] = chunk
+    out = chunk[0][chunk[1]:chunk[1] + n]
+    chunk[1] += (n + 3) // 4 * 4  # (16-byte steps for the float slots, 32-byte for doubles)
+    return out
+
+
 def _ws(nbytes: int, device, lane: str = "main") -> torch.Tensor:
     """Grow-only scratch buffer per device and stream lane (conv weight slabs / wgrad partial slabs)."""
     key = (device.type, device.index, lane)
@@ -340,7 +359,7 @@ def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, f
         _native.ptr(dy), _native.ptr(codes), _native.ptr(w), _native.ptr(z), _native.ptr(tab), _native.ptr(slope),
         _native.ptr(bn_codes), _native.ptr(dz), _native.ptr(out), n, cin, h, wd, cout, _native.ptr(ws), ws.numel(),
         _native.ptr(sws), sws.numel(), _native.stream_ptr()), "afd_conv3x3_backward_data_bnapply")
-    dslope = out[cin:].sum().float().reshape(1) if slope is not None else None
+    dslope = out[cin:].sum(dtype=torch.float32).reshape(1) if slope is not None else None
     return dz, out[:cin], dslope
 
 
@@ -436,7 +455,7 @@ def _pool_backward(u, slope, idx, du, zshape, out_link):
     n, c, h, w = zshape
     du = _f32c(du)
     dz = torch.empty((n, c, h, w), dtype=torch.float32, device=u.device)
-    dslope = torch.zeros(1, dtype=torch.float32, device=u.device) if slope is not None else None
+    dslope = _zeros(1, torch.float32, u.device) if slope is not None else None
     coef = out_link.pop("affine_coef", None) if out_link is not None else None
     _native.check(lib.afd_prelu_pool_backward_affine(
         _native.ptr(u), _native.ptr(slope), _native.ptr(idx), _native.ptr(du), _native.ptr(coef), c,
@@ -511,7 +530,7 @@ class _Conv1PReLUPool(torch.autograd.Function):
         du = _f32c(du)
         dw = torch.empty(wshape, dtype=torch.float32, device=x.device)
         db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
-        dslope = torch.zeros(1, dtype=torch.float32, device=x.device)
+        dslope = _zeros(1, torch.float32, x.device)
         ws = _ws(lib.afd_conv1_pool_workspace_bytes(n, h, wd, cout, pad), x.device)
         # the consumer of u (`_BNConv1x1PReLUBN`) may have left the affine part of its input gradient,
         # alpha[c] * u + beta[c], to this kernel, which reads du and u anyway
@@ -617,7 +636,7 @@ class _Conv3x3PReLUPool(torch.autograd.Function):
                 gg, dslope = du, done
             else:
                 gg = _empty_with_slack(u.shape, torch.float32, u.device)
-                dslope = torch.zeros(1, dtype=torch.float32, device=u.device)
+                dslope = _zeros(1, torch.float32, u.device)
             coef = ctx.out_link.pop("affine_coef", None) if ctx.out_link is not None else None
             if done is None:
                 _native.check(lib.afd_prelu_pool_backward_compact(
@@ -950,8 +969,8 @@ class _BatchNorm(torch.autograd.Function):
                 "afd_bn_backward_stats")
         dgamma = dbeta = None
         if has_gamma:
-            dbeta = sums[:c].float()
-            dgamma = sums[c:].float()
+            both = sums.float()  # (one cast launch for both halves)
+            dbeta, dgamma = both[:c], both[c:]
         if _dist_on(sync):
             sums = sums.clone()
             all_reduce_sum(sums)
@@ -971,9 +990,9 @@ class _BatchNorm(torch.autograd.Function):
             ctx.prod_link["affine_coef"] = coef
             return dy, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         dx = torch.empty_like(x)
-        dslope = torch.zeros(1, dtype=torch.float32, device=x.device) if has_slope else None
+        dslope = _zeros(1, torch.float32, x.device) if has_slope else None
         # the per-channel sums of dx for the convolution that produced x (its bias gradient), from the same pass
-        dxs = torch.zeros(c, dtype=torch.float64, device=x.device) if ctx.sum_link is not None else None
+        dxs = _zeros(c, torch.float64, x.device) if ctx.sum_link is not None else None
         _native.check(lib.afd_bn_backward_apply_sums(
             _native.ptr(x), _native.ptr(slope), _native.ptr(dy), _native.ptr(mean),
             _native.ptr(invstd), _native.ptr(gamma), _native.ptr(mdy), _native.ptr(mdyx),
@@ -1247,7 +1266,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         t = torch.empty_like(u)
         gw = torch.empty((cout, c), dtype=torch.float32, device=dev)
         db = torch.empty(cout, dtype=torch.float32, device=dev)
-        dslope = torch.zeros(1, dtype=torch.float32, device=dev)
+        dslope = _zeros(1, torch.float32, dev)
         ws = _ws(lib.afd_conv1x1_prelu_bn_backward_workspace_bytes(c, cout), dev)
         _native.check(lib.afd_conv1x1_prelu_bn_backward(
             _native.ptr(g), _native.ptr(z), _native.ptr(u), _native.ptr(wf), _native.ptr(coef),
@@ -1363,7 +1382,7 @@ class _PReLUDropout(torch.autograd.Function):
         p, seed = ctx.cfg
         dy = _f32c(dy)
         dz = torch.empty_like(z)
-        dslope = torch.zeros(1, dtype=torch.float32, device=z.device)
+        dslope = _zeros(1, torch.float32, z.device)
         _native.check(_lib().afd_prelu_dropout_backward(
             _native.ptr(z), _native.ptr(slope), _native.ptr(dy), _native.ptr(dz), _native.ptr(dslope),
             z.numel(), p, seed, _native.stream_ptr()), "afd_prelu_dropout_backward")
