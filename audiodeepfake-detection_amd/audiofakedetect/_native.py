@@ -110,8 +110,8 @@ _SIGNATURES = {
     "afd_bn_backward_stats": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_p]),
     "afd_bn_backward_apply": (c_i, [c_p] * 10 + [c_i, c_i, c_i, c_p]),
     "afd_bn_backward_apply_sums": (c_i, [c_p] * 11 + [c_i, c_i, c_i, c_p]),
-    "afd_bn_finalize": (c_i, [c_p, c_i, ctypes.c_double, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "afd_bn_backward_means": (c_i, [c_p, c_i, ctypes.c_double, c_p, c_p, c_p, c_p]),
+    "afd_bn_finalize": (c_i, [c_p, c_i, ctypes.c_double, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "afd_bn_backward_means": (c_i, [c_p, c_i, ctypes.c_double, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "afd_dropout_permute": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_ul, c_i, c_p]),
     "afd_linear_mean_forward": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "afd_linear_mean_backward": (c_i, [c_p] * 6 + [c_i, c_i, c_i, c_i, c_p]),

@@ -348,10 +348,11 @@ def _dgrad_with_bn_backward(lib, z, w, dw, dy, codes, dy_sums, db, geom, crop, f
     mdy = torch.empty(cin, dtype=torch.float32, device=dev)
     mdyx = torch.empty(cin, dtype=torch.float32, device=dev)
     on_dev = torch.is_tensor(count)
+    tab = torch.empty((cin, 4), dtype=torch.float32, device=dev)  # (mean, invstd, mdy, mdyx): written by the same launch
     _native.check(lib.afd_bn_backward_means(
         _native.ptr(sums), cin, -1.0 if on_dev else float(count), _native.ptr(count) if on_dev else None,
-        _native.ptr(mdy), _native.ptr(mdyx), _native.stream_ptr()), "afd_bn_backward_means")
-    tab = torch.stack((mean, invstd, mdy, mdyx), dim=1).contiguous()
+        _native.ptr(mdy), _native.ptr(mdyx), _native.ptr(mean), _native.ptr(invstd), _native.ptr(tab),
+        _native.stream_ptr()), "afd_bn_backward_means")
     dz = _empty_with_slack(z.shape, torch.float32, dev)  # (a pooled gradient is read in whole vectors past its end)
     out = torch.empty(2 * cin, dtype=torch.float64, device=dev)
     sws = _ws(lib.afd_conv3x3_backward_data_bnstats_workspace_bytes(n, cin, h, wd), dev, "bnstats")
@@ -849,6 +850,7 @@ class _BatchNorm(torch.autograd.Function):
         hw = x.numel() // (n * c)
         dev = x.device
         count = float(n * hw)
+        fold_tab = None
         if training:
             if pre_sums is not None:
                 sums = pre_sums  # from the producer's epilogue (afd_conv3x3_forward_stats)
@@ -865,6 +867,9 @@ class _BatchNorm(torch.autograd.Function):
                 mean = torch.empty(c, dtype=torch.float32, device=dev)
                 invstd = torch.empty(c, dtype=torch.float32, device=dev)
                 cnt = torch.empty(1, dtype=torch.float64, device=dev) if dist_on else None
+                # (a deferred BatchNorm's (mean, invstd) pairs come out of the same launch: no torch.stack)
+                fold_tab = (torch.empty((c, 2), dtype=torch.float32, device=dev)
+                            if defer and gamma is None and link is not None else None)
                 mom = momentum
                 if mom is None:  # cumulative moving average (nn.BatchNorm2d(momentum=None))
                     mom = 1.0 / float(int(nbt) + 1) if nbt is not None else 0.0
@@ -872,7 +877,7 @@ class _BatchNorm(torch.autograd.Function):
                     _native.check(lib.afd_bn_finalize(
                         _native.ptr(sums), c, -1.0 if dist_on else count, float(eps), float(mom),
                         _native.ptr(mean), _native.ptr(invstd), _native.ptr(running_mean),
-                        _native.ptr(running_var), _native.ptr(nbt), _native.ptr(cnt),
+                        _native.ptr(running_var), _native.ptr(nbt), _native.ptr(cnt), _native.ptr(fold_tab),
                         _native.stream_ptr()), "afd_bn_finalize")
                 ctx.count = cnt if dist_on else count
             else:
@@ -886,7 +891,7 @@ class _BatchNorm(torch.autograd.Function):
             # the convolution that consumes the result normalises x while it loads (`_take_fold`): no pass here, the
             # result is never stored.  The backward below is unchanged: it takes the gradient of the normalised
             # tensor from that convolution's backward-data launch, and never read the normalised tensor itself.
-            link["fold"] = (_pack_fold(mean, invstd), slope)
+            link["fold"] = (fold_tab if fold_tab is not None else _pack_fold(mean, invstd), slope)
             link["bn"] = True
             if prod_link is None:
                 # the consumer's backward-data launch may apply this layer's (and the PReLU's) backward itself
@@ -979,7 +984,7 @@ class _BatchNorm(torch.autograd.Function):
         on_dev = torch.is_tensor(ctx.count)
         _native.check(lib.afd_bn_backward_means(
             _native.ptr(sums), c, -1.0 if on_dev else float(ctx.count),
-            _native.ptr(ctx.count) if on_dev else None, _native.ptr(mdy), _native.ptr(mdyx),
+            _native.ptr(ctx.count) if on_dev else None, _native.ptr(mdy), _native.ptr(mdyx), None, None, None,
             _native.stream_ptr()), "afd_bn_backward_means")
         if ctx.prod_link is not None and not has_slope and not has_gamma:
             # the producer of x (a PReLU + max-pool backward) applies dx = A dy + B x + K where it reads dy and x
@@ -1076,7 +1081,7 @@ class _BNConv1x1(torch.autograd.Function):
                 _native.check(lib.afd_bn_finalize(
                     _native.ptr(sums), c, -1.0 if dist_on else count, float(eps), float(mom),
                     _native.ptr(mean), _native.ptr(invstd), _native.ptr(running_mean),
-                    _native.ptr(running_var), _native.ptr(nbt), _native.ptr(cnt),
+                    _native.ptr(running_var), _native.ptr(nbt), _native.ptr(cnt), None,
                     _native.stream_ptr()), "afd_bn_finalize")
             ctx.count = cnt if dist_on else count
         else:
@@ -1148,9 +1153,10 @@ def bn_conv1x1_applicable(bn: torch.nn.Module, conv: torch.nn.Module) -> bool:
             and conv.in_channels <= 128 and conv.out_channels <= 128)
 
 
-def _bn_finalize_sums(sums, c, count, bn, sync):
+def _bn_finalize_sums(sums, c, count, bn, sync, fold_tab=None):
     """(mean, invstd, count) from the packed [sum | sum of squares | count slot] double vector of a training
-    batch (all-reduced first when a process group is up); updates bn's running buffers."""
+    batch (all-reduced first when a process group is up); updates bn's running buffers.  `fold_tab`: a [c][2] tensor
+    that takes the (mean, invstd) pairs in the same launch."""
     lib = _lib()
     dev = sums.device
     dist_on = _dist_on(sync)
@@ -1168,7 +1174,7 @@ def _bn_finalize_sums(sums, c, count, bn, sync):
         _native.check(lib.afd_bn_finalize(
             _native.ptr(sums), c, -1.0 if dist_on else count, float(bn.eps), float(mom),
             _native.ptr(mean), _native.ptr(invstd), _native.ptr(bn.running_mean),
-            _native.ptr(bn.running_var), _native.ptr(nbt), _native.ptr(cnt),
+            _native.ptr(bn.running_var), _native.ptr(nbt), _native.ptr(cnt), _native.ptr(fold_tab),
             _native.stream_ptr()), "afd_bn_finalize")
     return mean, invstd, (cnt if dist_on else count)
 
@@ -1216,10 +1222,11 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
             _native.ptr(u), _native.ptr(wf), _native.ptr(bf), _native.ptr(slope), _native.ptr(z),
             _native.ptr(sums2), n, c, cout, hw, _native.ptr(ws), ws.numel(), _native.stream_ptr()),
             "afd_conv1x1_forward_stats")
-        mean2, invstd2, cnt2 = _bn_finalize_sums(sums2, cout, float(n * hw), bn2, sync)
+        fold2 = torch.empty((cout, 2), dtype=torch.float32, device=dev) if defer and out_link is not None else None
+        mean2, invstd2, cnt2 = _bn_finalize_sums(sums2, cout, float(n * hw), bn2, sync, fold2)
         if defer and out_link is not None:
             # the 3x3 convolution behind the second BatchNorm applies PReLU and the normalisation while it loads z
-            out_link["fold"] = (_pack_fold(mean2, invstd2), slope)
+            out_link["fold"] = (fold2, slope)
             y = z
         else:
             y = torch.empty_like(z)
@@ -1258,7 +1265,7 @@ class _BNConv1x1PReLUBN(torch.autograd.Function):
         on_dev = torch.is_tensor(cnt2)
         _native.check(lib.afd_bn_backward_means(
             _native.ptr(sums), cout, -1.0 if on_dev else float(cnt2), _native.ptr(cnt2) if on_dev else None,
-            _native.ptr(mdy), _native.ptr(mdyx), _native.stream_ptr()), "afd_bn_backward_means")
+            _native.ptr(mdy), _native.ptr(mdyx), None, None, None, _native.stream_ptr()), "afd_bn_backward_means")
         coef = torch.empty((cout, 4), dtype=torch.float32, device=dev)
         _native.check(lib.afd_bn_backward_coef(_native.ptr(mean2), _native.ptr(invstd2), _native.ptr(mdy),
                                                _native.ptr(mdyx), _native.ptr(coef), cout, _native.stream_ptr()),

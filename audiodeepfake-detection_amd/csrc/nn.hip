@@ -958,7 +958,8 @@ extern "C" int afd_prelu_pool_backward_affine(const float* u, const float* slope
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, double count, float eps,
                                    float momentum, float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   long long* __restrict__ nbt, double* __restrict__ count_out) {
+                                   long long* __restrict__ nbt, double* __restrict__ count_out,
+                                   float* __restrict__ fold_tab) {
     const double cnt = count < 0.0 ? sums[2 * C] : count;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
         const double m = sums[c] / cnt;
@@ -966,6 +967,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
         if (var < 0.0) var = 0.0;
         mean[c] = (float)m;
         invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (fold_tab) {  // [C][2] = (mean, invstd): the table the folded convolution launches read
+            fold_tab[2 * c] = mean[c];
+            fold_tab[2 * c + 1] = invstd[c];
+        }
         if (running_mean) {
             const double unbiased = var * (cnt / (cnt > 1.0 ? cnt - 1.0 : 1.0));
             running_mean[c] = running_mean[c] * (1.f - momentum) + (float)m * momentum;
@@ -980,32 +985,41 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int C, doubl
 
 __global__ void bn_bwd_means_kernel(const double* __restrict__ sums, int C, double count,
                                     const double* __restrict__ count_dev, float* __restrict__ mdy,
-                                    float* __restrict__ mdyx) {
+                                    float* __restrict__ mdyx, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, float* __restrict__ tab4) {
     const double cnt = count < 0.0 ? *count_dev : count;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
-        mdy[c] = (float)(sums[c] / cnt);
-        mdyx[c] = (float)(sums[C + c] / cnt);
+        const float a = (float)(sums[c] / cnt), b = (float)(sums[C + c] / cnt);
+        mdy[c] = a;
+        mdyx[c] = b;
+        if (tab4) {  // [C][4] = (mean, invstd, mean of g, mean of g xhat): afd_conv3x3_backward_data_bnapply's table
+            tab4[4 * c] = mean[c];
+            tab4[4 * c + 1] = invstd[c];
+            tab4[4 * c + 2] = a;
+            tab4[4 * c + 3] = b;
+        }
     }
 }
 
 extern "C" int afd_bn_finalize(const double* sums, int C, double count, float eps, float momentum,
                                float* mean, float* invstd, float* running_mean, float* running_var,
-                               long long* nbt, double* count_out, afd_stream_t stream) {
+                               long long* nbt, double* count_out, float* fold_tab, afd_stream_t stream) {
     if (!sums || !mean || !invstd || C < 1) return afd::fail(AFD_ERR_ARG, "bn finalize: bad argument");
     if ((running_mean == nullptr) != (running_var == nullptr)) return afd::fail(AFD_ERR_ARG, "bn finalize: running stats");
     afd::ScopedBytes timing(AFD_K_BATCHNORM, 40.0 * C, AFD_STREAM);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, AFD_STREAM, sums, C, count, eps,
-                       momentum, mean, invstd, running_mean, running_var, nbt, count_out);
+                       momentum, mean, invstd, running_mean, running_var, nbt, count_out, fold_tab);
     return afd::check_launch("bn_finalize_kernel");
 }
 
 extern "C" int afd_bn_backward_means(const double* sums, int C, double count, const double* count_dev,
-                                     float* mdy, float* mdyx, afd_stream_t stream) {
-    if (!sums || !mdy || !mdyx || C < 1 || (count < 0.0 && !count_dev))
+                                     float* mdy, float* mdyx, const float* mean, const float* invstd, float* tab4,
+                                     afd_stream_t stream) {
+    if (!sums || !mdy || !mdyx || C < 1 || (count < 0.0 && !count_dev) || (tab4 && (!mean || !invstd)))
         return afd::fail(AFD_ERR_ARG, "bn backward means: bad argument");
     afd::ScopedBytes timing(AFD_K_BATCHNORM, 24.0 * C, AFD_STREAM);
     hipLaunchKernelGGL(bn_bwd_means_kernel, dim3((C + 255) / 256), dim3(256), 0, AFD_STREAM, sums, C, count,
-                       count_dev, mdy, mdyx);
+                       count_dev, mdy, mdyx, mean, invstd, tab4);
     return afd::check_launch("bn_bwd_means_kernel");
 }
 

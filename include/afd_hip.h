@@ -446,11 +446,16 @@ int afd_bn_fold_backward_affine(const double* sums, double count, const double* 
                                 const float* invstd, float* alpha, float* beta, int Cin, afd_stream_t stream);
 int afd_bn_backward_coef(const float* mean, const float* invstd, const float* mdy, const float* mdyx,
                          float* coef, int C, afd_stream_t stream);
+/* fold_tab (may be NULL): also writes the pairs [C][2] = (mean, invstd) -- the table of a BatchNorm whose normalisation the
+ * next convolution applies while it loads (afd_conv3x3_forward_fold). */
 int afd_bn_finalize(const double* sums, int C, double count, float eps, float momentum, float* mean,
                     float* invstd, float* running_mean, float* running_var, long long* nbt,
-                    double* count_out, afd_stream_t stream);
+                    double* count_out, float* fold_tab, afd_stream_t stream);
+/* tab4 (may be NULL; needs mean and invstd): also writes [C][4] = (mean, invstd, mdy, mdyx), the table
+ * afd_conv3x3_backward_data_bnapply takes. */
 int afd_bn_backward_means(const double* sums, int C, double count, const double* count_dev,
-                          float* mdy, float* mdyx, afd_stream_t stream);
+                          float* mdy, float* mdyx, const float* mean, const float* invstd, float* tab4,
+                          afd_stream_t stream);
 
 /* Dropout(p) + permute(0,2,1,3).contiguous() (models.py:277,307): x [B][C][H][W] ->
  * y [B][H][C][W]; inverse != 0 runs the backward (dy [B][H][C][W] -> dx [B][C][H][W]) */
