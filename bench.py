@@ -325,7 +325,7 @@ def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads:
     root = tempfile.mkdtemp(prefix=f"afd_bench_wav_{rank}_")
     try:
         rng = np.random.default_rng(1234 + rank)
-        secs, files = 40, 16  # 2 x 16 files x 40 s: 896 one-second frames in the 70 % train split
+        secs, files = 40, 40  # 2 x 40 files x 40 s: 2 240 one-second frames in the 70 % train split (epochs of 17 batches)
         for name in ("A_real", "B_fake"):
             os.makedirs(os.path.join(root, name))
             for i in range(files):
