@@ -370,7 +370,9 @@ class NativeFrameLoader:
                 done += 1
             if done < self.AUTO_PROBE + 1:
                 return  # a short epoch: nothing left to hand over (the choice is made on a later, longer one)
-            self.consumer_ms = sum(gaps[1:]) / len(gaps[1:])  # the first gap holds the consumer's warm-up
+            # the median of the gaps after the first (which holds the consumer's warm-up): one stall -- a garbage
+            # collection, a checkpoint -- does not decide
+            self.consumer_ms = sorted(gaps[1:])[len(gaps[1:]) // 2]
             self._auto_choice = 1 if self.consumer_ms >= self.AUTO_STEP_MS else 0
             mode = self._auto_choice
             start = done
