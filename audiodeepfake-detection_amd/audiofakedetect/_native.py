@@ -39,6 +39,7 @@ _SIGNATURES = {
     "afd_wpt_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "afd_wpt_forward": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_i,
                               c_u, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_sz, c_p]),
+    "afd_wpt_analysis_step": (c_i, [c_p, c_i, c_i, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i, c_p, c_p, c_p]),
     "afd_wpt_lattice": (c_i, [ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i] + [ctypes.POINTER(ctypes.c_double)] * 4),
     "afd_rccl_unique_id": (c_i, [c_p]),
     "afd_rccl_init": (c_i, [c_p, c_i, c_i]),

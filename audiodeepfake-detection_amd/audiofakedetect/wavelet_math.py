@@ -94,8 +94,47 @@ def wpt_forward(
         *_channel_stats(mean, std), _native.ptr(out),
         _native.ptr(ws), ws_bytes, _native.stream_ptr(),
     )
+    if rc == _ERR_UNSUPPORTED and n > _LDS_FRAME:
+        # The kernels keep a frame's packet tree in LDS: frames beyond about 27 000 samples (1.2 s at 22 050 Hz) do not fit.
+        # Split level 1 off from global memory (afd_wpt_analysis_step) and transform the two children -- frames of half the
+        # length -- on their own (recursively: a 4 s frame splits twice).  In frequency order the packets of the
+        # approximation child come first and those of the detail child follow REVERSED (the Gray-code rule of
+        # ptwt's get_level: order_{k+1} = [a + p for p in order_k] + [d + p for p in reversed(order_k)]).
+        raw = _wpt_long_raw(x, wavelet, max_lev)
+        if flags == 0:
+            return raw
+        _native.check(lib.afd_packet_block_norm(
+            _native.ptr(raw), b, t_len, 1 << max_lev, None, flags, float(power), 1e-12, *_channel_stats(mean, std),
+            _native.ptr(out), _native.stream_ptr()), "afd_packet_block_norm")
+        return out
     _native.check(rc, "afd_wpt_forward")
     return out
+
+
+_ERR_UNSUPPORTED = -3
+_LDS_FRAME = 20000  # (frames at least this long may exceed what the LDS-resident kernels hold; shorter ones never do)
+
+
+def _wpt_long_raw(x: torch.Tensor, wavelet: Wavelet, level: int) -> torch.Tensor:
+    """Raw packet coefficients [B, 1, T, 2^level] of frames too long for the LDS-resident kernels: one analysis step
+    from global memory, then both children as frames of their own."""
+    lib = _native.load()
+    b, n = x.shape
+    length = wavelet.dec_len
+    n1 = lib.afd_wpt_out_len(n, length, 1)
+    ca = torch.empty((b, n1), dtype=torch.float32, device=x.device)
+    cd = torch.empty((b, n1), dtype=torch.float32, device=x.device)
+    lo, hi = _native.float_array(wavelet.dec_lo), _native.float_array(wavelet.dec_hi)
+    step = 65535  # (grid limit of the step kernel's batch axis)
+    for b0 in range(0, b, step):
+        nb = min(step, b - b0)
+        _native.check(lib.afd_wpt_analysis_step(_native.ptr(x[b0:]), nb, n, lo, hi, length, _native.ptr(ca[b0:]),
+                                                _native.ptr(cd[b0:]), _native.stream_ptr()), "afd_wpt_analysis_step")
+    if level == 1:
+        return torch.stack((ca, cd), dim=-1).unsqueeze(1)
+    pa = wpt_forward(ca, wavelet, level - 1)   # [B, 1, T, P/2] each, in their own frequency order
+    pd = wpt_forward(cd, wavelet, level - 1)
+    return torch.cat((pa, pd.flip(-1)), dim=-1)
 
 
 def _channel_stats(mean, std) -> Tuple[float, float, float, float]:

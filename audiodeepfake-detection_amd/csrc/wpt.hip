@@ -241,6 +241,41 @@ __global__ void __launch_bounds__(kThreads) wpt_fused_kernel(const WptParams p) 
 
 int child_len(int n, int L) { return (n + L - 2 + (n & 1)) / 2; }
 
+// One analysis step of long frames straight from global memory (afd_wpt_analysis_step): thread = output position of one
+// frame, both children.  For frames whose packet tree does not fit LDS the host splits level 1 (2, ...) off with this
+// kernel and hands the children -- frames of half the length -- to the LDS-resident kernels.
+struct StepParams {
+    const float* x;
+    float* ca;
+    float* cd;
+    int B, N, L, n_out;
+    float lo[kMaxTaps], hi[kMaxTaps];
+};
+
+__global__ void __launch_bounds__(256) wpt_step_kernel(const StepParams p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= p.n_out) return;
+    const float* x = p.x + (size_t)b * p.N;
+    const int j0 = 2 * i + 1;
+    float a = 0.f, d = 0.f;
+    if (j0 - (p.L - 1) >= 0 && j0 < p.N) {
+        for (int m = 0; m < p.L; ++m) {
+            const float v = x[j0 - m];
+            a = fmaf(p.lo[m], v, a);
+            d = fmaf(p.hi[m], v, d);
+        }
+    } else {
+        for (int m = 0; m < p.L; ++m) {
+            const float v = x[reflect_idx(j0 - m, p.N)];
+            a = fmaf(p.lo[m], v, a);
+            d = fmaf(p.hi[m], v, d);
+        }
+    }
+    p.ca[(size_t)b * p.n_out + i] = a;
+    p.cd[(size_t)b * p.n_out + i] = d;
+}
+
 // fills n[], K1, K2, G; returns 0 or an error
 int make_plan(WptParams& p) {
     p.n[0] = p.N;
@@ -332,6 +367,25 @@ int wpt3_forward(const float* x, int B, int N, const float* dec_lo, const float*
                  int level, unsigned flags, float power, float eps, float mean, float std, float sign_mean,
                  float sign_std, float* out, void* ws, size_t ws_bytes, hipStream_t stream);
 }  // namespace afd
+
+extern "C" int afd_wpt_analysis_step(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
+                                     float* ca, float* cd, afd_stream_t stream) {
+    if (!x || !dec_lo || !dec_hi || !ca || !cd) return afd::fail(AFD_ERR_ARG, "wpt step: null pointer");
+    if (B < 1 || B > 65535 || N < 2) return afd::fail(AFD_ERR_ARG, "wpt step: bad shape B=%d N=%d", B, N);
+    if (L < 2 || L > kMaxTaps || (L & 1)) return afd::fail(AFD_ERR_ARG, "wpt step: filter length %d", L);
+    if (L - 2 + (N & 1) >= N) return afd::fail(AFD_ERR_UNSUPPORTED, "wpt step: reflect pad %d >= frame length %d", L - 2 + (N & 1), N);
+    StepParams p{};
+    p.x = x; p.ca = ca; p.cd = cd; p.B = B; p.N = N; p.L = L;
+    p.n_out = child_len(N, L);
+    for (int m = 0; m < L; ++m) {
+        p.lo[m] = dec_lo[m];
+        p.hi[m] = dec_hi[m];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    afd::ScopedTiming timing(AFD_K_WPT, 4.0 * B * ((double)N + 2.0 * p.n_out), s);
+    hipLaunchKernelGGL(wpt_step_kernel, dim3((p.n_out + 255) / 256, B), dim3(256), 0, s, p);
+    return afd::check_launch("wpt_step_kernel");
+}
 
 extern "C" size_t afd_wpt_workspace_bytes(int B, int N, int L, int level) {
     if (B < 1 || N < 2 || L < 2 || (L & 1) || L > kMaxTaps || level < 1 || level > kMaxLevel) return 0;

@@ -95,6 +95,13 @@ int afd_wpt_forward(const float* x, int B, int N, const float* dec_lo, const flo
                     int L, int level, unsigned flags, float power, float eps, float mean,
                     float std, float sign_mean, float sign_std, float* out, void* ws, size_t ws_bytes,
                     afd_stream_t stream);
+/* One two-channel analysis step of frames of ANY length straight from global memory: ca / cd [B][n1],
+ * n1 = afd_wpt_out_len(N, L, 1) (reflect mode, the step of afd_wpt_forward).  afd_wpt_forward keeps a frame's packet
+ * tree in LDS and returns AFD_ERR_UNSUPPORTED for frames beyond about 27 000 samples; the host then splits the top
+ * level(s) off with this call and transforms the children (the packets of a detail child come out in reversed
+ * frequency order: wavelet_math.wpt_forward). */
+int afd_wpt_analysis_step(const float* x, int B, int N, const float* dec_lo, const float* dec_hi, int L,
+                          float* ca, float* cd, afd_stream_t stream);
 
 /* The orthogonal lattice the level-9..14 kernel runs a filter bank in (host only, no GPU; exported for the tests):
  * dec_lo, dec_hi [host] L taps -> alpha, beta [L/2] stage coefficients, scales[2] = output scales of (cA, cD),

@@ -290,3 +290,30 @@ def test_per_node_estimators_match_reference_welford():
         assert torch.equal(gm.cpu(), final[k]["mean"].cpu()) and gm.shape == (1,)
         assert abs(float(gm) - float(rm)) <= 1e-6 * max(1.0, abs(float(rm))) + 2e-7
         assert abs(float(gs) - float(rs)) <= 1e-5 * float(rs) + 1e-7
+
+
+@pytest.mark.parametrize("name,n,level", [("sym8", 44100, 8), ("coif4", 44100, 8), ("haar", 88200, 9), ("coif10", 30000, 7),
+                                          ("sym5", 66150, 1), ("db4", 48000, 10)])
+def test_frames_longer_than_the_lds_resident_tree(name, n, level):
+    """Frames beyond about 27 000 samples do not fit the kernels' LDS-resident packet tree: `wpt_forward` splits the top
+    level(s) off with `afd_wpt_analysis_step` and transforms the children (the reference takes any window size:
+    `--window-size` / `--seconds`).  Raw coefficients against the float64 oracle at the usual bar, then the log / sign
+    epilogue against the same formulas on the oracle's coefficients."""
+    g = torch.Generator().manual_seed(n + level)
+    x = (0.1 * torch.randn(3, n, generator=g)).clamp_(-1, 1)
+    x[0, 0] = 1.0
+    x[1, -1] = -1.0
+    w = wavelets.Wavelet(name)
+    got, _ = Packets(name, max_lev=level)(x.cuda())
+    ref = wpt_oracle.packet_features(x.double().numpy(), w.dec_lo, level, dec_hi=w.dec_hi)
+    assert tuple(got.shape) == ref.shape
+    _check_coeffs(got.cpu().double().numpy(), ref)
+    both, _ = Packets(name, max_lev=level, log_scale=True, loss_less=True)(x.unsqueeze(1).cuda())
+    both = both.cpu().double().numpy()
+    coef = ref[:, 0]
+    d = COEF_RTOL * np.max(np.abs(coef))
+    lref = np.log(coef ** 2 + 1e-12)
+    bound = 1e-5 + 2 * np.abs(coef) * d / (coef ** 2 + 1e-12) + 2e-6 * np.abs(lref)
+    assert both.shape[1] == 2 and np.all(np.abs(both[:, 0] - lref) <= bound)
+    sure = np.abs(coef) > d
+    assert np.array_equal(both[:, 1][sure], np.where(coef < 0, -1.0, 1.0)[sure])
