@@ -256,10 +256,14 @@ extern "C" int afd_stft_forward(const float* x, int B, int N, int n_fft, int hop
     p.FP = p.MP / 2;
     p.flags = flags; p.power = power; p.eps = eps; p.mean = mean; p.std = std;
     // frames per workgroup: 4 waves x 32, shrunk until the padded segment fits LDS
+    // (any number of frames per workgroup works -- lanes past it idle -- so a large hop shrinks the group as far as it must:
+    // hop 1024 leaves 28 frames per workgroup)
+    constexpr long kSegMax = 29000;
+    if (n_fft > kSegMax) return afd::fail(AFD_ERR_UNSUPPORTED, "stft: n_fft %d does not fit LDS", n_fft);
     int tg = 128;
-    while (tg > 32 && ((long)(tg - 1) * hop + n_fft) > 29000) tg >>= 1;
-    if ((long)(tg - 1) * hop + n_fft > 29000) return afd::fail(AFD_ERR_UNSUPPORTED, "stft: hop %d too large", hop);
-    if (p.T < tg) tg = ((p.T + 31) / 32) * 32;
+    if ((long)(tg - 1) * hop + n_fft > kSegMax) tg = (int)((kSegMax - n_fft) / hop) + 1;
+    const int t32 = ((p.T + 31) / 32) * 32;
+    if (t32 < tg) tg = t32;
     p.TG = tg;
     p.seg = (tg - 1) * hop + n_fft;
     p.segpad = (p.seg + 3) & ~3;

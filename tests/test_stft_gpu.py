@@ -32,7 +32,7 @@ def test_reference_test_shapes():
     assert out.shape == (2, 1, 256, 101)
 
 
-@pytest.mark.parametrize("n_fft,hop", [(511, 220), (512, 200), (255, 100)])
+@pytest.mark.parametrize("n_fft,hop", [(511, 220), (512, 200), (255, 100), (511, 1024), (1023, 512), (64, 7), (2048, 3000)])
 def test_power_spectrum_matches_torch_stft(n_fft, hop):
     x = _x()
     got, _ = STFTLayer(n_fft=n_fft, hop_length=hop)(x.cuda())
