@@ -505,19 +505,23 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ mdy, const float* __restrict__ mdyx,
                                     float* __restrict__ dx, float* __restrict__ dslope, int C,
-                                    int HW, double* __restrict__ dxsum) {
-    const size_t plane = blockIdx.y;
-    const int c = (int)(plane % C);
+                                    int HW, double* __restrict__ dxsum, int N, int G) {
+    // workgroup (x, y): channel c = y % C of the images G (y / C) .. + G - 1 (G = 1: one plane per workgroup; small planes
+    // -- the level-8 dilated stack -- share a workgroup, whose two atomics then close 16 k elements instead of 2 k)
+    const int c = (int)(blockIdx.y % C);
+    const int n_begin = (int)(blockIdx.y / C) * G;
+    const int n_end = min(n_begin + G, N);
     const bool act = slope != nullptr;
     const float a = act ? slope[0] : 1.f;
     const float m = mean[c], is = invstd[c];
     const float gs = is * (gamma ? gamma[c] : 1.f);
     const float k0 = mdy[c], k1 = mdyx[c];
-    const size_t base = plane * (size_t)HW;
+    float ds = 0.f, u0 = 0.f, u1 = 0.f;
+    for (int n = n_begin; n < n_end; ++n) {
+    const size_t base = ((size_t)n * C + c) * (size_t)HW;
     const float* xp = x + base;
     const float* gp = dy + base;
     float* op = dx + base;
-    float ds = 0.f, u0 = 0.f, u1 = 0.f;
     auto one = [&](float zz, float gy) {
         const float v = act ? prelu(zz, a) : zz;
         const float xh = (v - m) * is;
@@ -536,6 +540,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
                    *reinterpret_cast<float4*>(op + i) =
                        make_float4(one(v.x, g.x), one(v.y, g.y), one(v.z, g.z), one(v.w, g.w));
                });
+    }
     if (act || dxsum) {
         block_sum3(ds, u0, u1);
         if (threadIdx.x == 0 && act && ds != 0.f) atomicAdd(dslope, ds);
@@ -1139,6 +1144,14 @@ extern "C" int afd_bn_backward_coef(const float* mean, const float* invstd, cons
 // few channels (the dilated stack's BatchNorms have 3): a plane is shared by workgroups of at least 16 k elements until
 // about six of them sit on a CU (384 workgroups on 256 CUs ran at 2.4 TB/s: 84 -> 64 us); more than that and the
 // double atomics on the 2 C addresses take over (3 072 workgroups: 95 us)
+// small planes (the level-8 dilated stack: 13 channels of 64 x 32): a workgroup takes the planes of several images so that
+// it sums at least 16 k elements -- one workgroup per 2 048-element plane was 1 664 workgroups ending in 3 328 double atomics
+// on 26 addresses (26 us for 1.7 MB; round 6)
+static int small_plane_rows(int gy, int N, int HW) {
+    while (gy > 1 && (long)HW * ((N + gy - 1) / gy) < 16384) gy = (gy + 1) / 2;
+    return gy;
+}
+
 static int plane_splits(int C, int gy, int HW) {
     int gz = 1;
     while ((long)C * gy * gz < 1024 && gz < 16 && HW / (gz * 2) >= 16384) gz *= 2;
@@ -1153,6 +1166,7 @@ extern "C" int afd_bn_stats(const float* x, const float* slope, double* sums, in
     if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "bn stats: memset: %s", hipGetErrorString(e));
     int gy = N;
     while ((long)gy * C > 4096 && gy > 1) gy = (gy + 1) / 2;
+    gy = small_plane_rows(gy, N, HW);
     const int gz = plane_splits(C, gy, HW);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(C, gy, gz), dim3(kT), 0, AFD_STREAM, x, slope, sums, N, C, HW);
     return afd::check_launch("bn_stats_kernel");
@@ -1181,6 +1195,7 @@ extern "C" int afd_bn_backward_stats(const float* x, const float* slope, const f
     if (e != hipSuccess) return afd::fail(AFD_ERR_HIP, "bn bwd stats: memset: %s", hipGetErrorString(e));
     int gy = N;
     while ((long)gy * C > 4096 && gy > 1) gy = (gy + 1) / 2;
+    gy = small_plane_rows(gy, N, HW);
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(C, gy, plane_splits(C, gy, HW)), dim3(kT), 0, AFD_STREAM, x, slope, dy, mean,
                        invstd, sums, N, C, HW);
     return afd::check_launch("bn_bwd_stats_kernel");
@@ -1208,8 +1223,11 @@ extern "C" int afd_bn_backward_apply_sums(const float* x, const float* slope, co
     unsigned bx = (unsigned)(HW / 16384);
     if (bx < 1) bx = 1;
     if (bx > 16) bx = 16;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx, N * C), dim3(kT), 0, AFD_STREAM, x,
-                       slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, C, HW, dx_sums);
+    int G = 1;  // images per workgroup: small planes share one (at least 16 k elements, at most 16 images)
+    while (G < 16 && G < N && (long)HW * G < 16384) G *= 2;
+    const int ngroups = (N + G - 1) / G;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx, ngroups * C), dim3(kT), 0, AFD_STREAM, x,
+                       slope, dy, mean, invstd, gamma, mean_dy, mean_dy_xhat, dx, dslope, C, HW, dx_sums, N, G);
     return afd::check_launch("bn_bwd_apply_kernel");
 }
 
