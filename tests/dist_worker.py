@@ -104,13 +104,50 @@ def gpu_dcnn(rank, world):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(total, 1, packets, frames_t, generator=g).cuda()
     y = torch.randint(0, 2, (total,), generator=g).cuda()
+    mine = slice(rank * per_rank, (rank + 1) * per_rank)
+
+    def tapped_forward(model, inp):
+        ops.debug_taps = []
+        try:
+            return model(inp), ops.debug_taps
+        finally:
+            ops.debug_taps = None
+
+    ref = make(False)  # no cross-rank statistics: plain full-batch step in this process
+    ropt = ops.FusedAdam(ref.parameters(), lr=4e-4, weight_decay=1e-3)
+    ropt.zero_grad()
+    rout, rtaps = tapped_forward(ref, x)
+
     net = make(True)
     wrapped = DataParallelRCCL(net)
     opt = ops.FusedAdam(net.parameters(), lr=4e-4, weight_decay=1e-3)
     opt.zero_grad()
     ops.collective_counters(reset=True)
-    out = wrapped(x[rank * per_rank:(rank + 1) * per_rank])
-    loss = ops.CrossEntropyLoss()(out, y[rank * per_rank:(rank + 1) * per_rank])
+    out, taps = tapped_forward(wrapped, x[mine])
+    # The shard's BatchNorm statistics are the full batch's up to the rounding of a different summation order, so a
+    # 2x2 max-pool near tie or a PReLU zero crossing may go the other way in a handful of positions; each re-routes one
+    # gradient element, which at 8 frames is 1e-3 of the gradient norm (tests/test_dcnn_gpu.py documents the same for
+    # the reference's own fp32 run).  Those decisions are aligned with the full-batch run's before backward -- what is
+    # compared is the arithmetic of the sharded step, to 1e-4, and the number of such positions is bounded.
+    assert len(taps) == len(rtaps)
+    flips = decisions = 0
+    for (kind, t), (rkind, r) in zip(taps, rtaps):
+        assert kind == rkind and t.shape[1:] == r.shape[1:] and r.shape[0] == total, (kind, t.shape, r.shape)
+        r = r[mine]
+        diff = (t != r) if kind == "pool" else ((t <= 0) != (r <= 0))
+        decisions += diff.numel()
+        nd = int(diff.sum())
+        if nd:
+            flips += nd
+            if kind == "pool":
+                t.data[diff] = r[diff]
+            else:
+                assert t.data[diff].abs().max().item() <= 2e-5
+                tiny = torch.full_like(t.data[diff], 1e-30)
+                t.data[diff] = torch.where(r[diff] <= 0, -tiny, tiny)
+    assert flips <= max(8, decisions // 100000), f"{flips} routing differences in {decisions} decisions"
+    ops.CrossEntropyLoss()(rout, y).backward()
+    loss = ops.CrossEntropyLoss()(out, y[mine])
     start_gradient_allreduce(opt)  # as left behind by a step whose backward raised before its callbacks ran
     start_gradient_allreduce(opt)  # the all-reduce is issued (once) by the end-of-backward hook
     loss.backward()
@@ -125,15 +162,10 @@ def gpu_dcnn(rank, world):
     grads = (opt.flat_grad * scale).clone()
     bn_rm = net.cnn[3].running_mean.clone()
 
-    ref = make(False)  # no cross-rank statistics: plain full-batch step in this process
-    ropt = ops.FusedAdam(ref.parameters(), lr=4e-4, weight_decay=1e-3)
-    ropt.zero_grad()
-    rout = ref(x)
-    ops.CrossEntropyLoss()(rout, y).backward()
-    err = (out - rout[rank * per_rank:(rank + 1) * per_rank]).abs().max().item()
+    err = (out - rout[mine]).abs().max().item()
     assert err <= 1e-4, f"sharded logits differ from full-batch logits: {err}"
     rel = ((grads - ropt.flat_grad).norm() / ropt.flat_grad.norm()).item()
-    assert rel <= 3e-3, f"all-reduced gradients differ from full-batch gradients: {rel}"
+    assert rel <= 1e-4, f"all-reduced gradients differ from full-batch gradients: {rel} ({flips} routing positions aligned)"
     assert torch.allclose(bn_rm, ref.cnn[3].running_mean, atol=1e-5)
     opt.step(grad_scale=scale)
     ropt.step()

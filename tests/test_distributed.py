@@ -54,7 +54,9 @@ def test_world2_sharded_dcnn_step_equals_full_batch_step(geometry):
     level-8 / STFT shapes (4 frames per rank) and the level-14 benchmark shape (2 frames per rank).  Each geometry
     activates a different set of fused units -- the four input folds, both BatchNorm-backward epilogues, the one-pass
     block 2 -- and each unit's packed BatchNorm sums must come out of a real two-rank reduction: 8 + 8 + 1 collectives,
-    sharded logits / gradients / running statistics / Adam update equal to the full batch's."""
+    sharded logits / gradients / running statistics / Adam update equal to the full batch's -- the gradients to 1e-4 with
+    the handful of max-pool near ties / PReLU zero crossings that went the other way (the shard sums its statistics in
+    another order) aligned with the full-batch run first, as tests/test_dcnn_gpu.py does against the reference's run."""
     _run_world2("gpu_dcnn", extra_env={"AFD_TEST_GEOMETRY": geometry}, timeout=600)
 
 
