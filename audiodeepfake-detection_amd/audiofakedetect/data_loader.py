@@ -262,6 +262,8 @@ class NativeFrameLoader:
 
     AUTO_STEP_MS = 15.0  # prefetch pays above this consumer step time (level-14 steps: 23-45 ms), not on the 5 ms steps
     AUTO_PROBE = 3       # consumer gaps measured before the choice
+    WORKER_PAUSE = 0.2   # the prefetch thread stays idle for this part of the measured step after handing a batch over ...
+    WORKER_PAUSE_CAP_MS = 10.0  # ... at most this long
 
     def __init__(self, dataset: "CustomDataset", batch_size: int, device, shuffle: bool = True, seed: int = 0,
                  drop_last: bool = True, rank: int = 0, world: int = 1, threads: int = 8, prefetch="auto",
@@ -407,7 +409,7 @@ class NativeFrameLoader:
             return False
 
         # (tools/e2e_probe.py, level-14 step, same box: resident batch 43.96 ms, prefetching 44.64, with this pause 44.44-44.49)
-        delay = min(0.010, 0.2e-3 * self.consumer_ms) if self.consumer_ms else 0.0
+        delay = min(1e-3 * self.WORKER_PAUSE_CAP_MS, 1e-3 * self.WORKER_PAUSE * self.consumer_ms) if self.consumer_ms else 0.0
 
         def worker() -> None:
             try:

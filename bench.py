@@ -353,9 +353,11 @@ def end_to_end(trainer, batch_size: int, rank: int, device, steps: int, threads:
                 trainer._run_batch(0, batch)
                 done += 1
                 if done >= steps + untimed:
+                    # (the clock stops before the loop is left: abandoning an epoch half way makes the loader wait for its
+                    # background thread to notice, up to 50 ms that no step of a full epoch pays)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
                     break
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
         return {"value": batch_size * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                 "frames_on_disk": len(ds), "reader_threads": threads,
                 "loader_prefetch": loader._auto_choice, "loader_measured_step_ms": loader.consumer_ms,
@@ -761,6 +763,17 @@ def main() -> None:
                     "algorithmic_bytes_per_frame": k["work"] / timed_steps / batch_size,
                     "hbm_bytes_per_step_pmc": class_traffic(pmc, "wpt")}
 
+    # (before the other legs build their models: the process is then in the state a trainer is in -- its objects frozen
+    # out of the garbage collector after the second step, nothing else allocated since)
+    e2e = None
+    # (single-process runs only: with several ranks a failure of this leg on one rank would leave the others
+    # waiting in a collective)
+    if kind == "train" and a.e2e_steps > 0 and world == 1:
+        try:
+            e2e = end_to_end(trainer, batch_size, rank, device, a.e2e_steps)
+            log(f"end to end (WAV files -> loader -> H2D -> step): {e2e['ms_per_step']:.3f} ms/step")
+        except Exception as exc:  # noqa: BLE001 - the headline figure does not depend on this leg
+            e2e = {"error": f"{type(exc).__name__}: {exc}"}
     fe_lines = None
     if a.workload == "coif4-l14" and world == 1 and a.frontends:
         try:
@@ -774,15 +787,6 @@ def main() -> None:
         secondary = secondary_lines(device, _native, rank, cpu_threads=a.cpu_threads)
         log("secondary: " + "; ".join(f"{f['workload']}: {f['ms_per_step']:.3f} ms" if "ms_per_step" in f else
                                       f"{f['workload']}: {f['error']}" for f in secondary))
-    e2e = None
-    # (single-process runs only: with several ranks a failure of this leg on one rank would leave the others
-    # waiting in a collective)
-    if kind == "train" and a.e2e_steps > 0 and world == 1:
-        try:
-            e2e = end_to_end(trainer, batch_size, rank, device, a.e2e_steps)
-            log(f"end to end (WAV files -> loader -> H2D -> step): {e2e['ms_per_step']:.3f} ms/step")
-        except Exception as exc:  # noqa: BLE001 - the headline figure does not depend on this leg
-            e2e = {"error": f"{type(exc).__name__}: {exc}"}
     cpu = None
     log(f"kernel classes (ms/step): { {k: round(v['ms_per_step'], 3) for k, v in classes.items()} }")
     if rank == 0 and world == 1 and a.cpu_frames > 0 and kind != "eval":
