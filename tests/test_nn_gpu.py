@@ -79,6 +79,19 @@ CONV_CASES = [
     (2, 64, 12, 32, 32, 3, 1, 1),
     (2, 96, 7, 40, 128, 3, 1, 1),
     (1, 32, 9, 24, 96, 3, 1, 1),
+    # every other shape the few-channel matrix-core kernels accept (dilconv_mfma.hip: Cin == Cout in 5..16, (k, dilation) in
+    # (3, 1) / (5, 2) / (7, 4), any padding up to the full one): plain 3x3 layers, no padding, "same" and full padding, wide
+    # and odd images, 5 and 16 channels
+    (2, 8, 20, 50, 8, 3, 1, 1),
+    (2, 16, 17, 33, 16, 3, 0, 1),
+    (2, 10, 24, 24, 10, 3, 2, 1),
+    (1, 5, 40, 41, 5, 7, 2, 4),
+    (2, 16, 30, 36, 16, 5, 4, 2),
+    (2, 16, 30, 36, 16, 5, 8, 2),
+    (1, 6, 30, 600, 6, 3, 1, 1),
+    (1, 9, 45, 200, 9, 5, 2, 2),
+    (2, 7, 50, 30, 7, 7, 12, 4),
+    (2, 11, 31, 29, 11, 7, 24, 4),
     # LCNN shapes (models.py:85-110)
     (2, 1, 101, 256, 64, 5, 2, 1),
     (2, 48, 25, 64, 128, 3, 1, 1),
